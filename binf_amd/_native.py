@@ -1,0 +1,231 @@
+"""
+ctypes binding of libbinf_hip.so (the C ABI declared in include/binf_hip.h).
+
+The HIP library IS the product path: there is no CPU or PyTorch fallback.  If
+the shared object is missing or a call fails, this module raises.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libbinf_hip.so')
+
+MODE_EXACT = 0
+MODE_FMA = 1
+
+E_ARG = -1
+E_UNSUPPORTED = -2
+E_ALIAS = -3
+
+
+class NativeLibraryError(RuntimeError):
+    """libbinf_hip.so is missing, stale or failed."""
+
+
+_lib = None
+
+_vp = ctypes.c_void_p
+_i64 = ctypes.c_int64
+_i32 = ctypes.c_int32
+_f64 = ctypes.c_double
+
+# name -> (restype, argtypes); must list every symbol of include/binf_hip.h
+SIGNATURES = {
+    'binf_abi_version': (_i32, []),
+    'binf_last_error': (_i32, [ctypes.c_char_p, ctypes.c_size_t]),
+    'binf_hmc_sample_gauss_f64': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                         _f64, _vp, _i64, _i64, _i32, _f64,
+                                         _f64, _i32, _f64, _f64, _i32, _vp]),
+    'binf_row_sum_f64': (_i32, [_vp, _vp, _i64, _i64, _i32, _f64, _f64, _vp]),
+    'binf_leapfrog_kick_f64': (_i32, [_vp, _vp, _f64, _vp, _i32, _i64, _i64,
+                                      _i32, _vp]),
+    'binf_leapfrog_drift_f64': (_i32, [_vp, _vp, _f64, _vp, _i64, _i64, _i32,
+                                       _vp]),
+    'binf_gauss_grad_f64': (_i32, [_vp, _vp, _f64, _f64, _i64, _i64, _vp]),
+    'binf_accept_select_f64': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                      _i32, _f64, _f64, _i64, _i64, _vp]),
+    'binf_pairwise_tree_height': (_i32, [_i64]),
+    'binf_pairwise_leaf': (_i32, [_i64, _i32, _i32,
+                                  ctypes.POINTER(_i64), ctypes.POINTER(_i64),
+                                  ctypes.POINTER(_i32), ctypes.POINTER(_i32)]),
+}
+
+ABI_VERSION = 1
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NativeLibraryError(
+                '%s not found: build it with `python -c "import '
+                '__graft_entry__ as g; g.build()"` (hipcc --offload-arch='
+                'gfx950).  binf_amd has no CPU fallback.' % LIB_PATH)
+        try:
+            L = ctypes.CDLL(LIB_PATH)
+        except OSError as e:
+            raise NativeLibraryError('cannot load %s: %s' % (LIB_PATH, e))
+        for name, (res, args) in SIGNATURES.items():
+            try:
+                f = getattr(L, name)
+            except AttributeError:
+                raise NativeLibraryError('%s does not export %s (stale '
+                                         'build?)' % (LIB_PATH, name))
+            f.restype = res
+            f.argtypes = args
+        v = L.binf_abi_version()
+        if v != ABI_VERSION:
+            raise NativeLibraryError('ABI version %d != expected %d'
+                                     % (v, ABI_VERSION))
+        _lib = L
+    return _lib
+
+
+def last_error():
+    buf = ctypes.create_string_buffer(512)
+    lib().binf_last_error(buf, 512)
+    return buf.value.decode('utf-8', 'replace')
+
+
+def check(rc, what):
+    """Map a C-ABI return code onto the exception classes the reference
+    raises for the same mistakes (ValueError / NotImplementedError)."""
+    if rc == 0:
+        return
+    msg = '%s: %s' % (what, last_error())
+    if rc in (E_ARG, E_ALIAS):
+        raise ValueError(msg)
+    if rc == E_UNSUPPORTED:
+        raise NotImplementedError(msg)
+    raise NativeLibraryError(msg + ' [hipError_t %d]' % rc)
+
+
+def dptr(t, dtype=torch.float64, numel=None, name='tensor'):
+    """Device pointer of a contiguous ROCm tensor, with the shape checks the
+    kernels rely on (a wrong size here would be an out-of-bounds access)."""
+    if t is None:
+        return None
+    if not isinstance(t, torch.Tensor):
+        raise TypeError('%s must be a torch.Tensor' % name)
+    if not t.is_cuda:
+        raise ValueError('%s must live in GPU memory (got %s)'
+                         % (name, t.device))
+    if t.dtype != dtype:
+        raise ValueError('%s must be %s (got %s)' % (name, dtype, t.dtype))
+    if not t.is_contiguous():
+        raise ValueError('%s must be contiguous' % name)
+    if numel is not None and t.numel() != numel:
+        raise ValueError('%s has %d elements, expected %d'
+                         % (name, t.numel(), numel))
+    return t.data_ptr()
+
+
+def stream_handle(device=None):
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def pairwise_tree_height(n):
+    return lib().binf_pairwise_tree_height(int(n))
+
+
+def pairwise_leaf(n, H, path):
+    off, ln = _i64(), _i64()
+    depth, canon = _i32(), _i32()
+    rc = lib().binf_pairwise_leaf(int(n), int(H), int(path),
+                                  ctypes.byref(off), ctypes.byref(ln),
+                                  ctypes.byref(depth), ctypes.byref(canon))
+    check(rc, 'binf_pairwise_leaf')
+    return off.value, ln.value, depth.value, canon.value
+
+
+def hmc_sample_gauss(q0, p0, u, q_out, accepted, n_accepted, e_before, e_after, timestep,
+                     dt_chain, nsteps, k, x0, adapt, uprate, downrate,
+                     mode=MODE_EXACT):
+    """binf_hmc_sample_gauss_f64 on torch's current stream."""
+    if q0.dim() != 2:
+        raise ValueError('q0 must be [n_chains, n_dims]')
+    C, D = q0.shape
+    n = C * D
+    rc = lib().binf_hmc_sample_gauss_f64(
+        dptr(q0, numel=n, name='q0'), dptr(p0, numel=n, name='p0'),
+        dptr(u, numel=C, name='u'), dptr(q_out, numel=n, name='q_out'),
+        dptr(accepted, torch.uint8, C, 'accepted'),
+        dptr(n_accepted, torch.int64, C, 'n_accepted'),
+        dptr(e_before, numel=C, name='e_before'),
+        dptr(e_after, numel=C, name='e_after'),
+        float(timestep), dptr(dt_chain, numel=C, name='dt_chain'),
+        C, D, int(nsteps), float(k), float(x0), int(bool(adapt)),
+        float(uprate), float(downrate), int(mode), stream_handle(q0.device))
+    check(rc, 'binf_hmc_sample_gauss_f64')
+
+
+ROW_SUM, ROW_SUMSQ, ROW_SUMSQ_SHIFT = 0, 1, 2
+
+
+def _cd(x):
+    if x.dim() != 2:
+        raise ValueError('expected a [n_chains, n_dims] tensor, got shape %s'
+                         % (tuple(x.shape),))
+    return x.shape
+
+
+def row_sum(x, op=ROW_SUM, shift=0.0, scale=1.0, out=None):
+    """scale * np.sum(f(x[c, :])) per chain, numpy pairwise order."""
+    C, D = _cd(x)
+    if out is None:
+        out = torch.empty(C, dtype=torch.float64, device=x.device)
+    rc = lib().binf_row_sum_f64(dptr(x, numel=C * D, name='x'),
+                                dptr(out, numel=C, name='out'), C, D, int(op),
+                                float(shift), float(scale),
+                                stream_handle(x.device))
+    check(rc, 'binf_row_sum_f64')
+    return out
+
+
+def leapfrog_kick(p, grad, timestep, dt_chain=None, half=False,
+                  mode=MODE_EXACT):
+    C, D = _cd(p)
+    rc = lib().binf_leapfrog_kick_f64(
+        dptr(p, numel=C * D, name='p'), dptr(grad, numel=C * D, name='grad'),
+        float(timestep), dptr(dt_chain, numel=C, name='dt_chain'),
+        int(bool(half)), C, D, int(mode), stream_handle(p.device))
+    check(rc, 'binf_leapfrog_kick_f64')
+
+
+def leapfrog_drift(q, p, timestep, dt_chain=None, mode=MODE_EXACT):
+    C, D = _cd(q)
+    rc = lib().binf_leapfrog_drift_f64(
+        dptr(q, numel=C * D, name='q'), dptr(p, numel=C * D, name='p'),
+        float(timestep), dptr(dt_chain, numel=C, name='dt_chain'), C, D,
+        int(mode), stream_handle(q.device))
+    check(rc, 'binf_leapfrog_drift_f64')
+
+
+def gauss_grad(x, k, x0, out=None):
+    C, D = _cd(x)
+    if out is None:
+        out = torch.empty_like(x)
+    rc = lib().binf_gauss_grad_f64(dptr(x, numel=C * D, name='x'),
+                                   dptr(out, numel=C * D, name='out'),
+                                   float(k), float(x0), C, D,
+                                   stream_handle(x.device))
+    check(rc, 'binf_gauss_grad_f64')
+    return out
+
+
+def accept_select(q_prop, q_old, e_before, e_after, u, q_out, accepted,
+                  n_accepted=None, dt_chain=None, adapt=False, uprate=1.05, downrate=0.95):
+    C, D = _cd(q_prop)
+    n = C * D
+    rc = lib().binf_accept_select_f64(
+        dptr(q_prop, numel=n, name='q_prop'), dptr(q_old, numel=n, name='q_old'),
+        dptr(e_before, numel=C, name='e_before'),
+        dptr(e_after, numel=C, name='e_after'), dptr(u, numel=C, name='u'),
+        dptr(q_out, numel=n, name='q_out'),
+        dptr(accepted, torch.uint8, C, 'accepted'),
+        dptr(n_accepted, torch.int64, C, 'n_accepted'),
+        dptr(dt_chain, numel=C, name='dt_chain'), int(bool(adapt)),
+        float(uprate), float(downrate), C, D, stream_handle(q_prop.device))
+    check(rc, 'binf_accept_select_f64')

@@ -1,0 +1,86 @@
+// Shared host/device helpers of libbinf_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/binf_hip.h"
+
+// numpy rounds every multiply and add separately; EXACT-mode kernels must not
+// contract a*b+c.  (The build also passes -ffp-contract=off.)
+#pragma clang fp contract(off)
+
+namespace binf {
+
+// ---- error text (thread-local) -------------------------------------------
+void set_error(const char *fmt, ...);
+int32_t fail(int32_t code, const char *fmt, ...);
+int32_t hip_fail(hipError_t e, const char *what);
+
+#define BINF_HIP_CHECK(expr)                                   \
+    do {                                                       \
+        hipError_t e_ = (expr);                                \
+        if (e_ != hipSuccess) return binf::hip_fail(e_, #expr); \
+    } while (0)
+
+// ---- numpy pairwise-summation geometry -------------------------------------
+// np.add.reduce on a contiguous f64 vector: blocks of <=128 elements ("leaves")
+// are summed with 8 strided accumulators, blocks are joined by a binary tree
+// that splits n at n/2 rounded down to a multiple of 8.
+constexpr int PW_BLOCK = 128;
+
+struct Leaf {
+    int32_t off;        // first element of the leaf
+    int32_t len;        // number of elements (<=128)
+    int32_t depth;      // depth of the leaf in the tree (root = 0)
+    int32_t canonical;  // 1 if `path` is the lowest path that reaches it
+};
+
+inline int32_t pairwise_tree_height(int64_t n)  // host only
+{
+    if (n <= PW_BLOCK) return 0;
+    int64_t n2 = n / 2;
+    n2 -= n2 % 8;
+    int32_t a = pairwise_tree_height(n2);
+    int32_t b = pairwise_tree_height(n - n2);
+    return 1 + (a > b ? a : b);
+}
+
+// Walk from the root along `path` (bit H-1 first; 0 = left half).  A leaf
+// that sits above depth H is reached by every path below it; those paths
+// recompute the same leaf ("redundant groups"), which keeps the cross-leaf
+// butterfly uniform.
+__host__ __device__ inline Leaf pairwise_leaf(int32_t n, int32_t H, int32_t path)
+{
+    Leaf L;
+    int32_t off = 0, depth = 0;
+    for (int32_t d = 0; d < H; ++d) {
+        if (n <= PW_BLOCK) break;
+        int32_t n2 = n / 2;
+        n2 -= n2 % 8;
+        if ((path >> (H - 1 - d)) & 1) {
+            off += n2;
+            n -= n2;
+        } else {
+            n = n2;
+        }
+        ++depth;
+    }
+    L.off = off;
+    L.len = n;
+    L.depth = depth;
+    L.canonical = ((path & ((1 << (H - depth)) - 1)) == 0) ? 1 : 0;
+    return L;
+}
+
+// ---- wave64 cross-lane moves for doubles ----------------------------------
+__device__ inline double shfl_xor_f64(double v, int mask)
+{
+    return __shfl_xor(v, mask, 64);
+}
+__device__ inline double shfl_f64(double v, int src)
+{
+    return __shfl(v, src, 64);
+}
+
+}  // namespace binf

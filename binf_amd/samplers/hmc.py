@@ -1,0 +1,213 @@
+"""
+Chain-batched Hamiltonian Monte Carlo behind the reference's ``HMCSampler``
+surface (``binf/samplers/hmc.py:15-191``).
+
+One ``sample()`` call advances C independent chains by one HMC transition:
+momentum draw, E_before, ``nsteps`` leapfrog steps, E_after, Metropolis
+accept, optional step-size adaption.  The state is a ``[C x D]`` fp64 ROCm
+tensor (a ``[D]`` tensor is one chain).  All arithmetic runs in HIP kernels:
+
+* fused tier  -- the PDF advertises a native trajectory kernel
+  (``pdf.native_hmc_spec``): the whole transition is one launch with q, p held
+  in registers;
+* generic tier -- any PDF with ``log_prob`` / ``gradient`` returning batched
+  tensors: kick / drift / energy / accept are separate launches around the
+  user's gradient.
+
+There is no CPU path: without the HIP library this module raises.
+"""
+from collections import namedtuple
+
+import torch
+
+from binf_amd import _native
+from binf_amd.samplers.rng import HostLegacyRNG
+
+HMCSampleStats = namedtuple('HMCSampleStats', 'accepted stepsize')
+
+_MODES = {'exact': _native.MODE_EXACT, 'fma': _native.MODE_FMA}
+
+
+class HMCSampler(object):
+    """Same constructor and attributes as the reference (``hmc.py:17-62``).
+
+    Differences that follow from batching, all per chain:
+    ``last_move_accepted`` is a ``[C]`` bool tensor, ``n_accepted`` a ``[C]``
+    int64 tensor, ``acceptance_rate`` a ``[C]`` tensor; ``timestep`` becomes a
+    ``[C]`` tensor once step-size adaption is switched on (chains adapt
+    independently, as C separate reference samplers would).
+
+    Extra keyword arguments (not in the reference):
+      rng   object with ``normal(shape, device)`` / ``uniform(n, device)``;
+            default :class:`HostLegacyRNG` (the reference's np.random stream).
+      mode  'exact' (default; bit-identical to the numpy restatement) or 'fma'.
+      record_energies  keep E_before / E_after of the last call in
+            ``last_e_before`` / ``last_e_after``.
+
+    The tensor returned by ``sample()`` IS the new state (no defensive copy --
+    a copy would double the HBM traffic of the transition).  The sampler never
+    writes into a tensor it has handed out; callers that want to modify a
+    sample in place must clone it first.
+    """
+
+    def __init__(self, pdf, state, timestep, nsteps, timestep_adaption_limit=0,
+                 adaption_uprate=1.05, adaption_downrate=0.95,
+                 variable_name=None, rng=None, mode='exact',
+                 record_energies=False):
+        if mode not in _MODES:
+            raise ValueError("mode must be 'exact' or 'fma', not %r" % (mode,))
+        self.pdf = pdf
+        self.state = state
+        self._timestep = timestep
+        self._dt_chain = None
+        self.nsteps = nsteps
+        self.timestep_adaption_limit = timestep_adaption_limit
+        self.adaption_uprate = adaption_uprate
+        self.adaption_downrate = adaption_downrate
+        self._variable_name = variable_name
+        self.rng = rng if rng is not None else HostLegacyRNG()
+        self.mode = mode
+        self.record_energies = record_energies
+
+        self._last_move_accepted = 0
+        self.n_accepted = 0
+        self.counter = 0
+        self.last_e_before = None
+        self.last_e_after = None
+
+    # -- reference attributes ----------------------------------------------
+    @property
+    def timestep(self):
+        return self._dt_chain if self._dt_chain is not None else self._timestep
+
+    @timestep.setter
+    def timestep(self, value):
+        if isinstance(value, torch.Tensor) and value.dim() > 0:
+            self._dt_chain = value
+        else:
+            self._timestep = float(value)
+            self._dt_chain = None
+
+    @property
+    def acceptance_rate(self):
+        if self.counter > 0:
+            return self.n_accepted / float(self.counter)
+        return 0.0
+
+    @property
+    def variable_name(self):
+        return 'HMC' if self._variable_name is None else self._variable_name
+
+    @property
+    def last_move_accepted(self):
+        return self._last_move_accepted
+
+    @property
+    def last_draw_stats(self):
+        return {self.variable_name: HMCSampleStats(self.last_move_accepted,
+                                                   self.timestep)}
+
+    # -- one transition ------------------------------------------------------
+    def sample(self, p0=None, u=None):
+        """Draw one sample per chain.  ``p0`` (``[C x D]``) and ``u`` (``[C]``)
+        override the random draws (parity tests, pre-generated pools)."""
+        name = self._variable_name
+        if not isinstance(name, str):
+            # reference: pdf.log_prob(**{None: x}) -> TypeError (quirk Q1)
+            raise TypeError('HMCSampler needs variable_name to sample()')
+        state = self.state
+        shape = state.shape                       # quirk Q2: arrays only
+        q0 = state if state.dim() == 2 else state.reshape(1, -1)
+        C, D = q0.shape
+        dev = q0.device
+        if p0 is None:
+            p0 = self.rng.normal((C, D), dev)
+            own_p = True
+        else:
+            p0 = p0 if p0.dim() == 2 else p0.reshape(1, -1)
+            own_p = False
+        if u is None:
+            u = self.rng.uniform(C, dev)
+
+        adapt = (self.counter + 1) < self.timestep_adaption_limit
+        if adapt and self._dt_chain is None:
+            self._dt_chain = torch.full((C,), float(self._timestep),
+                                        dtype=torch.float64, device=dev)
+        if not isinstance(self.n_accepted, torch.Tensor):
+            self.n_accepted = torch.zeros(C, dtype=torch.int64, device=dev)
+
+        accepted = torch.empty(C, dtype=torch.uint8, device=dev)
+        spec = None
+        get_spec = getattr(self.pdf, 'native_hmc_spec', None)
+        if get_spec is not None:
+            spec = get_spec(name)
+        if spec is not None and spec[0] == 'gauss' and \
+                _gauss_kernel_covers(D):
+            q_out = self._sample_fused_gauss(spec, q0, p0, u, accepted, adapt)
+        else:
+            q_out = self._sample_generic(name, state, q0, p0, own_p, u,
+                                         accepted, adapt)
+
+        self._last_move_accepted = accepted.view(torch.bool)
+        self.counter += 1
+        q_out = q_out.view(shape)
+        self.state = q_out
+        return q_out
+
+    # -- fused tier ----------------------------------------------------------
+    def _sample_fused_gauss(self, spec, q0, p0, u, accepted, adapt):
+        _, k, x0 = spec
+        C, D = q0.shape
+        q_out = torch.empty_like(q0)
+        eb = ea = None
+        if self.record_energies:
+            eb = torch.empty(C, dtype=torch.float64, device=q0.device)
+            ea = torch.empty(C, dtype=torch.float64, device=q0.device)
+        _native.hmc_sample_gauss(q0, p0, u, q_out, accepted, self.n_accepted,
+                                 eb, ea, self._timestep, self._dt_chain,
+                                 self.nsteps, k, x0, adapt,
+                                 self.adaption_uprate, self.adaption_downrate,
+                                 _MODES[self.mode])
+        self.last_e_before, self.last_e_after = eb, ea
+        return q_out
+
+    # -- generic tier --------------------------------------------------------
+    def _sample_generic(self, name, state, q0, p0, own_p, u, accepted, adapt):
+        pdf = self.pdf
+        mode = _MODES[self.mode]
+        shape = state.shape
+        dt, dtc = self._timestep, self._dt_chain
+        V = lambda x: -_as_chain_vector(pdf.log_prob(**{name: x.view(shape)}))
+        grad = lambda x: _as2d(pdf.gradient(**{name: x.view(shape)}))
+
+        q = q0.clone()
+        p = p0 if own_p else p0.clone()
+        e_before = V(q) + _native.row_sum(p, _native.ROW_SUMSQ, scale=0.5)
+        # _leapfrog, reference hmc.py:116-123
+        _native.leapfrog_kick(p, grad(q), dt, dtc, half=True, mode=mode)
+        for _ in range(self.nsteps - 1):
+            _native.leapfrog_drift(q, p, dt, dtc, mode=mode)
+            _native.leapfrog_kick(p, grad(q), dt, dtc, mode=mode)
+        _native.leapfrog_drift(q, p, dt, dtc, mode=mode)
+        _native.leapfrog_kick(p, grad(q), dt, dtc, half=True, mode=mode)
+        e_after = V(q) + _native.row_sum(p, _native.ROW_SUMSQ, scale=0.5)
+        _native.accept_select(q, q0, e_before, e_after, u, q, accepted,
+                              self.n_accepted, dtc, adapt,
+                              self.adaption_uprate, self.adaption_downrate)
+        self.last_e_before, self.last_e_after = e_before, e_after
+        return q
+
+
+def _gauss_kernel_covers(D):
+    return 1 <= D <= 1024 and _native.pairwise_tree_height(D) <= 3
+
+
+def _as2d(x):
+    return x if x.dim() == 2 else x.reshape(1, -1)
+
+
+def _as_chain_vector(x):
+    if not isinstance(x, torch.Tensor):
+        raise TypeError('pdf.log_prob must return a tensor with one value per '
+                        'chain, got %r' % type(x))
+    return x.reshape(-1)

@@ -1,0 +1,157 @@
+/*
+ * binf_hip.h -- C ABI of libbinf_hip.so, the MI355X (gfx950) engine behind
+ * binf's HMC hot path.  Plain C types only; every pointer marked "device" is
+ * HBM memory owned by the CALLER (e.g. a PyTorch-ROCm tensor's data_ptr()).
+ *
+ * Conventions (all functions)
+ *   - return 0 on success, <0 for an argument error (BINF_E_*), >0 = hipError_t.
+ *     Nothing is thrown across the ABI; binf_last_error() gives the text.
+ *   - stateless and re-entrant; work is enqueued on `stream` (a hipStream_t,
+ *     NULL = the default stream) and the call returns without synchronising.
+ *   - the library allocates nothing persistent, keeps no pointer past return
+ *     and never frees caller memory.  Safe inside hipGraph stream capture.
+ *   - layout: chain-major row-major fp64, x[c*D + i] for chain c, dimension i.
+ *
+ * The reference (simeoncarstens/binf) has no native code and no FFI; each
+ * entry point below names the reference Python it replaces (paths relative to
+ * the reference root).
+ */
+#ifndef BINF_HIP_H
+#define BINF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BINF_ABI_VERSION 1
+
+#define BINF_E_ARG        (-1)  /* null pointer / negative size / bad flag    */
+#define BINF_E_UNSUPPORTED (-2) /* shape outside what the kernels cover       */
+#define BINF_E_ALIAS      (-3)  /* illegal partial overlap of buffers         */
+
+/* arithmetic mode of the leapfrog update */
+#define BINF_MODE_EXACT 0  /* every multiply and add rounded separately, numpy
+                              pairwise-sum order: bit-identical to the CPU
+                              restatement of the reference's numpy path      */
+#define BINF_MODE_FMA   1  /* p-=dt*g and q+=p*dt contracted to one FMA each:
+                              within 1e-10 relative of EXACT, not bit-equal  */
+
+int32_t binf_abi_version(void);
+
+/* Copies the calling thread's last error text (NUL-terminated, truncated to
+ * n) into buf; returns its full length. */
+int32_t binf_last_error(char *buf, size_t n);
+
+/* ------------------------------------------------------------------------
+ * Fused HMC transition on an isotropic Gaussian  (BASELINE config C2)
+ *
+ * Replaces, for C independent chains in one launch:
+ *   HMCSampler.sample()          binf/samplers/hmc.py:136-164
+ *   HMCSampler._leapfrog()       binf/samplers/hmc.py:92-125
+ *   HMCSampler._adapt_timestep() binf/samplers/hmc.py:183-191
+ *   TestHO log_prob / gradient   binf/pdf/__init__.py:181-191
+ *       log p(x) = -0.5*k*sum((x-x0)**2),  gradient = k*(x-x0)  [of -log p]
+ *
+ * Per chain c:   p = p0[c];  E_b = V(q0)+0.5*sum(p**2);  leapfrog nsteps;
+ *   E_a = V(q)+0.5*sum(p**2);  acc = u[c] < exp(clip(-(E_a-E_b),-308,709));
+ *   q_out[c] = acc ? q : q0[c].
+ *
+ *   q0, p0      device, [C*D]   start positions; momentum draws (the
+ *                               np.random.normal(size=D) of hmc.py:146)
+ *   u           device, [C]     uniform draws (hmc.py:151)
+ *   q_out       device, [C*D]   returned samples.  May be EXACTLY q0 (state
+ *                               updated in place) or disjoint from q0/p0.
+ *   accepted    device, [C]     1/0
+ *   n_accepted  device, [C] or NULL  per-chain acceptance counter, += 1 on
+ *                               accept (hmc.py:161)
+ *   e_before/e_after device,[C] energies of hmc.py:148,150 (may be NULL)
+ *   timestep    host scalar     used when dt_chain == NULL
+ *   dt_chain    device, [C] or NULL  per-chain timestep; when adapt != 0 it is
+ *                               updated in place: *uprate on accept,
+ *                               *downrate on reject (hmc.py:188-191).
+ *                               adapt != 0 requires dt_chain != NULL.
+ *   mode        BINF_MODE_EXACT | BINF_MODE_FMA
+ * Supported: 1 <= D <= 1024 whose numpy pairwise-sum tree has height <= 3
+ * (every D <= 920 and all multiples of 8 up to 1024); nsteps >= 1.
+ * ---------------------------------------------------------------------- */
+int32_t binf_hmc_sample_gauss_f64(const double *q0, const double *p0,
+                                  const double *u, double *q_out,
+                                  uint8_t *accepted, int64_t *n_accepted,
+                                  double *e_before,
+                                  double *e_after, double timestep,
+                                  double *dt_chain, int64_t C, int64_t D,
+                                  int32_t nsteps, double k, double x0,
+                                  int32_t adapt, double uprate, double downrate,
+                                  int32_t mode, void *stream);
+
+/* ------------------------------------------------------------------------
+ * Generic per-step tier: the pieces of HMCSampler.sample() as separate
+ * chain-batched launches, for posteriors whose gradient comes from other code
+ * (any plug-in with log_prob / gradient, reference binf/samplers/hmc.py:114,143).
+ * ---------------------------------------------------------------------- */
+
+/* Row reductions in numpy's pairwise order, bit-identical to np.sum on each
+ * row:  out[c] = scale * np.sum(f(x[c,:])).
+ *   op = BINF_ROW_SUM          f(x) = x
+ *        BINF_ROW_SUMSQ        f(x) = x*x            (0.5*np.sum(p**2): scale=0.5,
+ *                                                     hmc.py:148,150)
+ *        BINF_ROW_SUMSQ_SHIFT  f(x) = (x-shift)**2   (binf/pdf/__init__.py:185)
+ * (rows longer than numpy's 8192-element buffer are accumulated chunk by chunk,
+ * as numpy does).  x device [C*D], out device [C]; any D < 2^31. */
+#define BINF_ROW_SUM 0
+#define BINF_ROW_SUMSQ 1
+#define BINF_ROW_SUMSQ_SHIFT 2
+int32_t binf_row_sum_f64(const double *x, double *out, int64_t C, int64_t D,
+                         int32_t op, double shift, double scale, void *stream);
+
+/* p[c,:] -= (half ? 0.5*dt : dt) * grad[c,:]     hmc.py:116,120,123
+ * dt = dt_chain[c] if dt_chain != NULL else timestep. */
+int32_t binf_leapfrog_kick_f64(double *p, const double *grad, double timestep,
+                               const double *dt_chain, int32_t half, int64_t C,
+                               int64_t D, int32_t mode, void *stream);
+
+/* q[c,:] += p[c,:] * dt                           hmc.py:119,122 */
+int32_t binf_leapfrog_drift_f64(double *q, const double *p, double timestep,
+                                const double *dt_chain, int64_t C, int64_t D,
+                                int32_t mode, void *stream);
+
+/* out = k * (x - x0): energy gradient of TestHO, binf/pdf/__init__.py:187-191 */
+int32_t binf_gauss_grad_f64(const double *x, double *out, double k, double x0,
+                            int64_t C, int64_t D, void *stream);
+
+/* acc[c] = u[c] < exp(clip(-(e_after[c]-e_before[c]), -308, 709));
+ * q_out[c,:] = acc ? q_prop[c,:] : q_old[c,:];  optional step-size adaption of
+ * dt_chain as in binf_hmc_sample_gauss_f64.       hmc.py:151-164,188-191
+ * n_accepted (device [C] or NULL) += 1 on accept.
+ * q_out may be exactly q_prop or exactly q_old. */
+int32_t binf_accept_select_f64(const double *q_prop, const double *q_old,
+                               const double *e_before, const double *e_after,
+                               const double *u, double *q_out, uint8_t *accepted,
+                               int64_t *n_accepted, double *dt_chain,
+                               int32_t adapt, double uprate,
+                               double downrate, int64_t C, int64_t D,
+                               void *stream);
+
+/* ------------------------------------------------------------------------
+ * Host-side helpers exposing the reduction geometry the kernels use, so that
+ * CPU tests can check it against numpy's pairwise summation (no GPU needed).
+ * ---------------------------------------------------------------------- */
+
+/* Height of numpy's pairwise-sum recursion tree for a length-n vector
+ * (0 when n <= 128). */
+int32_t binf_pairwise_tree_height(int64_t n);
+
+/* Leaf reached by the root-to-leaf path `path` (bit H-1 = first split, 0 =
+ * left) in a tree padded to height H.  Outputs the leaf's offset and length,
+ * its depth, and whether `path` is the canonical (lowest) path reaching it.
+ * Returns 0, or BINF_E_ARG. */
+int32_t binf_pairwise_leaf(int64_t n, int32_t H, int32_t path, int64_t *off,
+                           int64_t *len, int32_t *depth, int32_t *canonical);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BINF_HIP_H */

@@ -1,0 +1,69 @@
+"""TEST INFRASTRUCTURE ONLY (see oracle/__init__.py): ctypes binding of
+oracle/liboracle_c.so, the plain-C restatement of the batched HMC transition."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, 'liboracle_c.so')
+_lib = None
+
+
+def build(force=False):
+    src = os.path.join(_HERE, 'oracle_c.c')
+    if force or not os.path.exists(_SO) or \
+            os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(['make', '-C', _HERE, '-B', 'liboracle_c.so'],
+                              stdout=subprocess.DEVNULL)
+    return _SO
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            build()
+        _lib = ctypes.CDLL(_SO)
+        _lib.oracle_pairwise_sum.restype = ctypes.c_double
+        _lib.oracle_pairwise_sum.argtypes = [ctypes.c_void_p, ctypes.c_int64]
+        _lib.oracle_np_sum.restype = ctypes.c_double
+        _lib.oracle_np_sum.argtypes = [ctypes.c_void_p, ctypes.c_int64]
+        _lib.oracle_hmc_sample_gauss.restype = ctypes.c_int
+        _lib.oracle_hmc_sample_gauss.argtypes = (
+            [ctypes.c_void_p] * 8 + [ctypes.c_int64, ctypes.c_int64,
+                                     ctypes.c_int32, ctypes.c_double,
+                                     ctypes.c_double, ctypes.c_int32,
+                                     ctypes.c_double, ctypes.c_double,
+                                     ctypes.c_int32])
+    return _lib
+
+
+def np_sum(a):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    return lib().oracle_np_sum(a.ctypes.data, a.size)
+
+
+def hmc_sample_gauss(q0, p0, u, timestep, nsteps, k=1.0, x0=0.0, adapt=False,
+                     uprate=1.05, downrate=0.95, nthreads=1):
+    q0 = np.ascontiguousarray(q0, dtype=np.float64)
+    p0 = np.ascontiguousarray(p0, dtype=np.float64)
+    u = np.ascontiguousarray(u, dtype=np.float64)
+    C, D = q0.shape
+    assert p0.shape == (C, D) and u.shape == (C,)
+    dt = np.ascontiguousarray(
+        np.broadcast_to(np.asarray(timestep, dtype=np.float64), (C,))).copy()
+    q_out = np.empty_like(q0)
+    acc = np.zeros(C, dtype=np.uint8)
+    eb = np.empty(C)
+    ea = np.empty(C)
+    rc = lib().oracle_hmc_sample_gauss(
+        q0.ctypes.data, p0.ctypes.data, u.ctypes.data, q_out.ctypes.data,
+        acc.ctypes.data, eb.ctypes.data, ea.ctypes.data, dt.ctypes.data,
+        C, D, int(nsteps), float(k), float(x0), int(bool(adapt)),
+        float(uprate), float(downrate), int(nthreads))
+    if rc != 0:
+        raise ValueError('oracle_hmc_sample_gauss rc=%d' % rc)
+    return dict(q_out=q_out, accepted=acc, e_before=eb, e_after=ea,
+                timestep_out=dt)

@@ -1,0 +1,106 @@
+"""CPU tests of the C-ABI boundary: the library loads, exports every symbol
+include/binf_hip.h declares, and its reduction geometry is numpy's."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from binf_amd import _native
+from conftest import ROOT
+from oracle import ref_numpy as R
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, 'include', 'binf_hip.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(binf_[a-z0-9_]+)\s*\(', text)))
+
+
+def test_library_loads_and_reports_abi_version():
+    assert _native.lib().binf_abi_version() == _native.ABI_VERSION
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    names = declared_symbols()
+    assert 'binf_hmc_sample_gauss_f64' in names
+    raw = ctypes.CDLL(_native.LIB_PATH)
+    for n in names:
+        assert hasattr(raw, n), 'missing export: ' + n
+        assert n in _native.SIGNATURES, 'no ctypes signature for ' + n
+    assert sorted(_native.SIGNATURES) == names
+
+
+def test_error_codes_and_text_without_gpu():
+    L = _native.lib()
+    rc = L.binf_hmc_sample_gauss_f64(None, None, None, None, None, None, None,
+                                     None, 0.1, None, 4, 0, 1, 1.0, 0.0, 0,
+                                     1.05, 0.95, 0, None)
+    assert rc == _native.E_ARG and 'D>=1' in _native.last_error()
+    # never dereferenced: argument validation returns before any launch
+    fake = [i << 40 for i in range(1, 6)]
+    rc = L.binf_hmc_sample_gauss_f64(fake[0], fake[1], fake[2], fake[3], fake[4],
+                                     None, None, None, 0.1, None, 4, 5000, 1,
+                                     1.0, 0.0, 0, 1.05, 0.95, 0, None)
+    assert rc == _native.E_UNSUPPORTED
+    with pytest.raises(NotImplementedError):
+        _native.check(rc, 'x')
+    rc = L.binf_hmc_sample_gauss_f64(fake[0], fake[1], fake[2], fake[0] + 8,
+                                     fake[4], None, None, None, 0.1, None, 4, 64,
+                                     1, 1.0, 0.0, 0, 1.05, 0.95, 0, None)
+    assert rc == _native.E_ALIAS
+    rc = L.binf_row_sum_f64(None, None, -1, 4, 0, 0.0, 1.0, None)
+    assert rc == _native.E_ARG
+    with pytest.raises(ValueError):
+        _native.check(rc, 'x')
+
+
+def test_dptr_rejects_host_and_misshapen_tensors():
+    import torch
+    t = torch.zeros(4, dtype=torch.float64)
+    with pytest.raises(ValueError):
+        _native.dptr(t)
+    with pytest.raises(TypeError):
+        _native.dptr(np.zeros(4))
+
+
+@pytest.mark.parametrize('n', [1, 7, 8, 100, 128, 129, 200, 258, 260, 300, 768,
+                               920, 921, 1000, 1023, 1024, 1025, 4096, 5000,
+                               16384, 100003])
+def test_tree_walk_matches_numpy_recursion(n):
+    """The padded-path walk the kernels use enumerates exactly the leaves of
+    numpy's pairwise recursion, with their depths."""
+    leaves, tree = R.pairwise_leaves(n)
+
+    def height(t):
+        return 0 if isinstance(t, int) else 1 + max(height(t[0]), height(t[1]))
+
+    def depths(t, d, out):
+        if isinstance(t, int):
+            out[t] = d
+        else:
+            depths(t[0], d + 1, out)
+            depths(t[1], d + 1, out)
+
+    H = _native.pairwise_tree_height(n)
+    assert H == height(tree)
+    want_depth = {}
+    depths(tree, 0, want_depth)
+    canon = []
+    for path in range(1 << H):
+        off, ln, depth, c = _native.pairwise_leaf(n, H, path)
+        if c:
+            canon.append((off, ln, depth))
+        else:
+            # redundant path: same leaf as the canonical path above it
+            base = path & ~((1 << (H - depth)) - 1)
+            assert _native.pairwise_leaf(n, H, base)[:3] == (off, ln, depth)
+    assert [(o, l) for o, l, _ in canon] == leaves
+    assert [d for _, _, d in canon] == [want_depth[i] for i in range(len(leaves))]
+
+
+def test_fused_kernel_coverage_claim():
+    # header: every D <= 920 and all multiples of 8 up to 1024 have height <= 3
+    for D in list(range(1, 921)) + list(range(928, 1025, 8)):
+        assert _native.pairwise_tree_height(D) <= 3, D

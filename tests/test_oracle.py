@@ -1,0 +1,128 @@
+"""CPU tests of the oracle itself (test infrastructure): the restatements agree
+with numpy, with each other and with the committed golden vectors."""
+import numpy as np
+import pytest
+
+from conftest import golden_files, load_golden
+from oracle import c_oracle
+from oracle import ref_numpy as R
+
+LENGTHS = list(range(0, 300)) + [511, 512, 768, 920, 1000, 1023, 1024, 2049,
+                                 4096, 5000, 16384, 100003]
+
+
+def test_pairwise_restatement_matches_np_sum_bitwise():
+    rs = np.random.RandomState(0)
+    for n in LENGTHS:
+        a = rs.standard_normal(n) * 10 ** rs.uniform(-3, 3)
+        want = float(np.sum(a))
+        if n <= 5000:
+            assert R.np_sum_py(a) == want, n
+        assert c_oracle.np_sum(a) == want, n
+
+
+def test_pairwise_signed_zero():
+    for n in (0, 1, 3, 8, 9, 200):
+        a = np.full(n, -0.0)
+        got = c_oracle.np_sum(a)
+        want = float(np.sum(a))
+        assert got == want and np.signbit(got) == np.signbit(want)
+
+
+def test_pairwise_leaves_cover_the_vector():
+    for n in (1, 7, 8, 128, 129, 258, 1023, 1024, 5000):
+        leaves, _ = R.pairwise_leaves(n)
+        pos = 0
+        for off, ln in leaves:
+            assert off == pos and 0 < ln <= 128
+            pos += ln
+        assert pos == n
+
+
+def test_polyval_restatement_is_numpys():
+    rs = np.random.RandomState(3)
+    x = np.linspace(-2, 2, 50)
+    for K in (1, 2, 4, 33):
+        c = rs.standard_normal(K)
+        assert np.array_equal(R.polyval(x, c),
+                              np.polynomial.polynomial.polyval(x, c))
+
+
+def test_clipped_exp_bounds():
+    assert R.exp(-1e6) == np.exp(-308.0)
+    assert R.exp(1e6) == np.exp(709.0)
+    assert R.exp(0.5) == np.exp(0.5)
+    assert np.isnan(R.exp(np.nan))
+
+
+@pytest.mark.parametrize('D,L,k,x0,dt', [
+    (1, 1, 1.0, 0.0, 0.5), (4, 3, 1.0, 0.0, 0.3), (7, 2, 2.5, 0.3, 0.9),
+    (8, 5, 1.0, 0.0, 0.5), (33, 20, 2.5, 0.3, 0.35), (129, 4, 1.0, -1.0, 0.3),
+    (300, 10, 1.0, 0.0, 0.25), (768, 20, 1.0, 0.0, 0.22),
+    (1023, 3, 2.5, 0.3, 0.1), (1024, 20, 1.0, 0.0, 0.2), (2500, 2, 1.0, 0.0, 0.1)])
+def test_c_oracle_equals_numpy_restatement(D, L, k, x0, dt):
+    rs = np.random.RandomState(D * 31 + L)
+    C = 5
+    q0 = rs.standard_normal((C, D))
+    p0 = rs.standard_normal((C, D))
+    u = rs.uniform(size=C)
+    dts = dt * rs.uniform(0.8, 1.2, size=C)
+    a = R.hmc_sample_batch(lambda c: R.GaussianPDF(k, x0), q0, p0, u, dts, L,
+                           adapt=True)
+    b = c_oracle.hmc_sample_gauss(q0, p0, u, dts, L, k, x0, adapt=True,
+                                  nthreads=2)
+    for key in a:
+        assert np.array_equal(a[key], b[key]), key
+
+
+def test_adaption_multiplies_uprate_on_accept():
+    # quirk Q3: reference hmc.py:188-191 (docstring says the opposite)
+    s = R.RefHMCSampler(R.GaussianPDF(), np.zeros(4), 0.1, 1,
+                        timestep_adaption_limit=10, variable_name='x',
+                        normal=lambda size: np.zeros(size), uniform=lambda: 0.0)
+    s.sample()
+    assert s.last_move_accepted and s.timestep == 0.1 * 1.05
+
+
+def test_adaption_limit_checked_after_increment():
+    s = R.RefHMCSampler(R.GaussianPDF(), np.zeros(4), 0.1, 1,
+                        timestep_adaption_limit=2, variable_name='x',
+                        normal=lambda size: np.zeros(size), uniform=lambda: 0.0)
+    s.sample()              # counter 1 < 2 -> adapts
+    t1 = s.timestep
+    s.sample()              # counter 2 == limit -> no adaption
+    assert t1 == 0.1 * 1.05 and s.timestep == t1
+
+
+@pytest.mark.parametrize('path', golden_files('gauss_'))
+def test_golden_vectors_are_reproduced_by_both_restatements(path):
+    g = load_golden(path)
+    assert 'parity unpinned' in str(g['provenance'])
+    D, L = int(g['D']), int(g['L'])
+    k, x0, dt0 = float(g['k']), float(g['x0']), float(g['timestep'])
+    limit = int(g['adaption_limit'])
+    ncalls, C, _ = g['p0'].shape
+    q = g['q0'].copy()
+    dt = np.full(C, dt0)
+    for i in range(ncalls):
+        adapt = (i + 1) < limit
+        r = c_oracle.hmc_sample_gauss(q, g['p0'][i], g['u'][i], dt, L, k, x0,
+                                      adapt=adapt)
+        assert np.array_equal(r['q_out'], g['q_out'][i])
+        assert np.array_equal(r['accepted'], g['accepted'][i])
+        assert np.array_equal(r['e_before'], g['e_before'][i])
+        assert np.array_equal(r['e_after'], g['e_after'][i])
+        assert np.array_equal(r['timestep_out'], g['timestep_out'][i])
+        q, dt = r['q_out'], r['timestep_out']
+
+
+def test_golden_rng_stream_order():
+    """p0 / u in the fixtures are the global-stream draws in the reference's
+    order: normal(size=D) then uniform() per sample (hmc.py:146,151)."""
+    g = load_golden(golden_files('gauss_d33_l20')[0])
+    seed = int(g['seed'])
+    for c in range(g['p0'].shape[1]):
+        np.random.seed(seed + c)
+        for i in range(g['p0'].shape[0]):
+            assert np.array_equal(np.random.normal(size=int(g['D'])), g['p0'][i, c])
+            assert np.random.uniform() == g['u'][i, c]
