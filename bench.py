@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""
+Headline benchmark: chain*leapfrog-steps per second on BASELINE config C2
+(1024-d isotropic Gaussian, 4096 chains per GPU, 20 leapfrog steps, fp64).
+
+A "step" is one HMCSampler.sample() over the whole chain batch = ONE launch of
+the fused HIP trajectory kernel through the C ABI.  Inputs (state, a pool of
+pre-generated momentum / uniform draws) are resident in HBM before the timed
+region.  Multi-GPU: chains are sharded (weak scaling, 4096 chains per GPU), no
+collective in the data path; the sample gather is timed separately.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
+      --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X spec, MI355X_MICROARCH.md "HBM3E peak BW"
+HBM_COPY_GBS = 6290.0        # measured float4 copy ceiling, same table
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--chains', type=int, default=4096, help='chains per GPU')
+    ap.add_argument('--dims', type=int, default=1024)
+    ap.add_argument('--nsteps', type=int, default=20, help='leapfrog steps')
+    ap.add_argument('--timestep', type=float, default=0.05)
+    ap.add_argument('--mode', default='exact', choices=['exact', 'fma'])
+    ap.add_argument('--pool', type=int, default=16,
+                    help='momentum-draw buffers cycled through (pool*C*D*8 B; '
+                         '16 -> 512 MiB, larger than the 256 MiB Infinity Cache)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-chains', type=int, default=64)
+    ap.add_argument('--cpu-calls', type=int, default=400)
+    return ap.parse_args()
+
+
+def cpu_baseline(D, L, dt, chains, calls):
+    """The reference semantics (one chain per sampler, numpy fp64,
+    hmc.py:136-164) via the numpy restatement, on ONE host core; plus the C
+    restatement on all host cores as an extra figure."""
+    from oracle import c_oracle
+    from oracle import ref_numpy as R
+    rs = np.random.RandomState(1234)
+    q0 = rs.standard_normal((chains, D))
+    samplers = [R.RefHMCSampler(R.GaussianPDF(1.0, 0.0), q0[c].copy(), dt, L,
+                                variable_name='x') for c in range(chains)]
+    np.random.seed(1000)
+    for s in samplers[:4]:
+        s.sample()
+    t0 = time.perf_counter()
+    for _ in range(calls):
+        for s in samplers:
+            s.sample()
+    t = time.perf_counter() - t0
+    out = {'value': chains * calls * L / t, 'unit': 'chain*leapfrog-steps/s',
+           'cores': 1, 'kind': 'port',
+           'sample': '%d chains x %d sample() calls, D=%d, L=%d, numpy '
+                     'restatement of hmc.py:136-164, %.1f s'
+                     % (chains, calls, D, L, t)}
+    ncores = os.cpu_count() or 1
+    Cc = 64 * ncores
+    q = rs.standard_normal((Cc, D))
+    p = rs.standard_normal((Cc, D))
+    u = rs.uniform(size=Cc)
+    c_oracle.hmc_sample_gauss(q, p, u, dt, L, nthreads=ncores)
+    t0 = time.perf_counter()
+    reps = 20
+    for _ in range(reps):
+        c_oracle.hmc_sample_gauss(q, p, u, dt, L, nthreads=ncores)
+    t = time.perf_counter() - t0
+    out['c_port_all_cores'] = {'value': Cc * reps * L / t, 'cores': ncores,
+                               'sample': '%d chains x %d calls, C restatement, '
+                                         'OpenMP' % (Cc, reps)}
+    return out
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit('bench.py --gpus %d must be launched with torch.distributed'
+                     '.run --nproc-per-node %d' % (args.gpus, args.gpus))
+        args.gpus = world
+    if not torch.cuda.is_available():
+        sys.exit('bench.py needs a GPU (binf_amd has no CPU path)')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl', device_id=dev)
+
+    from binf_amd.pdf import IsotropicGaussian
+    from binf_amd.samplers.hmc import HMCSampler
+
+    C, D, L, dt = args.chains, args.dims, args.nsteps, args.timestep
+    K, W, P = args.steps, args.warmup, max(1, args.pool)
+
+    # synthetic inputs, resident in HBM before the timed region
+    q0 = torch.from_numpy(
+        np.random.RandomState(1234 + rank).standard_normal((C, D))).to(dev)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1000 + rank)
+    p_pool = [torch.randn((C, D), dtype=torch.float64, device=dev, generator=gen)
+              for _ in range(P)]
+    u_pool = [torch.rand(C, dtype=torch.float64, device=dev, generator=gen)
+              for _ in range(P)]
+
+    sampler = HMCSampler(IsotropicGaussian(1.0, 0.0), q0, dt, L,
+                         variable_name='x', mode=args.mode)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(W):
+        sampler.sample(p0=p_pool[i % P], u=u_pool[i % P])
+    barrier()
+    ev0 = torch.cuda.Event(enable_timing=True)
+    ev1 = torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for i in range(K):
+        sampler.sample(p0=p_pool[i % P], u=u_pool[i % P])
+    ev1.record()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    dev_ms = ev0.elapsed_time(ev1)              # same stream as the launches
+
+    acc_rate = float(sampler.acceptance_rate.mean())
+    gather_ms = None
+    if dist is not None:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax[0])
+        # the only collective of the path: gather one recorded draw (RCCL)
+        out = torch.empty((world * C, D), dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(out, sampler.state)
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(5):
+            dist.all_gather_into_tensor(out, sampler.state)
+        barrier()
+        gather_ms = (time.perf_counter() - t1) / 5 * 1e3
+
+    if rank == 0:
+        steps_total = float(world) * C * L * K
+        value = steps_total / elapsed
+        bytes_per_launch = (24.0 * D + 25.0) * C
+        launch_s = dev_ms * 1e-3 / K
+        achieved = bytes_per_launch / launch_s / 1e9
+        res = {
+            'metric': 'chain*leapfrog-steps/sec, 1024-d Gaussian',
+            'value': value,
+            'unit': 'chain*leapfrog-steps/s',
+            'n_gpus': world, 'steps': K, 'warmup': W,
+            'ms_per_step': elapsed / K * 1e3,
+            'higher_is_better': True,
+            'scaling': 'weak',
+            'vs_baseline': None,
+            'dtype': 'f64',
+            'data': 'synthetic',
+            'config': {'workload': 'C2: %d-d isotropic Gaussian (k=1, x0=0), '
+                                   '%d chains/GPU, %d leapfrog steps, dt=%g, '
+                                   'fused HMC transition, mode=%s'
+                                   % (D, C, L, dt, args.mode),
+                       'chains_per_gpu': C, 'n_dims': D, 'leapfrog_steps': L,
+                       'parallelism': 'chains sharded x%d, no data-path '
+                                      'collective' % world,
+                       'draw_pool_buffers': P},
+            'acceptance_rate': acc_rate,
+            'roofline': {'bound': 'hbm', 'achieved': achieved,
+                         'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': achieved / HBM_PEAK_GBS,
+                         'frac_of_measured_copy_ceiling': achieved / HBM_COPY_GBS,
+                         'traffic': None,
+                         'kernel': 'hmc_gauss_wave_kernel',
+                         'algorithmic_bytes_per_launch': bytes_per_launch,
+                         'avg_launch_us': launch_s * 1e6},
+        }
+        if gather_ms is not None:
+            res['sample_gather_ms'] = gather_ms
+        if world == 1 and not args.no_cpu_baseline:
+            res['cpu_baseline'] = cpu_baseline(D, L, dt, args.cpu_chains,
+                                               args.cpu_calls)
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

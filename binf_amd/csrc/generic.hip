@@ -241,7 +241,7 @@ extern "C" int32_t binf_row_sum_f64(const double *x, double *out, int64_t C,
     if (C < 0 || D < 0) return fail(BINF_E_ARG, "row_sum: negative size");
     if (op < 0 || op > 2) return fail(BINF_E_ARG, "row_sum: unknown op %d", op);
     if (C == 0) return 0;
-    if (!x || !out) return fail(BINF_E_ARG, "row_sum: null buffer");
+    if ((!x && D > 0) || !out) return fail(BINF_E_ARG, "row_sum: null buffer");
     if (D > 0x7fffffffLL) return fail(BINF_E_UNSUPPORTED, "row_sum: D too large");
     RowSumArgs a;
     a.x = x; a.out = out; a.C = C; a.D = (int32_t)D; a.shift = shift; a.scale = scale;

@@ -91,7 +91,10 @@ class HMCSampler(object):
     @property
     def acceptance_rate(self):
         if self.counter > 0:
-            return self.n_accepted / float(self.counter)
+            n = self.n_accepted
+            if isinstance(n, torch.Tensor):
+                n = n.to(torch.float64)
+            return n / float(self.counter)
         return 0.0
 
     @property

