@@ -1,0 +1,122 @@
+"""
+Posterior = product of likelihoods and priors.  Mirror of reference
+``binf/pdf/posteriors.py:15-210``; this is the gradient dispatch every
+leapfrog step of the generic HMC tier goes through.
+
+Component order.  The reference iterates Python-2 dicts (hash order; for the
+log-prob even object-address order, ``:123,139-145``), so the order in which
+it adds component terms is not reproducible between processes.  This build
+fixes the order to SORTED COMPONENT NAME for both ``log_prob`` and
+``gradient``; single-component cases are unaffected.
+
+Quirk kept on purpose (Q4): a component contributes to ``gradient`` only if it
+has at least one variable AND at least one differentiable variable
+(``:183``) -- priors that register their variable as non-differentiable are
+part of the energy but not of the force.
+"""
+from binf_amd.pdf import AbstractBinfPDF
+
+
+class Posterior(AbstractBinfPDF):
+
+    def __init__(self, likelihoods, priors, name='the one and only posterior'):
+        super(Posterior, self).__init__(name)
+        self._likelihoods = likelihoods
+        self._priors = priors
+        self._setup_parameters()
+        self._components = dict(priors)
+        self._components.update(likelihoods)
+        self._register_component_variables(*self._get_component_variables())
+        self._set_original_variables()
+
+    # -- construction --------------------------------------------------------
+    def _setup_parameters(self):
+        """One posterior-level parameter per distinct component parameter
+        name; the components' parameters follow it (``:44-55``)."""
+        for group in (self._likelihoods, self._priors):
+            for comp in group.values():
+                for p in comp.parameters:
+                    if p not in self.parameters:
+                        self._register(p)
+                        self[p] = comp[p].__class__(comp[p].value, comp[p].name)
+                    comp[p].bind_to(self[p])
+
+    def _get_component_variables(self):
+        names, fixed, diff, types = [], [], [], []
+        for comp in self._components.values():
+            for v in comp.variables:
+                names.append(v)
+                types.append(comp.var_param_types[v])
+                if v in comp.differentiable_variables:
+                    diff.append(v)
+            for p in comp.parameters:
+                if p in comp._original_variables:
+                    fixed.append(p)
+        return names, set(fixed), set(diff), types
+
+    def _register_component_variables(self, names, fixed, diff, types):
+        for v in set(names):
+            self._register_variable(str(v), differentiable=v in diff)
+        self._original_variables.update(fixed)
+        self.update_var_param_types(**dict(zip(names, types)))
+
+    @property
+    def likelihoods(self):
+        return self._likelihoods
+
+    @property
+    def priors(self):
+        return self._priors
+
+    def _ordered_components(self):
+        return [self._components[n] for n in sorted(self._components)]
+
+    def _get_component_variables_list(self):
+        return {c: c.variables for c in self._components.values()}
+
+    # -- evaluation ----------------------------------------------------------
+    def _evaluate_components(self, **model_parameters):
+        return [c.log_prob(**{v: model_parameters[v] for v in c.variables})
+                for c in self._ordered_components()]
+
+    def _evaluate_log_prob(self, **model_parameters):
+        # numpy.sum over a short list = sequential adds (reference :147-151)
+        terms = self._evaluate_components(**model_parameters)
+        total = terms[0]
+        for t in terms[1:]:
+            total = total + t
+        return total
+
+    def _evaluate_gradient(self, **variables):
+        total = None
+        for f in self._ordered_components():
+            if len(f.variables) > 0 and len(f.differentiable_variables) > 0:
+                g = f.gradient(**{x: variables[x] for x in variables
+                                  if x in f.variables})
+                total = g if total is None else total + g
+        if total is None:
+            raise ValueError('posterior has no differentiable component')
+        return total
+
+    # -- copies --------------------------------------------------------------
+    def clone(self):
+        copy = self.__class__({n: c.clone() for n, c in self._likelihoods.items()},
+                              {n: c.clone() for n, c in self._priors.items()},
+                              self.name)
+        copy.set_fixed_variables_from_pdf(self)
+        return copy
+
+    def conditional_factory(self, **fixed_vars):
+        """A new posterior built from the conditional copies of every
+        component (``:201-210``)."""
+        liks = {n: c.conditional_factory(**fixed_vars)
+                for n, c in self._likelihoods.items()}
+        pris = {n: c.conditional_factory(**fixed_vars)
+                for n, c in self._priors.items()}
+        return self.__class__(liks, pris, self.name)
+
+    def native_hmc_spec(self, variable_name):
+        """Fused-trajectory descriptor when this (conditional) posterior is one
+        the HIP library knows how to integrate in a single launch."""
+        from binf_amd.example import native_poly
+        return native_poly.posterior_hmc_spec(self, variable_name)

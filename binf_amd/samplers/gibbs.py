@@ -1,0 +1,102 @@
+"""
+Gibbs sampling over named variables.  Mirror of reference
+``binf/samplers/gibbs.py:11-190`` (without the csb base class: its
+``State`` wrapper is never needed because no csb sampler exists here).
+
+One ``sample()`` = one sweep: for every variable in ALPHABETICAL order, refresh
+the conditional PDFs' parameters from the current state, let that variable's
+subsampler draw, store the draw (pinned by
+``binf/tests/samplers/gibbs.py:104-112``).  With chain-batched subsamplers the
+sweep advances all C chains at once; the state's values are device tensors.
+"""
+from collections import OrderedDict
+
+
+class GibbsSampler(object):
+
+    def __init__(self, pdf, state, subsamplers):
+        self._state = state
+        self._pdf = pdf
+        self._subsamplers = subsamplers
+        self._conditional_pdfs = {}
+        self._setup_conditional_pdfs()
+        self._update_subsampler_states()
+
+    # -- conditional PDFs ----------------------------------------------------
+    def _setup_conditional_pdfs(self):
+        """For every state variable: the full PDF with all OTHER variables
+        fixed to their current values; that conditional is handed to the
+        variable's subsampler (reference ``:40-52``)."""
+        current = self._state.variables
+        already_fixed = {x: self._pdf[x].value for x in self._pdf.parameters
+                         if x in self._pdf._original_variables}
+        for var in current:
+            fixed = {x: v for x, v in current.items() if x != var}
+            fixed.update(already_fixed)
+            cond = self._pdf.conditional_factory(**fixed)
+            self._conditional_pdfs[var] = cond
+            self._subsamplers[var].pdf = cond
+
+    def _update_conditional_pdf_params(self):
+        current = self._state.variables
+        for cond in self._conditional_pdfs.values():
+            for param in cond.parameters:
+                if param in current:
+                    cond[param].set(current[param])
+
+    def _checkstate(self, state):
+        if not type(state) == dict:
+            raise TypeError(state)
+
+    @property
+    def pdf(self):
+        return self._pdf
+
+    @pdf.setter
+    def pdf(self, value):
+        self._pdf = value
+        self._setup_conditional_pdfs()
+
+    @property
+    def state(self):
+        return self._state
+
+    @property
+    def subsamplers(self):
+        return self._subsamplers
+
+    def update_samplers(self, **samplers):
+        self._subsamplers.update(**samplers)
+
+    # -- sweep -----------------------------------------------------------------
+    def _update_subsampler_states(self):
+        current = self._state.variables
+        for variable in current:
+            self._subsamplers[variable].state = current[variable]
+
+    def _update_state(self, **variables):
+        self._state.update_variables(**variables)
+
+    def sample(self):
+        self._update_subsampler_states()          # "needed for RE", :144
+        for var in sorted(list(self._pdf.variables)):
+            self._update_conditional_pdf_params()
+            new = self._subsamplers[var].sample()
+            self._update_state(**{var: new})
+        return self._state
+
+    # -- statistics ------------------------------------------------------------
+    @property
+    def last_draw_stats(self):
+        # a subsampler's stats are keyed by ITS variable name, which must be
+        # the Gibbs key (reference :165-174)
+        return {k: v.last_draw_stats[k] for k, v in self._subsamplers.items()
+                if getattr(v, 'last_draw_stats', None) is not None}
+
+    @property
+    def sampling_stats(self):
+        out = OrderedDict()
+        for s in self._subsamplers.values():
+            if 'sampling_stats' in dir(s):
+                out.update(s.sampling_stats)
+        return out
