@@ -46,6 +46,19 @@ SIGNATURES = {
     'binf_gauss_grad_f64': (_i32, [_vp, _vp, _f64, _f64, _i64, _i64, _vp]),
     'binf_accept_select_f64': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                       _i32, _f64, _f64, _i64, _i64, _vp]),
+    'binf_row_sumsq_diff_f64': (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _f64,
+                                       _vp]),
+    'binf_poly_forward_f64': (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _vp]),
+    'binf_gauss_err_grad_f64': (_i32, [_vp, _vp, _f64, _vp, _vp, _i64, _i64,
+                                       _vp]),
+    'binf_gauss_err_logp_f64': (_i32, [_vp, _vp, _f64, _vp, _vp, _i64, _i64,
+                                       _vp]),
+    'binf_poly_gauss_logp_f64': (_i32, [_vp, _vp, _vp, _f64, _vp, _vp, _i64,
+                                        _i64, _i64, _vp]),
+    'binf_poly_gauss_grad_workspace_bytes': (_i64, [_i64, _i64, _i64]),
+    'binf_poly_gauss_grad_f64': (_i32, [_vp, _vp, _vp, _f64, _vp, _vp, _vp,
+                                        _i64, _i64, _i64, _i64, _vp]),
+    'binf_gamma_precision_update_f64': (_i32, [_vp, _vp, _f64, _vp, _i64, _vp]),
     'binf_pairwise_tree_height': (_i32, [_i64]),
     'binf_pairwise_leaf': (_i32, [_i64, _i32, _i32,
                                   ctypes.POINTER(_i64), ctypes.POINTER(_i64),
@@ -229,3 +242,120 @@ def accept_select(q_prop, q_old, e_before, e_after, u, q_out, accepted,
         dptr(dt_chain, numel=C, name='dt_chain'), int(bool(adapt)),
         float(uprate), float(downrate), C, D, stream_handle(q_prop.device))
     check(rc, 'binf_accept_select_f64')
+
+
+def _precision_args(precision, C, device):
+    """(host scalar, per-chain tensor or None) from a float or a [C] tensor."""
+    if isinstance(precision, torch.Tensor):
+        if precision.dim() == 0:
+            return float(precision), None
+        p = precision.reshape(-1)
+        if p.numel() != C:
+            raise ValueError('precision has %d entries for %d chains'
+                             % (p.numel(), C))
+        return 0.0, p.contiguous()
+    return float(precision), None
+
+
+def row_sumsq_diff(x, y, scale=1.0, weights=None):
+    C, D = _cd(x)
+    out = torch.empty(C, dtype=torch.float64, device=x.device)
+    rc = lib().binf_row_sumsq_diff_f64(dptr(x, numel=C * D, name='x'),
+                                       dptr(y, numel=D, name='y'),
+                                       dptr(weights, numel=D, name='weights'),
+                                       dptr(out), C, D, float(scale),
+                                       stream_handle(x.device))
+    check(rc, 'binf_row_sumsq_diff_f64')
+    return out
+
+
+def poly_forward(coeffs, xs):
+    C, K = _cd(coeffs)
+    N = xs.numel()
+    out = torch.empty((C, N), dtype=torch.float64, device=coeffs.device)
+    rc = lib().binf_poly_forward_f64(dptr(coeffs, numel=C * K, name='coeffs'),
+                                     dptr(xs, numel=N, name='xs'), dptr(out),
+                                     C, K, N, stream_handle(coeffs.device))
+    check(rc, 'binf_poly_forward_f64')
+    return out
+
+
+def gauss_err_grad(mock, ys, precision):
+    C, N = _cd(mock)
+    tau, tau_chain = _precision_args(precision, C, mock.device)
+    out = torch.empty_like(mock)
+    rc = lib().binf_gauss_err_grad_f64(dptr(mock, numel=C * N, name='mock'),
+                                       dptr(ys, numel=N, name='ys'), tau,
+                                       dptr(tau_chain, numel=C, name='precision'),
+                                       dptr(out), C, N,
+                                       stream_handle(mock.device))
+    check(rc, 'binf_gauss_err_grad_f64')
+    return out
+
+
+def gauss_err_logp(mock, ys, precision):
+    C, N = _cd(mock)
+    tau, tau_chain = _precision_args(precision, C, mock.device)
+    out = torch.empty(C, dtype=torch.float64, device=mock.device)
+    rc = lib().binf_gauss_err_logp_f64(dptr(mock, numel=C * N, name='mock'),
+                                       dptr(ys, numel=N, name='ys'), tau,
+                                       dptr(tau_chain, numel=C, name='precision'),
+                                       dptr(out), C, N,
+                                       stream_handle(mock.device))
+    check(rc, 'binf_gauss_err_logp_f64')
+    return out
+
+
+def poly_gauss_logp(coeffs, xs, ys, precision):
+    C, K = _cd(coeffs)
+    N = xs.numel()
+    tau, tau_chain = _precision_args(precision, C, coeffs.device)
+    out = torch.empty(C, dtype=torch.float64, device=coeffs.device)
+    rc = lib().binf_poly_gauss_logp_f64(
+        dptr(coeffs, numel=C * K, name='coeffs'), dptr(xs, numel=N, name='xs'),
+        dptr(ys, numel=N, name='ys'), tau,
+        dptr(tau_chain, numel=C, name='precision'), dptr(out), C, K, N,
+        stream_handle(coeffs.device))
+    check(rc, 'binf_poly_gauss_logp_f64')
+    return out
+
+
+_grad_ws = {}
+
+
+def poly_gauss_grad(coeffs, design, ys, precision):
+    C, K = _cd(coeffs)
+    N = ys.numel()
+    if design.shape != (K, N):
+        raise ValueError('design matrix must be [%d x %d], got %s'
+                         % (K, N, tuple(design.shape)))
+    tau, tau_chain = _precision_args(precision, C, coeffs.device)
+    need = lib().binf_poly_gauss_grad_workspace_bytes(C, K, N)
+    ws = None
+    if need > 0:
+        key = (coeffs.device, need)
+        ws = _grad_ws.get(key)
+        if ws is None:
+            ws = torch.empty(need // 8, dtype=torch.float64,
+                             device=coeffs.device)
+            _grad_ws.clear()
+            _grad_ws[key] = ws
+    out = torch.empty((C, K), dtype=torch.float64, device=coeffs.device)
+    rc = lib().binf_poly_gauss_grad_f64(
+        dptr(coeffs, numel=C * K, name='coeffs'),
+        dptr(design, numel=K * N, name='design'), dptr(ys, numel=N, name='ys'),
+        tau, dptr(tau_chain, numel=C, name='precision'), dptr(out),
+        ws.data_ptr() if ws is not None else None, need, C, K, N,
+        stream_handle(coeffs.device))
+    check(rc, 'binf_poly_gauss_grad_f64')
+    return out
+
+
+def gamma_precision_update(g, lp_unit, prior_rate):
+    C = g.numel()
+    out = torch.empty(C, dtype=torch.float64, device=g.device)
+    rc = lib().binf_gamma_precision_update_f64(
+        dptr(g, numel=C, name='g'), dptr(lp_unit, numel=C, name='lp_unit'),
+        float(prior_rate), dptr(out), C, stream_handle(g.device))
+    check(rc, 'binf_gamma_precision_update_f64')
+    return out

@@ -5,135 +5,47 @@
 // Reference lines replaced: binf/samplers/hmc.py:116-123 (kick / drift),
 // :148,150 (energy reductions), :151-164 (accept, adapt, select) and the
 // TestHO gradient binf/pdf/__init__.py:191.
-#include "common.hpp"
+#include "rowsum.hpp"
 
 namespace binf {
 
 // ---------------------------------------------------------------------------
-// row reductions in numpy's pairwise order
+// row reductions in numpy's pairwise order (machinery: rowsum.hpp)
 // ---------------------------------------------------------------------------
-enum { OP_SUM = 0, OP_SUMSQ = 1, OP_SUMSQ_SHIFT = 2 };
+enum { OP_SUM = 0, OP_SUMSQ = 1, OP_SUMSQ_SHIFT = 2, OP_SUMSQ_DIFF = 3, OP_SUMSQ_DIFF_DIV = 4 };
 
-template <int OP>
-__device__ inline double red_elem(double x, double shift)
-{
-    if (OP == OP_SUM) return x;
-    if (OP == OP_SUMSQ) return x * x;
-    const double d = x - shift;
-    return d * d;
-}
-
-// Sum of one leaf (<=128 elements at `a`) by the 8 lanes of a group; every
-// lane of the wave must call it.  Returns the leaf sum in all 8 lanes.
-template <int OP>
-__device__ inline double leaf_sum(const double *a, int n, int lane, double shift,
-                                  bool active)
-{
-    const int j = lane & 7;
-    const int T = (n >= 8) ? (n >> 3) : 0;
-    const int rem = (n >= 8) ? (n & 7) : n;
-    double r = 0.0;
-    if (active && T > 0) {
-        r = red_elem<OP>(a[j], shift);
-        for (int t = 1; t < T; ++t) r = r + red_elem<OP>(a[8 * t + j], shift);
-    }
-    r = r + shfl_xor_f64(r, 1);
-    r = r + shfl_xor_f64(r, 2);
-    r = r + shfl_xor_f64(r, 4);
-    double res = (T > 0) ? r : -0.0;
-    double tail = 0.0;
-    if (active && j < rem) tail = red_elem<OP>(a[8 * T + j], shift);
-    const int leafbase = lane & ~7;
-#pragma unroll
-    for (int i = 0; i < 7; ++i) {
-        const double v = shfl_f64(tail, leafbase + i);
-        const double s = res + v;
-        res = (i < rem) ? s : res;
-    }
-    return res;
-}
-
-struct RowSumArgs {
+struct RedArgs {
     const double *x;
-    double *out;
-    int64_t C;
-    int32_t D;
-    int32_t H;
+    const double *y;     // OP_SUMSQ_DIFF*: per-column vector subtracted first
+    const double *w;     // OP_SUMSQ_DIFF_DIV: per-column divisor of the square
     double shift;
-    double scale;
+    int64_t D;
 };
 
-// H <= 3: G = 8<<H lanes of one wave per row, 64/G rows per wave.
 template <int OP>
-__global__ void __launch_bounds__(256) row_sum_wave_kernel(const RowSumArgs a)
-{
-    const int lane = threadIdx.x & 63;
-    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int H = a.H;
-    const int lg = 3 + H;
-    const int slot = lane & ((1 << lg) - 1);
-    const int64_t row_raw = (wave << (6 - lg)) + (lane >> lg);
-    const bool valid = row_raw < a.C;
-    const int64_t row = valid ? row_raw : a.C - 1;
-    const Leaf L = pairwise_leaf(a.D, H, slot >> 3);
-    double res = leaf_sum<OP>(a.x + row * (int64_t)a.D + L.off, L.len, lane,
-                              a.shift, true);
-    for (int l = 0; l < H; ++l) {
-        const double o = shfl_xor_f64(res, 8 << l);
-        const double s = res + o;
-        res = (L.depth >= H - l) ? s : res;
+struct RedElem {
+    const double *row;
+    const double *y;
+    const double *w;
+    double shift;
+    __device__ inline double operator()(int i) const
+    {
+        const double x = row[i];
+        if (OP == OP_SUM) return x;
+        if (OP == OP_SUMSQ) return x * x;
+        const double d = (OP == OP_SUMSQ_SHIFT) ? x - shift : x - y[i];
+        if (OP == OP_SUMSQ_DIFF_DIV) return d * d / w[i];
+        return d * d;
     }
-    if (valid && slot == 0) a.out[row] = a.scale * (0.0 + res);
-}
-
-// Any D: one 256-thread workgroup per row.  numpy's buffered reduction feeds
-// the pairwise loop NPY_BUFSIZE = 8192 elements at a time and adds the chunk
-// sums up one after the other; a chunk's tree has height <= 6 (64 leaves), so
-// its leaf sums and the leaf tree fit in 64 LDS slots.
-constexpr int NPY_BUFSIZE = 8192;
+};
 
 template <int OP>
-__global__ void __launch_bounds__(256) row_sum_block_kernel(const RowSumArgs a)
-{
-    __shared__ double S[64];
-    __shared__ int dep[64];
-    const int H = a.H;                       // height for min(D, 8192) elements
-    const int npaths = 1 << H;
-    const int lane = threadIdx.x & 63;
-    const int group = threadIdx.x >> 3;      // 32 groups of 8 lanes
-    const int64_t row = blockIdx.x;
-    const double *x = a.x + row * (int64_t)a.D;
-    double total = 0.0;                      // the reduction's identity
-    for (int cbase = 0; cbase == 0 || cbase < a.D; cbase += NPY_BUFSIZE) {
-        const int n = (a.D - cbase < NPY_BUFSIZE) ? a.D - cbase : NPY_BUFSIZE;
-        for (int base = 0; base < npaths; base += 32) {
-            const int path = base + group;
-            const bool act = path < npaths;
-            const Leaf L = pairwise_leaf(n, H, act ? path : 0);
-            const double s = leaf_sum<OP>(x + cbase + L.off, L.len, lane,
-                                          a.shift, act);
-            if (act && (lane & 7) == 0) {
-                S[path] = s;
-                dep[path] = L.depth;
-            }
-        }
-        __syncthreads();
-        for (int l = 0; l < H; ++l) {
-            double v = 0.0;
-            const int p = threadIdx.x;
-            if (p < npaths) {
-                const double mine = S[p];
-                v = (dep[p] >= H - l) ? mine + S[p ^ (1 << l)] : mine;
-            }
-            __syncthreads();
-            if (p < npaths) S[p] = v;
-            __syncthreads();
-        }
-        total = total + S[0];
-        __syncthreads();
+struct RedMake {
+    __device__ static inline RedElem<OP> make(const RedArgs &a, int64_t row)
+    {
+        return RedElem<OP>{a.x + row * a.D, a.y, a.w, a.shift};
     }
-    if (threadIdx.x == 0) a.out[row] = a.scale * total;
-}
+};
 
 // ---------------------------------------------------------------------------
 // elementwise leapfrog pieces
@@ -212,24 +124,6 @@ __global__ void __launch_bounds__(256) accept_select_kernel(const AcceptArgs a)
     }
 }
 
-template <int OP>
-static int32_t row_sum_launch(const RowSumArgs &a, hipStream_t st)
-{
-    if (a.H <= 3) {
-        const int64_t rows_per_wave = 64 >> (3 + a.H);
-        const int64_t waves = (a.C + rows_per_wave - 1) / rows_per_wave;
-        const int64_t blocks = (waves + 3) / 4;
-        if (blocks > 0x7fffffffLL) return fail(BINF_E_UNSUPPORTED, "row_sum: too many rows");
-        row_sum_wave_kernel<OP><<<dim3((unsigned)blocks), 256, 0, st>>>(a);
-    } else {
-        if (a.C > 0x7fffffffLL) return fail(BINF_E_UNSUPPORTED, "row_sum: too many rows");
-        row_sum_block_kernel<OP><<<dim3((unsigned)a.C), 256, 0, st>>>(a);
-    }
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return hip_fail(e, "row_sum launch");
-    return 0;
-}
-
 }  // namespace binf
 
 using namespace binf;
@@ -242,16 +136,29 @@ extern "C" int32_t binf_row_sum_f64(const double *x, double *out, int64_t C,
     if (op < 0 || op > 2) return fail(BINF_E_ARG, "row_sum: unknown op %d", op);
     if (C == 0) return 0;
     if ((!x && D > 0) || !out) return fail(BINF_E_ARG, "row_sum: null buffer");
-    if (D > 0x7fffffffLL) return fail(BINF_E_UNSUPPORTED, "row_sum: D too large");
-    RowSumArgs a;
-    a.x = x; a.out = out; a.C = C; a.D = (int32_t)D; a.shift = shift; a.scale = scale;
-    a.H = pairwise_tree_height(D < NPY_BUFSIZE ? D : NPY_BUFSIZE);
+    RedArgs a;
+    a.x = x; a.y = nullptr; a.w = nullptr; a.shift = shift; a.D = D;
     hipStream_t st = (hipStream_t)stream;
     switch (op) {
-    case OP_SUM: return row_sum_launch<OP_SUM>(a, st);
-    case OP_SUMSQ: return row_sum_launch<OP_SUMSQ>(a, st);
-    default: return row_sum_launch<OP_SUMSQ_SHIFT>(a, st);
+    case OP_SUM: return row_reduce_launch<RedMake<OP_SUM>, RedArgs>(a, C, D, scale, out, st, false, "row_sum");
+    case OP_SUMSQ: return row_reduce_launch<RedMake<OP_SUMSQ>, RedArgs>(a, C, D, scale, out, st, false, "row_sum");
+    default: return row_reduce_launch<RedMake<OP_SUMSQ_SHIFT>, RedArgs>(a, C, D, scale, out, st, false, "row_sum");
     }
+}
+
+extern "C" int32_t binf_row_sumsq_diff_f64(const double *x, const double *y,
+                                           const double *w, double *out,
+                                           int64_t C, int64_t D, double scale,
+                                           void *stream)
+{
+    if (C < 0 || D < 0) return fail(BINF_E_ARG, "row_sumsq_diff: negative size");
+    if (C == 0) return 0;
+    if (((!x || !y) && D > 0) || !out) return fail(BINF_E_ARG, "row_sumsq_diff: null buffer");
+    RedArgs a;
+    a.x = x; a.y = y; a.w = w; a.shift = 0.0; a.D = D;
+    if (w)
+        return row_reduce_launch<RedMake<OP_SUMSQ_DIFF_DIV>, RedArgs>(a, C, D, scale, out, (hipStream_t)stream, false, "row_sumsq_diff");
+    return row_reduce_launch<RedMake<OP_SUMSQ_DIFF>, RedArgs>(a, C, D, scale, out, (hipStream_t)stream, false, "row_sumsq_diff");
 }
 
 static int32_t ew_launch(int kind, double *y, const double *x, double timestep,

@@ -1,0 +1,441 @@
+// Polynomial forward model + Gaussian error model (BASELINE configs C1/C3/C4).
+// gfx950 (MI355X), wave64.
+//
+// Reference lines replaced:
+//   ForwardModel._evaluate / _evaluate_jacobi_matrix  binf/example/likelihood.py:24-30
+//   GaussianErrorModel log_prob / gradient            binf/example/likelihood.py:54-61
+//   Likelihood._evaluate_log_prob / _evaluate_gradient binf/pdf/likelihoods.py:141-155
+//   GammaSampler rate / draw                          binf/example/samplers.py:34-51
+//
+// log-prob: Horner evaluation in numpy.polynomial.polyval's order, squared
+// residuals summed in np.sum's order -> bit-identical chi^2.
+// gradient: G = (Theta.A - y) tau . A^T with the [K x N] design matrix A, as
+// two chained f64 MFMA products per 16x16 tile; the [C x N] mock data never
+// leaves registers.  BLAS summation order is not reproducible, so this path
+// is held to the reference by tolerance, not bitwise.
+#include "rowsum.hpp"
+
+namespace binf {
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------------------
+// Horner, numpy.polynomial.polynomial.polyval order:
+//   c0 = c[-1] + x*0;  for i in 2..K: c0 = c[-i] + c0*x
+// Coefficients above K-1 are zero-padded: 0 + 0*x steps are exact no-ops for
+// finite x, so one KMAX instantiation serves every K <= KMAX bit-exactly.
+// ---------------------------------------------------------------------------
+template <int KMAX>
+struct Horner {
+    double c[KMAX];
+    __device__ inline void load(const double *theta, int K)
+    {
+#pragma unroll
+        for (int i = 0; i < KMAX; ++i) c[i] = (i < K) ? theta[i] : 0.0;
+    }
+    __device__ inline double operator()(double x) const
+    {
+        double v = c[KMAX - 1] + x * 0.0;
+#pragma unroll
+        for (int i = KMAX - 2; i >= 0; --i) v = c[i] + v * x;
+        return v;
+    }
+};
+
+struct PolyArgs {
+    const double *theta;   // [C x K]
+    const double *xs;      // [N]
+    const double *ys;      // [N]
+    int32_t K;
+};
+
+template <int KMAX>
+struct ResidSq {
+    Horner<KMAX> h;
+    const double *xs;
+    const double *ys;
+    __device__ inline double operator()(int i) const
+    {
+        const double d = h(xs[i]) - ys[i];
+        return d * d;
+    }
+};
+
+template <int KMAX>
+struct ResidSqMake {
+    __device__ static inline ResidSq<KMAX> make(const PolyArgs &a, int64_t row)
+    {
+        ResidSq<KMAX> f;
+        f.h.load(a.theta + row * a.K, a.K);
+        f.xs = a.xs;
+        f.ys = a.ys;
+        return f;
+    }
+};
+
+// mock[c, n] = polyval(xs[n], theta[c, :])
+template <int KMAX>
+__global__ void __launch_bounds__(256)
+poly_forward_kernel(const PolyArgs a, double *out, int64_t C, int64_t N)
+{
+    const int64_t c = blockIdx.y;
+    Horner<KMAX> h;
+    h.load(a.theta + c * a.K, a.K);
+    for (int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x; n < N;
+         n += (int64_t)gridDim.x * 256)
+        out[c * N + n] = h(a.xs[n]);
+}
+
+// out[c, n] = (mock[c, n] - ys[n]) * tau_c          likelihood.py:59-61
+__global__ void __launch_bounds__(256)
+gauss_err_grad_kernel(const double *mock, const double *ys, double tau,
+                      const double *tau_chain, double *out, int64_t N)
+{
+    const int64_t c = blockIdx.y;
+    const double t = tau_chain ? tau_chain[c] : tau;
+    for (int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x; n < N;
+         n += (int64_t)gridDim.x * 256)
+        out[c * N + n] = (mock[c * N + n] - ys[n]) * t;
+}
+
+// lp[c] = -0.5 * chi2[c] * tau_c + N * 0.5 * log(tau_c)     likelihood.py:54-57
+__global__ void gauss_logp_finish_kernel(const double *chi2, double tau,
+                                         const double *tau_chain, double *out,
+                                         int64_t C, double n_data)
+{
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const double t = tau_chain ? tau_chain[c] : tau;
+    const double logZ = n_data * 0.5 * log(t);
+    out[c] = -0.5 * chi2[c] * t + logZ;
+}
+
+// tau[c] = g[c] / (-lp1[c] + prior_rate)                     samplers.py:34-51
+__global__ void gamma_update_kernel(const double *g, const double *lp1,
+                                    double prior_rate, double *out, int64_t C)
+{
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const double rate = -lp1[c] + prior_rate;
+    out[c] = g[c] / rate;
+}
+
+// ---------------------------------------------------------------------------
+// gradient: two chained f64 MFMA products per (16 data points x 16 chains)
+// ---------------------------------------------------------------------------
+struct GradArgs {
+    const double *theta;     // [C x K]
+    const double *A;         // [K x N] design matrix, A[i][n] = xs[n]**i
+    const double *ys;        // [N]
+    const double *tau_chain; // [C] or null
+    double tau;
+    double *part;            // [NS x C x K] partial sums (or the output if NS==1)
+    int64_t C;
+    int32_t K;
+    int32_t N;
+    int32_t tiles_per_split; // data tiles (of 16) per blockIdx.y
+};
+
+constexpr int LDA = 17;      // padded row length of the staged A tile (doubles)
+
+// KS = ceil(K/4) forward k-steps, RT = ceil(K/16) backward row tiles.
+template <int KS, int RT>
+__global__ void __launch_bounds__(256) poly_grad_mfma_kernel(const GradArgs a)
+{
+    constexpr int ROWS = (4 * KS > 16 * RT) ? 4 * KS : 16 * RT;
+    constexpr int PASSES = (ROWS + 15) / 16;
+    __shared__ double sA[2][ROWS][LDA];
+    __shared__ double sY[2][16];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int lc = lane & 15;
+    const int lk = lane >> 4;
+    const int64_t chain = (int64_t)blockIdx.x * 64 + wave * 16 + lc;
+    const bool cvalid = chain < a.C;
+    const int K = a.K, N = a.N;
+
+    // forward B operands: theta[chain][4s + lk]
+    double th[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const int k = 4 * s + lk;
+        th[s] = (cvalid && k < K) ? a.theta[chain * K + k] : 0.0;
+    }
+    const double tau = cvalid ? (a.tau_chain ? a.tau_chain[chain] : a.tau) : 0.0;
+
+    v4d G[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) G[rt] = (v4d){0.0, 0.0, 0.0, 0.0};
+
+    const int t0 = blockIdx.y * a.tiles_per_split;
+    int t1 = t0 + a.tiles_per_split;
+    const int ntiles = (N + 15) / 16;
+    if (t1 > ntiles) t1 = ntiles;
+
+    // staging: thread (srow, scol) moves A[16*pass + srow][n0 + scol]
+    const int srow = tid >> 4, scol = tid & 15;
+    double pre[PASSES];
+    double prey = 0.0;
+    auto fetch = [&](int t) {
+        const int n = t * 16 + scol;
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ++ps) {
+            const int k = 16 * ps + srow;
+            pre[ps] = (k < K && n < N) ? a.A[(int64_t)k * N + n] : 0.0;
+        }
+        if (tid < 16) prey = (t * 16 + tid < N) ? a.ys[t * 16 + tid] : 0.0;
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ++ps) {
+            const int k = 16 * ps + srow;
+            if (k < ROWS) sA[buf][k][scol] = pre[ps];
+        }
+        if (tid < 16) sY[buf][tid] = prey;
+    };
+
+    if (t0 < t1) {
+        fetch(t0);
+        stash(0);
+    }
+    __syncthreads();
+    for (int t = t0; t < t1; ++t) {
+        const int buf = (t - t0) & 1;
+        if (t + 1 < t1) fetch(t + 1);          // in flight during the MFMAs
+        // forward: M^T[n][c] = sum_k A[k][n] theta[c][k]
+        v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sA[buf][4 * s + lk][lc], th[s], acc, 0, 0, 0);
+        // error-model gradient in place: r[n][c] = (mock - y[n]) * tau_c
+        double rr[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int nl = lk + 4 * r;
+            rr[r] = (t * 16 + nl < N) ? (acc[r] - sY[buf][nl]) * tau : 0.0;
+        }
+        // backward: G^T[i][c] += sum_n A[i][n] r[n][c]; the D-layout register r
+        // of the forward product is exactly the B operand of k-step r.
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                G[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(sA[buf][16 * rt + lc][4 * s + lk], rr[s], G[rt], 0, 0, 0);
+        if (t + 1 < t1) stash(buf ^ 1);
+        __syncthreads();
+    }
+    if (cvalid) {
+        double *dst = a.part + ((int64_t)blockIdx.y * a.C + chain) * K;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = 16 * rt + lk + 4 * r;
+                if (i < K) dst[i] = G[rt][r];
+            }
+    }
+}
+
+// out[j] = part[0][j] + part[1][j] + ... in split order (deterministic)
+__global__ void split_reduce_kernel(const double *part, double *out, int64_t n,
+                                    int32_t ns)
+{
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    double s = part[j];
+    for (int k = 1; k < ns; ++k) s = s + part[(int64_t)k * n + j];
+    out[j] = s;
+}
+
+static int grad_splits(int64_t C, int64_t N)
+{
+    // aim at ~4 workgroups per CU; never more splits than data tiles
+    const int64_t wgx = (C + 63) / 64;
+    const int64_t ntiles = (N + 15) / 16;
+    int64_t ns = (1024 + wgx - 1) / wgx;
+    if (ns > 16) ns = 16;
+    if (ns > ntiles) ns = ntiles;
+    if (ns < 1) ns = 1;
+    return (int)ns;
+}
+
+template <int KS, int RT>
+static hipError_t grad_launch(const GradArgs &a, dim3 grid, hipStream_t st)
+{
+    poly_grad_mfma_kernel<KS, RT><<<grid, 256, 0, st>>>(a);
+    return hipGetLastError();
+}
+
+}  // namespace binf
+
+using namespace binf;
+
+#define BINF_KMAX_DISPATCH(K, CALL)                                          \
+    do {                                                                      \
+        if ((K) <= 4) { CALL(4); }                                            \
+        else if ((K) <= 8) { CALL(8); }                                       \
+        else if ((K) <= 16) { CALL(16); }                                     \
+        else if ((K) <= 36) { CALL(36); }                                     \
+        else { CALL(64); }                                                    \
+    } while (0)
+
+static int32_t check_poly(const char *what, int64_t C, int64_t K, int64_t N)
+{
+    if (C < 0 || K < 1 || N < 0)
+        return fail(BINF_E_ARG, "%s: need C>=0, K>=1, N>=0", what);
+    if (K > 64)
+        return fail(BINF_E_UNSUPPORTED, "%s: K=%lld coefficients > 64 not covered by the native polynomial kernels", what, (long long)K);
+    if (C > 65535 * 64LL || N > 0x7fffffffLL)
+        return fail(BINF_E_UNSUPPORTED, "%s: too large", what);
+    return 0;
+}
+
+extern "C" int32_t binf_poly_forward_f64(const double *coeffs, const double *xs,
+                                         double *out, int64_t C, int64_t K,
+                                         int64_t N, void *stream)
+{
+    int32_t rc = check_poly("poly_forward", C, K, N);
+    if (rc) return rc;
+    if (C == 0 || N == 0) return 0;
+    if (!coeffs || !xs || !out) return fail(BINF_E_ARG, "poly_forward: null buffer");
+    if (C > 65535) return fail(BINF_E_UNSUPPORTED, "poly_forward: more than 65535 chains per call");
+    PolyArgs a;
+    a.theta = coeffs; a.xs = xs; a.ys = nullptr; a.K = (int32_t)K;
+    int64_t bx = (N + 255) / 256;
+    if (bx > 256) bx = 256;
+    dim3 grid((unsigned)bx, (unsigned)C);
+    hipStream_t st = (hipStream_t)stream;
+#define CALL(KM) poly_forward_kernel<KM><<<grid, 256, 0, st>>>(a, out, C, N)
+    BINF_KMAX_DISPATCH(K, CALL);
+#undef CALL
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "poly_forward launch");
+    return 0;
+}
+
+extern "C" int32_t binf_gauss_err_grad_f64(const double *mock, const double *ys,
+                                           double precision,
+                                           const double *precision_chain,
+                                           double *out, int64_t C, int64_t N,
+                                           void *stream)
+{
+    if (C < 0 || N < 0) return fail(BINF_E_ARG, "gauss_err_grad: negative size");
+    if (C == 0 || N == 0) return 0;
+    if (!mock || !ys || !out) return fail(BINF_E_ARG, "gauss_err_grad: null buffer");
+    if (C > 65535) return fail(BINF_E_UNSUPPORTED, "gauss_err_grad: more than 65535 chains per call");
+    int64_t bx = (N + 255) / 256;
+    if (bx > 256) bx = 256;
+    gauss_err_grad_kernel<<<dim3((unsigned)bx, (unsigned)C), 256, 0, (hipStream_t)stream>>>(
+        mock, ys, precision, precision_chain, out, N);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "gauss_err_grad launch");
+    return 0;
+}
+
+extern "C" int32_t binf_gauss_err_logp_f64(const double *mock, const double *ys,
+                                           double precision,
+                                           const double *precision_chain,
+                                           double *out, int64_t C, int64_t N,
+                                           void *stream)
+{
+    // chi^2 in np.sum order, then -0.5*chi2*tau + N*0.5*log(tau)
+    int32_t rc = binf_row_sumsq_diff_f64(mock, ys, nullptr, out, C, N, 1.0, stream);
+    if (rc || C == 0) return rc;
+    gauss_logp_finish_kernel<<<dim3((unsigned)((C + 255) / 256)), 256, 0, (hipStream_t)stream>>>(
+        out, precision, precision_chain, out, C, (double)N);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "gauss_err_logp launch");
+    return 0;
+}
+
+extern "C" int32_t binf_poly_gauss_logp_f64(const double *coeffs, const double *xs,
+                                            const double *ys, double precision,
+                                            const double *precision_chain,
+                                            double *out, int64_t C, int64_t K,
+                                            int64_t N, void *stream)
+{
+    int32_t rc = check_poly("poly_gauss_logp", C, K, N);
+    if (rc) return rc;
+    if (C == 0) return 0;
+    if (!coeffs || ((!xs || !ys) && N > 0) || !out)
+        return fail(BINF_E_ARG, "poly_gauss_logp: null buffer");
+    PolyArgs a;
+    a.theta = coeffs; a.xs = xs; a.ys = ys; a.K = (int32_t)K;
+    hipStream_t st = (hipStream_t)stream;
+    // the element function is ~2K flops: always one workgroup per chain
+#define CALL(KM) rc = row_reduce_launch<ResidSqMake<KM>, PolyArgs>(a, C, N, 1.0, out, st, true, "poly_gauss_logp")
+    BINF_KMAX_DISPATCH(K, CALL);
+#undef CALL
+    if (rc) return rc;
+    gauss_logp_finish_kernel<<<dim3((unsigned)((C + 255) / 256)), 256, 0, st>>>(
+        out, precision, precision_chain, out, C, (double)N);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "poly_gauss_logp launch");
+    return 0;
+}
+
+extern "C" int64_t binf_poly_gauss_grad_workspace_bytes(int64_t C, int64_t K, int64_t N)
+{
+    if (C <= 0 || K <= 0 || N <= 0) return 0;
+    const int ns = grad_splits(C, N);
+    return ns > 1 ? (int64_t)ns * C * K * (int64_t)sizeof(double) : 0;
+}
+
+extern "C" int32_t binf_poly_gauss_grad_f64(const double *coeffs, const double *design,
+                                            const double *ys, double precision,
+                                            const double *precision_chain,
+                                            double *out, void *workspace,
+                                            int64_t workspace_bytes, int64_t C,
+                                            int64_t K, int64_t N, void *stream)
+{
+    int32_t rc = check_poly("poly_gauss_grad", C, K, N);
+    if (rc) return rc;
+    if (C == 0) return 0;
+    if (!coeffs || !out || ((!design || !ys) && N > 0))
+        return fail(BINF_E_ARG, "poly_gauss_grad: null buffer");
+    int ns = grad_splits(C, N);
+    const int64_t need = ns > 1 ? (int64_t)ns * C * K * (int64_t)sizeof(double) : 0;
+    if (need > 0 && (!workspace || workspace_bytes < need)) ns = 1;   // no workspace: single split
+    const int ntiles = (int)((N + 15) / 16);
+    GradArgs a;
+    a.theta = coeffs; a.A = design; a.ys = ys; a.tau_chain = precision_chain;
+    a.tau = precision; a.C = C; a.K = (int32_t)K; a.N = (int32_t)N;
+    a.tiles_per_split = (ntiles + ns - 1) / ns;
+    if (a.tiles_per_split < 1) a.tiles_per_split = 1;
+    a.part = ns > 1 ? (double *)workspace : out;
+    dim3 grid((unsigned)((C + 63) / 64), (unsigned)ns);
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e;
+    if (K <= 4)       e = grad_launch<1, 1>(a, grid, st);
+    else if (K <= 8)  e = grad_launch<2, 1>(a, grid, st);
+    else if (K <= 16) e = grad_launch<4, 1>(a, grid, st);
+    else if (K <= 32) e = grad_launch<8, 2>(a, grid, st);
+    else if (K <= 36) e = grad_launch<9, 3>(a, grid, st);
+    else if (K <= 48) e = grad_launch<12, 3>(a, grid, st);
+    else              e = grad_launch<16, 4>(a, grid, st);
+    if (e != hipSuccess) return hip_fail(e, "poly_gauss_grad launch");
+    if (ns > 1) {
+        const int64_t n = C * K;
+        split_reduce_kernel<<<dim3((unsigned)((n + 255) / 256)), 256, 0, st>>>(
+            (const double *)workspace, out, n, ns);
+        e = hipGetLastError();
+        if (e != hipSuccess) return hip_fail(e, "poly_gauss_grad reduce launch");
+    }
+    return 0;
+}
+
+extern "C" int32_t binf_gamma_precision_update_f64(const double *g, const double *lp_unit,
+                                                   double prior_rate, double *out,
+                                                   int64_t C, void *stream)
+{
+    if (C < 0) return fail(BINF_E_ARG, "gamma_precision_update: negative size");
+    if (C == 0) return 0;
+    if (!g || !lp_unit || !out) return fail(BINF_E_ARG, "gamma_precision_update: null buffer");
+    gamma_update_kernel<<<dim3((unsigned)((C + 255) / 256)), 256, 0, (hipStream_t)stream>>>(
+        g, lp_unit, prior_rate, out, C);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "gamma_precision_update launch");
+    return 0;
+}

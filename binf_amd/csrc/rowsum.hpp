@@ -1,0 +1,146 @@
+// Row reductions in numpy's summation order, generic over the element
+// function: out[row] = scale * np.sum([f(row, i) for i in range(D)]).
+// Shared by the generic tier (sum / sum of squares) and the polynomial model
+// (squared residuals evaluated on the fly).  gfx950, wave64.
+#pragma once
+#include "common.hpp"
+
+namespace binf {
+
+constexpr int NPY_BUFSIZE = 8192;   // numpy's ufunc buffer, in elements
+
+// Sum of one pairwise leaf (<=128 elements starting at `off`) by the 8 lanes
+// of a lane group; every lane of the wave must call it (shuffles).  Returns
+// the leaf sum in all 8 lanes.  f(i) = value of element i of the row.
+template <class F>
+__device__ inline double leaf_sum_f(const F &f, int off, int n, int lane,
+                                    bool active)
+{
+    const int j = lane & 7;
+    const int T = (n >= 8) ? (n >> 3) : 0;
+    const int rem = (n >= 8) ? (n & 7) : n;
+    double r = 0.0;
+    if (active && T > 0) {
+        r = f(off + j);
+        for (int t = 1; t < T; ++t) r = r + f(off + 8 * t + j);
+    }
+    r = r + shfl_xor_f64(r, 1);
+    r = r + shfl_xor_f64(r, 2);
+    r = r + shfl_xor_f64(r, 4);
+    double res = (T > 0) ? r : -0.0;
+    double tail = 0.0;
+    if (active && j < rem) tail = f(off + 8 * T + j);
+    const int leafbase = lane & ~7;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+        const double v = shfl_f64(tail, leafbase + i);
+        const double s = res + v;
+        res = (i < rem) ? s : res;
+    }
+    return res;
+}
+
+struct RowGeom {
+    int64_t C;
+    int32_t D;
+    int32_t H;       // pairwise tree height for min(D, 8192) elements
+    double scale;
+};
+
+// FM: functor factory -- FM::make(args, row) returns the per-row element
+// functor; ARGS is passed by value as kernel argument.
+
+// H <= 3 and D <= 8192: G = 8<<H lanes of one wave per row.
+template <class FM, class ARGS>
+__global__ void __launch_bounds__(256)
+row_reduce_wave_kernel(const ARGS args, const RowGeom g, double *out)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int H = g.H;
+    const int lg = 3 + H;
+    const int slot = lane & ((1 << lg) - 1);
+    const int64_t row_raw = (wave << (6 - lg)) + (lane >> lg);
+    const bool valid = row_raw < g.C;
+    const int64_t row = valid ? row_raw : g.C - 1;
+    const Leaf L = pairwise_leaf(g.D, H, slot >> 3);
+    const auto f = FM::make(args, row);
+    double res = leaf_sum_f(f, L.off, L.len, lane, true);
+    for (int l = 0; l < H; ++l) {
+        const double o = shfl_xor_f64(res, 8 << l);
+        const double s = res + o;
+        res = (L.depth >= H - l) ? s : res;
+    }
+    if (valid && slot == 0) out[row] = g.scale * (0.0 + res);
+}
+
+// Any D: one 256-thread workgroup per row.  numpy's buffered reduction feeds
+// the pairwise loop NPY_BUFSIZE elements at a time and adds the chunk sums up
+// one after the other; a chunk's tree has height <= 6 (64 leaves).
+template <class FM, class ARGS>
+__global__ void __launch_bounds__(256)
+row_reduce_block_kernel(const ARGS args, const RowGeom g, double *out)
+{
+    __shared__ double S[64];
+    __shared__ int dep[64];
+    const int H = g.H;
+    const int npaths = 1 << H;
+    const int lane = threadIdx.x & 63;
+    const int group = threadIdx.x >> 3;      // 32 groups of 8 lanes
+    const int64_t row = blockIdx.x;
+    const auto f = FM::make(args, row);
+    double total = 0.0;                      // the reduction's identity
+    for (int cbase = 0; cbase == 0 || cbase < g.D; cbase += NPY_BUFSIZE) {
+        const int n = (g.D - cbase < NPY_BUFSIZE) ? g.D - cbase : NPY_BUFSIZE;
+        for (int base = 0; base < npaths; base += 32) {
+            const int path = base + group;
+            const bool act = path < npaths;
+            const Leaf L = pairwise_leaf(n, H, act ? path : 0);
+            const double s = leaf_sum_f(f, cbase + L.off, L.len, lane, act);
+            if (act && (lane & 7) == 0) {
+                S[path] = s;
+                dep[path] = L.depth;
+            }
+        }
+        __syncthreads();
+        for (int l = 0; l < H; ++l) {
+            double v = 0.0;
+            const int p = threadIdx.x;
+            if (p < npaths) {
+                const double mine = S[p];
+                v = (dep[p] >= H - l) ? mine + S[p ^ (1 << l)] : mine;
+            }
+            __syncthreads();
+            if (p < npaths) S[p] = v;
+            __syncthreads();
+        }
+        total = total + S[0];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[row] = g.scale * total;
+}
+
+template <class FM, class ARGS>
+static int32_t row_reduce_launch(const ARGS &args, int64_t C, int64_t D,
+                                 double scale, double *out, hipStream_t st,
+                                 bool force_block, const char *what)
+{
+    if (C > 0x7fffffffLL || D > 0x7fffffffLL)
+        return fail(BINF_E_UNSUPPORTED, "%s: too large", what);
+    RowGeom g;
+    g.C = C; g.D = (int32_t)D; g.scale = scale;
+    g.H = pairwise_tree_height(D < NPY_BUFSIZE ? D : NPY_BUFSIZE);
+    if (g.H <= 3 && !force_block) {
+        const int64_t rows_per_wave = 64 >> (3 + g.H);
+        const int64_t waves = (C + rows_per_wave - 1) / rows_per_wave;
+        const int64_t blocks = (waves + 3) / 4;
+        row_reduce_wave_kernel<FM, ARGS><<<dim3((unsigned)blocks), 256, 0, st>>>(args, g, out);
+    } else {
+        row_reduce_block_kernel<FM, ARGS><<<dim3((unsigned)C), 256, 0, st>>>(args, g, out);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, what);
+    return 0;
+}
+
+}  // namespace binf

@@ -1,0 +1,146 @@
+"""
+The example application's likelihood pieces: polynomial forward model and
+Gaussian error model (mirror of reference ``binf/example/likelihood.py``),
+chain-batched and backed by the HIP kernels of ``csrc/poly.hip``.
+"""
+import numpy as np
+import torch
+
+from binf_amd import ArrayParameter, _native
+from binf_amd.model.errormodels import AbstractErrorModel
+from binf_amd.model.forwardmodels import AbstractForwardModel
+from binf_amd.params import Parameter as ScalarParameter
+
+POLYVAL = np.polynomial.polynomial.polyval
+
+
+def _as2d(x):
+    return x if x.dim() == 2 else x.reshape(1, -1)
+
+
+class ForwardModel(AbstractForwardModel):
+    """mock = polynomial(xses, coefficients); Jacobian rows are the powers of
+    ``xses`` (reference ``:11-37``).
+
+    ``polynomial`` is the callable the reference takes
+    (``numpy.polynomial.polynomial.polyval`` in ``example_script.py:21``).  For
+    exactly that callable the Horner recurrence runs natively (bit-identical
+    to numpy's); any other callable is applied as given.
+
+    The design matrix ``vstack([xses**i])`` is what the reference rebuilds on
+    every gradient call (``:28-30``); here it is built once per coefficient
+    count -- on the host with the same numpy expression, so its entries carry
+    the reference's bits -- and kept in HBM.
+    """
+
+    def __init__(self, xses, polynomial):
+        super(ForwardModel, self).__init__('polynomial')
+        self.xses = xses
+        self.polynomial = polynomial
+        self._dev = {}
+        self._register_variable('coefficients', differentiable=True)
+        self.update_var_param_types(coefficients=ArrayParameter)
+        self._set_original_variables()
+
+    # -- device-resident model data -----------------------------------------
+    def _xs_host(self):
+        x = self.xses
+        return x.detach().cpu().numpy() if isinstance(x, torch.Tensor) \
+            else np.asarray(x, dtype=np.float64)
+
+    def xs_device(self, device):
+        key = ('xs', device)
+        if key not in self._dev:
+            self._dev[key] = torch.from_numpy(
+                np.ascontiguousarray(self._xs_host())).to(device)
+        return self._dev[key]
+
+    def design_matrix(self, n_coefficients, device):
+        key = ('A', int(n_coefficients), device)
+        if key not in self._dev:
+            xs = self._xs_host()
+            A = np.vstack([xs ** i for i in range(int(n_coefficients))])
+            self._dev[key] = torch.from_numpy(np.ascontiguousarray(A)).to(device)
+        return self._dev[key]
+
+    @property
+    def is_native(self):
+        return self.polynomial is POLYVAL
+
+    # -- model interface ------------------------------------------------------
+    def _evaluate(self, coefficients):
+        if self.is_native and isinstance(coefficients, torch.Tensor) and \
+                coefficients.is_cuda:
+            out = _native.poly_forward(_as2d(coefficients),
+                                       self.xs_device(coefficients.device))
+            return out if coefficients.dim() == 2 else out.reshape(-1)
+        return self.polynomial(self.xses, coefficients)
+
+    def _evaluate_jacobi_matrix(self, coefficients):
+        if isinstance(coefficients, torch.Tensor):
+            return self.design_matrix(coefficients.shape[-1],
+                                      coefficients.device)
+        return np.vstack([self.xses ** i for i in range(len(coefficients))])
+
+    def clone(self):
+        copy = self.__class__(self.xses, self.polynomial)
+        copy._dev = self._dev            # immutable model data: share it
+        self._set_parameters(copy)
+        return copy
+
+    def native_spec(self):
+        return ('polynomial', self) if self.is_native else None
+
+
+class GaussianErrorModel(AbstractErrorModel):
+    """log p = -0.5*sum((mock-ys)**2)*precision + len(ys)*0.5*log(precision);
+    gradient w.r.t. mock_data = (mock-ys)*precision (reference ``:40-68``)."""
+
+    def __init__(self, ys):
+        super(GaussianErrorModel, self).__init__('error_model')
+        self.ys = ys
+        self._dev = {}
+        self._register_variable('mock_data')
+        self._register_variable('precision')
+        self.update_var_param_types(mock_data=ArrayParameter,
+                                    precision=ScalarParameter)
+        self._set_original_variables()
+
+    def ys_device(self, device):
+        if device not in self._dev:
+            y = self.ys
+            y = y.detach().cpu().numpy() if isinstance(y, torch.Tensor) \
+                else np.asarray(y, dtype=np.float64)
+            self._dev[device] = torch.from_numpy(np.ascontiguousarray(y)).to(device)
+        return self._dev[device]
+
+    def _evaluate_log_prob(self, mock_data, precision):
+        if isinstance(mock_data, torch.Tensor) and mock_data.is_cuda:
+            return _native.gauss_err_logp(_as2d(mock_data),
+                                          self.ys_device(mock_data.device),
+                                          precision)
+        logZ = len(self.ys) * 0.5 * np.log(precision)
+        return -0.5 * np.sum((mock_data - self.ys) ** 2) * precision + logZ
+
+    def _evaluate_gradient(self, mock_data, precision):
+        if isinstance(mock_data, torch.Tensor) and mock_data.is_cuda:
+            out = _native.gauss_err_grad(_as2d(mock_data),
+                                         self.ys_device(mock_data.device),
+                                         precision)
+            return out if mock_data.dim() == 2 else out.reshape(-1)
+        return (mock_data - self.ys) * precision
+
+    def clone(self):
+        copy = self.__class__(self.ys)
+        copy._dev = self._dev
+        copy.set_fixed_variables_from_pdf(self)
+        return copy
+
+    def native_spec(self):
+        return ('gaussian', self)
+
+
+def make_likelihood(xses, ys, polynomial):
+    from binf_amd.pdf.likelihoods import Likelihood
+    return Likelihood('points', ForwardModel(xses, polynomial),
+                      GaussianErrorModel(ys))

@@ -135,6 +135,67 @@ int32_t binf_accept_select_f64(const double *q_prop, const double *q_old,
                                double downrate, int64_t C, int64_t D,
                                void *stream);
 
+/* out[c] = scale * np.sum((x[c,:] - y[:])**2 / w[:]), numpy order; y, w device
+ * [D]; w == NULL means no division.  The chi^2 of GaussianErrorModel
+ * (binf/example/likelihood.py:57) and the GaussianPrior exponent
+ * (binf/example/priors.py:54). */
+int32_t binf_row_sumsq_diff_f64(const double *x, const double *y, const double *w,
+                                double *out, int64_t C, int64_t D, double scale,
+                                void *stream);
+
+/* ------------------------------------------------------------------------
+ * Polynomial forward model + Gaussian error model (the reference's example
+ * application, BASELINE configs C1/C3/C4).  K coefficients (<= 64), N data.
+ *   precision / precision_chain: host scalar, or device [C] per-chain values
+ *   (non-NULL wins) -- the Gibbs state's 'precision' variable.
+ * ---------------------------------------------------------------------- */
+
+/* out[c,n] = polyval(xs[n], coeffs[c,:]), Horner in numpy's order (bit-exact).
+ * ForwardModel._evaluate, binf/example/likelihood.py:24-26.  C <= 65535. */
+int32_t binf_poly_forward_f64(const double *coeffs, const double *xs, double *out,
+                              int64_t C, int64_t K, int64_t N, void *stream);
+
+/* out[c,n] = (mock[c,n] - ys[n]) * precision_c.
+ * GaussianErrorModel._evaluate_gradient, likelihood.py:59-61.  C <= 65535. */
+int32_t binf_gauss_err_grad_f64(const double *mock, const double *ys,
+                                double precision, const double *precision_chain,
+                                double *out, int64_t C, int64_t N, void *stream);
+
+/* out[c] = -0.5*np.sum((mock[c,:]-ys)**2)*precision_c + N*0.5*log(precision_c).
+ * GaussianErrorModel._evaluate_log_prob, likelihood.py:54-57. */
+int32_t binf_gauss_err_logp_f64(const double *mock, const double *ys,
+                                double precision, const double *precision_chain,
+                                double *out, int64_t C, int64_t N, void *stream);
+
+/* Likelihood._evaluate_log_prob (binf/pdf/likelihoods.py:141-146) for the
+ * polynomial + Gaussian pair, fused: the mock data is never materialised.
+ * chi^2 is bit-identical to the numpy path; log() is the device's. */
+int32_t binf_poly_gauss_logp_f64(const double *coeffs, const double *xs,
+                                 const double *ys, double precision,
+                                 const double *precision_chain, double *out,
+                                 int64_t C, int64_t K, int64_t N, void *stream);
+
+/* Likelihood._evaluate_gradient (binf/pdf/likelihoods.py:148-155) for the same
+ * pair: out[c,:] = J . ((mock_c - ys) * precision_c) with the Jacobian
+ * J = design [K x N] (design[i][n] = xs[n]**i, likelihood.py:28-30), as two
+ * chained f64 MFMA products per tile.  workspace: device scratch of
+ * binf_poly_gauss_grad_workspace_bytes(C,K,N) bytes (caller-owned; if NULL or
+ * too small the data range is not split and small chain counts under-fill
+ * the chip).  Deterministic; held to the reference by tolerance (BLAS order). */
+int64_t binf_poly_gauss_grad_workspace_bytes(int64_t C, int64_t K, int64_t N);
+int32_t binf_poly_gauss_grad_f64(const double *coeffs, const double *design,
+                                 const double *ys, double precision,
+                                 const double *precision_chain, double *out,
+                                 void *workspace, int64_t workspace_bytes,
+                                 int64_t C, int64_t K, int64_t N, void *stream);
+
+/* Conjugate precision draw, GammaSampler.sample (binf/example/samplers.py:34-51):
+ * out[c] = g[c] / (-lp_unit[c] + prior_rate), g = supplied Gamma(shape) variates,
+ * lp_unit = likelihood log-prob evaluated at precision = 1. */
+int32_t binf_gamma_precision_update_f64(const double *g, const double *lp_unit,
+                                        double prior_rate, double *out, int64_t C,
+                                        void *stream);
+
 /* ------------------------------------------------------------------------
  * Host-side helpers exposing the reduction geometry the kernels use, so that
  * CPU tests can check it against numpy's pairwise summation (no GPU needed).

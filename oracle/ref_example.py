@@ -1,0 +1,80 @@
+"""
+TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).  numpy restatement of the
+example application's Gibbs loop with HMC on the coefficients -- one chain,
+exactly the operations the reference classes would perform:
+
+  GibbsSampler.sample            binf/samplers/gibbs.py:136-151  (alphabetical
+                                 sweep: 'coefficients', then 'precision')
+  HMCSampler.sample              binf/samplers/hmc.py:136-164
+  conditional Posterior          binf/pdf/posteriors.py:147-151,173-187,201-210
+  GammaSampler.sample            binf/example/samplers.py:27-51
+  priors of make_priors()        binf/example/priors.py:66-73
+
+Parity status: the plumbing rules are pinned by the reference's test
+known-answers (tests/test_host_mirror.py); the numerics are **parity
+unpinned** (the reference never runs HMC and cannot be imported here).
+
+Quirk Q6 is reproduced: the GammaPrior inside every CONDITIONAL posterior is a
+clone built with (shape, shape) (binf/example/priors.py:27-32), so both the
+HMC energy's constant term and the Gamma draw's rate use rate == shape == 1.0,
+not the 0.2 that make_priors() constructs.
+"""
+import numpy as np
+
+from oracle import ref_numpy as R
+
+PRIOR_SHAPE = 1.0
+PRIOR_RATE_CONSTRUCTED = 0.2          # binf/example/priors.py:69
+PRIOR_RATE_IN_CONDITIONALS = 1.0      # == shape, quirk Q6
+
+
+def example_data(n_data_points=20, seed=0):
+    """example_script.py:17-26 after np.random.seed(seed)."""
+    np.random.seed(seed)
+    real_coeffs = np.array([2.0, -4.0, 1.0, 1.5])
+    real_precision = 2.5
+    xses = np.linspace(-2, 2, n_data_points)
+    ys = np.random.normal(loc=R.polyval(xses, real_coeffs),
+                          scale=1.0 / np.sqrt(real_precision))
+    return xses, ys
+
+
+def conditional_pdf(xses, ys, precision, K):
+    return R.PolyCoefficientsConditional(
+        xses, ys, precision, prior_means=np.zeros(K),
+        prior_variances=np.ones(K) * 5, gamma_shape=PRIOR_SHAPE,
+        gamma_rate=PRIOR_RATE_IN_CONDITIONALS)
+
+
+def gibbs_hmc_chain(xses, ys, coeffs0, precision0, timestep, nsteps, p0, u, g):
+    """Run len(p0) Gibbs sweeps for ONE chain with injected draws:
+    p0[s] (momentum, [K]), u[s] (uniform), g[s] (Gamma(shape) variate).
+    Returns per-sweep coefficients, precisions, accept flags, energies."""
+    K = len(coeffs0)
+    n = len(ys)
+    coeffs = np.array(coeffs0, dtype=np.float64)
+    tau = float(precision0)
+    draws = {'i': 0}
+    sampler = R.RefHMCSampler(None, coeffs.copy(), timestep, nsteps,
+                              variable_name='coefficients',
+                              normal=lambda size: p0[draws['i']].copy(),
+                              uniform=lambda: u[draws['i']])
+    out_c, out_t, out_a, out_eb, out_ea = [], [], [], [], []
+    for s in range(len(p0)):
+        draws['i'] = s
+        # 'coefficients': HMC on the conditional posterior (precision fixed)
+        sampler.pdf = conditional_pdf(xses, ys, tau, K)
+        sampler.state = coeffs
+        coeffs = sampler.sample()
+        # 'precision': conjugate Gamma draw given the new coefficients
+        shape = R.gamma_shape(n, PRIOR_SHAPE)
+        rate = R.gamma_rate(xses, ys, coeffs, PRIOR_RATE_IN_CONDITIONALS)
+        tau = R.gamma_draw(g[s], rate)
+        out_c.append(coeffs.copy())
+        out_t.append(tau)
+        out_a.append(bool(sampler.last_move_accepted))
+        out_eb.append(sampler.last_E_before)
+        out_ea.append(sampler.last_E_after)
+    return dict(coefficients=np.array(out_c), precision=np.array(out_t),
+                accepted=np.array(out_a), e_before=np.array(out_eb),
+                e_after=np.array(out_ea), gamma_shape=shape)

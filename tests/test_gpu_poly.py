@@ -1,0 +1,323 @@
+"""GPU parity tests of the polynomial forward model + Gaussian error model
+path (BASELINE configs C1 / C3 / C4) through the C ABI and through the
+Posterior / Likelihood / Gibbs class stack.
+
+Bars: Horner forward and chi^2 are BIT-EXACT against numpy; everything that
+involves log() of the precision or the J.r contraction (numpy: BLAS dgemv,
+whose summation order is not reproducible) is held to 1e-10 relative
+(BASELINE.json north_star), accept flags identical."""
+import numpy as np
+import pytest
+import torch
+
+from binf_amd import _native
+from binf_amd.example.likelihood import (POLYVAL, ForwardModel,
+                                         GaussianErrorModel, make_likelihood)
+from binf_amd.example.misc import make_posterior
+from binf_amd.example.priors import GammaPrior, GaussianPrior
+from binf_amd.example.samplers import (GammaSampler, RWMCSampler,
+                                       make_hmc_sampler, make_sampler)
+from binf_amd.samplers import BinfState
+from binf_amd.samplers.hmc import HMCSampler
+from oracle import ref_example as RE
+from oracle import ref_numpy as R
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-10
+
+
+def dev_t(a, device):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(device)
+
+
+def rel_close(got, want, rtol=RTOL):
+    got, want = np.asarray(got), np.asarray(want)
+    scale = np.abs(want).max() if want.size else 1.0
+    return np.abs(got - want).max() <= rtol * max(scale, 1e-300)
+
+
+def synth(K, N, C, seed, xlim=1.0, tau=2.5):
+    rs = np.random.RandomState(seed)
+    xs = np.linspace(-xlim, xlim, N)
+    c_true = rs.standard_normal(K)
+    ys = R.polyval(xs, c_true) + rs.standard_normal(N) / np.sqrt(tau)
+    theta = c_true + 0.3 * rs.standard_normal((C, K))
+    return xs, ys, theta
+
+
+SHAPES = [(1, 1, 3), (4, 20, 5), (4, 20, 70), (7, 37, 9), (8, 16, 64),
+          (17, 100, 33), (33, 1000, 20), (33, 16384, 6), (36, 129, 3),
+          (48, 500, 4), (64, 8200, 2)]
+
+
+@pytest.mark.parametrize('K,N,C', SHAPES)
+def test_poly_forward_is_numpy_polyval_bitwise(device, K, N, C):
+    xs, ys, theta = synth(K, N, C, K * 100 + N, xlim=2.0 if K <= 8 else 1.0)
+    got = _native.poly_forward(dev_t(theta, device), dev_t(xs, device)).cpu().numpy()
+    want = np.stack([POLYVAL(xs, theta[c]) for c in range(C)])
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize('K,N,C', SHAPES)
+def test_error_model_and_fused_logp(device, K, N, C):
+    xs, ys, theta = synth(K, N, C, K * 7 + N)
+    mock = np.stack([POLYVAL(xs, theta[c]) for c in range(C)])
+    tmock, tys = dev_t(mock, device), dev_t(ys, device)
+    # chi^2 bit-exact: at precision 1 the log-prob is exactly -0.5*chi2
+    want1 = np.array([-0.5 * np.sum((mock[c] - ys) ** 2) * 1.0 +
+                      N * 0.5 * np.log(1.0) for c in range(C)])
+    assert np.array_equal(_native.gauss_err_logp(tmock, tys, 1.0).cpu().numpy(), want1)
+    assert np.array_equal(
+        _native.poly_gauss_logp(dev_t(theta, device), dev_t(xs, device), tys, 1.0)
+        .cpu().numpy(), want1)
+    # general precision, scalar and per chain (device log): tolerance
+    taus = np.random.RandomState(1).uniform(0.5, 4.0, size=C)
+    for prec, tarr in ((2.5, np.full(C, 2.5)), (dev_t(taus, device), taus)):
+        want = np.array([-0.5 * np.sum((mock[c] - ys) ** 2) * tarr[c] +
+                         N * 0.5 * np.log(tarr[c]) for c in range(C)])
+        assert rel_close(_native.gauss_err_logp(tmock, tys, prec).cpu().numpy(), want, 1e-13)
+        assert rel_close(_native.poly_gauss_logp(dev_t(theta, device), dev_t(xs, device),
+                                                 tys, prec).cpu().numpy(), want, 1e-13)
+    # error-model gradient: elementwise, exact
+    got = _native.gauss_err_grad(tmock, tys, dev_t(taus, device)).cpu().numpy()
+    assert np.array_equal(got, (mock - ys) * taus[:, None])
+
+
+@pytest.mark.parametrize('K,N,C', SHAPES + [(33, 4096, 130), (4, 20, 1000)])
+def test_mfma_gradient_matches_numpy_chain_rule(device, K, N, C):
+    """J . ((mock - ys) * tau) with J = vstack([xs**i]) (likelihoods.py:148-155)."""
+    xs, ys, theta = synth(K, N, C, K + N + C)
+    fwm = ForwardModel(xs, POLYVAL)
+    A = fwm.design_matrix(K, device)
+    assert np.array_equal(A.cpu().numpy(), np.vstack([xs ** i for i in range(K)]))
+    taus = np.random.RandomState(2).uniform(0.5, 4.0, size=C)
+    Jn = np.vstack([xs ** i for i in range(K)])
+    for prec, tarr in ((2.5, np.full(C, 2.5)), (dev_t(taus, device), taus)):
+        got = _native.poly_gauss_grad(dev_t(theta, device), A, dev_t(ys, device),
+                                      prec).cpu().numpy()
+        want = np.stack([Jn.dot((POLYVAL(xs, theta[c]) - ys) * tarr[c])
+                         for c in range(C)])
+        # per-row scale: sum |J| |r| bounds the rounding of the contraction
+        bound = np.stack([np.abs(Jn).dot(np.abs((POLYVAL(xs, theta[c]) - ys) * tarr[c]))
+                          for c in range(C)])
+        assert np.all(np.abs(got - want) <= RTOL * np.maximum(bound, 1e-300))
+        assert rel_close(got, want, 1e-9)
+    # deterministic: two runs give identical bits
+    g1 = _native.poly_gauss_grad(dev_t(theta, device), A, dev_t(ys, device), 2.5)
+    g2 = _native.poly_gauss_grad(dev_t(theta, device), A, dev_t(ys, device), 2.5)
+    assert torch.equal(g1, g2)
+
+
+def test_likelihood_stack_dispatches_to_fused_kernels(device):
+    K, N, C = 4, 20, 12
+    xs, ys, theta = synth(K, N, C, 5, xlim=2.0)
+    L = make_likelihood(xs, ys, POLYVAL)
+    assert L.variables == {'coefficients', 'precision'}
+    tc = dev_t(theta, device)
+    lp = L.log_prob(coefficients=tc, precision=2.5).cpu().numpy()
+    gr = L.gradient(coefficients=tc, precision=2.5).cpu().numpy()
+    Jn = np.vstack([xs ** i for i in range(K)])
+    for c in range(C):
+        mock = POLYVAL(xs, theta[c])
+        assert abs(lp[c] - (-0.5 * np.sum((mock - ys) ** 2) * 2.5 +
+                            N * 0.5 * np.log(2.5))) <= 1e-12 * abs(lp[c])
+        assert np.allclose(gr[c], Jn.dot((mock - ys) * 2.5), rtol=1e-10, atol=1e-12)
+    # the unfused plug-in route (models called as written) agrees
+    mock_t = L.forward_model(coefficients=tc)
+    lp2 = L.error_model.log_prob(mock_data=mock_t, precision=2.5)
+    assert np.allclose(lp2.cpu().numpy(), lp, rtol=1e-13)
+    from binf_amd.pdf.likelihoods import contract_jacobian
+    g2 = contract_jacobian(L.forward_model.jacobi_matrix(coefficients=tc),
+                           L.error_model.gradient(mock_data=mock_t, precision=2.5))
+    assert np.allclose(g2.cpu().numpy(), gr, rtol=1e-10, atol=1e-12)
+
+
+def test_non_numpy_polynomial_callable_is_applied_as_given(device):
+    xs = np.linspace(-1, 1, 10)
+    fwm = ForwardModel(dev_t(xs, device), lambda x, c: c[..., :1] + 2.0 * x)
+    assert fwm.native_spec() is None
+    c = torch.ones((3, 2), dtype=torch.float64, device=device)
+    assert torch.allclose(fwm(coefficients=c)[0], 1.0 + 2.0 * dev_t(xs, device))
+
+
+def test_priors_match_reference_formulas_and_quirks(device):
+    K, C = 4, 9
+    rs = np.random.RandomState(0)
+    theta = rs.standard_normal((C, K))
+    means, var = rs.standard_normal(K), rs.uniform(1, 5, K)
+    cp = GaussianPrior(means, var)
+    got = cp.log_prob(coefficients=dev_t(theta, device)).cpu().numpy()
+    want = np.array([-0.5 * np.sum((theta[c] - means) ** 2 / var) for c in range(C)])
+    assert np.array_equal(got, want)
+    assert cp.differentiable_variables == set()            # quirk Q4
+    gp = GammaPrior(1.0, 0.2)
+    tau = dev_t(rs.uniform(0.5, 3, C), device)
+    assert torch.allclose(gp.log_prob(precision=tau), (1.0 - 1.0) * torch.log(tau) - tau * 0.2)
+    cl = gp.clone()
+    assert cl.shape == 1.0 and cl.rate == 1.0             # quirk Q6
+
+
+def test_conditional_posterior_matches_restatement(device):
+    """Energy = all three components in sorted-name order; force = likelihood
+    only (quirk Q4)."""
+    xs, ys = RE.example_data()
+    K, C = 4, 16
+    theta = np.random.RandomState(3).standard_normal((C, K))
+    post = make_posterior(xs, ys, POLYVAL)
+    assert post.variables == {'coefficients', 'precision'}
+    cond = post.conditional_factory(precision=2.0)
+    assert cond.variables == {'coefficients'}
+    tc = dev_t(theta, device)
+    lp = cond.log_prob(coefficients=tc).cpu().numpy()
+    gr = cond.gradient(coefficients=tc).cpu().numpy()
+    for c in range(C):
+        ref = RE.conditional_pdf(xs, ys, 2.0, K)
+        assert abs(lp[c] - ref.log_prob(coefficients=theta[c])) <= 1e-12 * abs(lp[c])
+        assert np.allclose(gr[c], ref.gradient(coefficients=theta[c]), rtol=1e-10, atol=1e-12)
+
+
+@pytest.mark.parametrize('K,N,C,L,dt,xlim', [(4, 20, 24, 50, 0.02, 2.0),
+                                             (33, 2048, 6, 5, 2e-4, 1.0)])
+def test_hmc_on_polynomial_posterior_vs_restatement(device, K, N, C, L, dt, xlim):
+    """Generic tier around the fused log-prob / MFMA gradient kernels against
+    the numpy restatement of HMCSampler on the same conditional posterior."""
+    if K == 4:
+        xs, ys = RE.example_data(N)
+    else:
+        xs, ys, _ = synth(K, N, 1, 11, xlim)
+    rs = np.random.RandomState(K)
+    q0 = 0.1 * rs.standard_normal((C, K)) + (1.0 if K == 4 else 0.0)
+    p0 = rs.standard_normal((C, K))
+    u = rs.uniform(size=C)
+    post = make_posterior(xs, ys, POLYVAL) if K == 4 else None
+    if post is None:
+        from binf_amd.pdf.posteriors import Posterior
+        lik = make_likelihood(xs, ys, POLYVAL)
+        post = Posterior({lik.name: lik},
+                         {'precision_prior': GammaPrior(1.0, 0.2),
+                          'coefficients_prior': GaussianPrior(np.zeros(K), np.ones(K) * 5)})
+    cond = post.conditional_factory(precision=2.5)
+    s = HMCSampler(cond, dev_t(q0, device), dt, L, variable_name='coefficients')
+    out = s.sample(p0=dev_t(p0, device), u=dev_t(u, device)).cpu().numpy()
+    acc = s.last_move_accepted.cpu().numpy()
+    eb, ea = s.last_e_before.cpu().numpy(), s.last_e_after.cpu().numpy()
+    for c in range(C):
+        ref = R.RefHMCSampler(RE.conditional_pdf(xs, ys, 2.5, K), q0[c].copy(), dt, L,
+                              variable_name='coefficients',
+                              normal=lambda size, c=c: p0[c].copy(),
+                              uniform=lambda c=c: u[c])
+        want = ref.sample()
+        assert bool(acc[c]) == bool(ref.last_move_accepted), c
+        assert np.allclose(out[c], want, rtol=RTOL, atol=RTOL * np.abs(want).max())
+        assert abs(eb[c] - ref.last_E_before) <= RTOL * abs(ref.last_E_before)
+        assert abs(ea[c] - ref.last_E_after) <= 1e-8 * abs(ref.last_E_after)
+    assert 0 < acc.mean()
+
+
+def test_gamma_sampler_matches_restatement(device):
+    xs, ys = RE.example_data()
+    K, C = 4, 10
+    rs = np.random.RandomState(4)
+    theta = rs.standard_normal((C, K))
+    post = make_posterior(xs, ys, POLYVAL)
+    cond = post.conditional_factory(coefficients=dev_t(theta, device))
+    g = rs.gamma(R.gamma_shape(len(ys), 1.0), size=C)
+    gs = GammaSampler(cond, None, gamma=lambda shape, n, dev: dev_t(g, dev))
+    assert gs._calculate_shape() == R.gamma_shape(len(ys), 1.0) == 10.0
+    assert gs._get_prior().rate == 1.0                      # quirk Q6
+    tau = gs.sample().cpu().numpy()
+    want = np.array([R.gamma_draw(g[c], R.gamma_rate(xs, ys, theta[c], 1.0))
+                     for c in range(C)])
+    assert np.array_equal(tau, want)
+    # default source: the global legacy stream, np.random.gamma(shape, size=C)
+    np.random.seed(7)
+    g2 = np.random.gamma(10.0, size=C)
+    np.random.seed(7)
+    tau2 = GammaSampler(cond, None).sample().cpu().numpy()
+    assert np.array_equal(tau2, np.array([g2[c] / R.gamma_rate(xs, ys, theta[c], 1.0)
+                                          for c in range(C)]))
+
+
+def test_gibbs_within_hmc_c1_plumbing(device):
+    """BASELINE config C1: example_script.py's posterior, HMC (50 leapfrog
+    steps) on the coefficients inside Gibbs, precision by the conjugate
+    update; several sweeps of several chains against the single-chain
+    restatement with the same injected draws."""
+    xs, ys = RE.example_data()
+    K, C, L, dt, S = 4, 8, 50, 0.02, 4
+    rs = np.random.RandomState(21)
+    p0 = rs.standard_normal((S, C, K))
+    u = rs.uniform(size=(S, C))
+    shape = R.gamma_shape(len(ys), 1.0)
+    g = rs.gamma(shape, size=(S, C))
+    coeffs0 = np.ones((C, K)) + 0.05 * rs.standard_normal((C, K))
+    tau0 = np.ones(C)
+
+    start = BinfState(dict(coefficients=dev_t(coeffs0, device),
+                           precision=dev_t(tau0, device)))
+    post = make_posterior(xs, ys, POLYVAL)
+    sweep = {'s': 0}
+    gips = make_hmc_sampler(post, dt, L, start,
+                            gamma=lambda sh, n, d: dev_t(g[sweep['s']], d))
+    hmc = gips.subsamplers['coefficients']
+    got_c, got_t, got_a = [], [], []
+    for s in range(S):
+        sweep['s'] = s
+        hmc.rng = type('Inject', (), {
+            'normal': staticmethod(lambda shp, d, s=s: dev_t(p0[s], d)),
+            'uniform': staticmethod(lambda n, d, s=s: dev_t(u[s], d))})()
+        state = gips.sample()
+        got_c.append(state.variables['coefficients'].cpu().numpy().copy())
+        got_t.append(state.variables['precision'].cpu().numpy().copy())
+        got_a.append(hmc.last_move_accepted.cpu().numpy().copy())
+    stats = gips.last_draw_stats
+    assert set(stats) == {'coefficients'} and stats['coefficients'].stepsize == dt
+    for c in range(C):
+        ref = RE.gibbs_hmc_chain(xs, ys, coeffs0[c], tau0[c], dt, L,
+                                 p0[:, c], u[:, c], g[:, c])
+        for s in range(S):
+            assert bool(got_a[s][c]) == bool(ref['accepted'][s]), (c, s)
+            assert np.allclose(got_c[s][c], ref['coefficients'][s], rtol=1e-9, atol=1e-10)
+            assert abs(got_t[s][c] - ref['precision'][s]) <= 1e-9 * ref['precision'][s]
+
+
+def test_rwmc_gibbs_factory_runs_and_accepts(device):
+    """The reference's own make_sampler wiring (RWMC + Gamma), batched."""
+    xs, ys = RE.example_data()
+    C = 32
+    start = BinfState(dict(coefficients=torch.ones((C, 4), dtype=torch.float64, device=device),
+                           precision=torch.ones(C, dtype=torch.float64, device=device)))
+    np.random.seed(3)
+    gips = make_sampler(make_posterior(xs, ys, POLYVAL), 0.1, start)
+    for _ in range(30):
+        state = gips.sample()
+    rate = gips.last_draw_stats['coefficients'].acceptance_rate
+    assert rate.shape == (C,) and 0.0 < float(rate.mean()) < 1.0
+    assert torch.isfinite(state.variables['coefficients']).all()
+    assert (state.variables['precision'] > 0).all()
+
+
+def test_c3_full_size_gradient_properties(device):
+    """BASELINE C3 size (K=33, N=16384, C=8192): linearity of the force in
+    theta (the model is linear-Gaussian) and agreement with numpy on a sample
+    of chains."""
+    K, N, C = 33, 16384, 8192
+    xs, ys, _ = synth(K, N, 1, 7)
+    rs = np.random.RandomState(8)
+    theta = rs.standard_normal((C, K))
+    fwm = ForwardModel(xs, POLYVAL)
+    A, tys = fwm.design_matrix(K, device), dev_t(ys, device)
+    g1 = _native.poly_gauss_grad(dev_t(theta, device), A, tys, 2.5)
+    g0 = _native.poly_gauss_grad(torch.zeros((C, K), dtype=torch.float64, device=device), A, tys, 2.5)
+    g2 = _native.poly_gauss_grad(dev_t(2.0 * theta, device), A, tys, 2.5)
+    # g(2 theta) - g(0) == 2 (g(theta) - g(0)) up to rounding
+    lhs, rhs = (g2 - g0).cpu().numpy(), 2.0 * (g1 - g0).cpu().numpy()
+    assert np.abs(lhs - rhs).max() <= 1e-9 * np.abs(rhs).max()
+    Jn = np.vstack([xs ** i for i in range(K)])
+    for c in (0, 17, 4095, 8191):
+        want = Jn.dot((POLYVAL(xs, theta[c]) - ys) * 2.5)
+        assert np.allclose(g1[c].cpu().numpy(), want, rtol=1e-9, atol=1e-9 * np.abs(want).max())
+    lp = _native.poly_gauss_logp(dev_t(theta, device), dev_t(xs, device), tys, 1.0).cpu().numpy()
+    for c in (0, 8191):
+        assert lp[c] == -0.5 * np.sum((POLYVAL(xs, theta[c]) - ys) ** 2) * 1.0 + N * 0.5 * np.log(1.0)
