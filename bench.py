@@ -155,12 +155,12 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax[0])
         # the only collective of the path: gather one recorded draw (RCCL)
-        out = torch.empty((world * C, D), dtype=torch.float64, device=dev)
-        dist.all_gather_into_tensor(out, sampler.state)
+        from binf_amd.dist import gather_chains
+        gather_chains(sampler.state)
         barrier()
         t1 = time.perf_counter()
         for _ in range(5):
-            dist.all_gather_into_tensor(out, sampler.state)
+            gather_chains(sampler.state)
         barrier()
         gather_ms = (time.perf_counter() - t1) / 5 * 1e3
 

@@ -1,0 +1,127 @@
+"""
+Chains across GPUs.
+
+Chains never interact (the reference has no cross-chain operation), so the
+path shards trivially: one process per GPU, each owning a contiguous block of
+chains, NO collective while sampling.  The only exchange is gathering drawn
+samples -- ``torch.distributed`` with the ``nccl`` backend, which is RCCL over
+xGMI on ROCm (``gloo`` on CPU, used by the tests).  Because an all-gather of
+every draw would cost more than producing it (32 MiB per GPU per draw at C2),
+draws are recorded into an on-device store, thinned (the reference's own
+script keeps 1 in 20 after burn-in, ``example_script.py:41``), and gathered
+once.
+"""
+import torch
+
+
+def _dist():
+    import torch.distributed as dist
+    return dist
+
+
+def world():
+    """(rank, world_size); (0, 1) when torch.distributed is not initialised."""
+    dist = _dist()
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def shard_chains(n_chains, rank=None, world_size=None):
+    """Contiguous block of chains owned by ``rank``: ``(start, count)``.  The
+    first ``n_chains % world_size`` ranks own one chain more."""
+    if rank is None or world_size is None:
+        rank, world_size = world()
+    if n_chains < 0 or world_size < 1 or not 0 <= rank < world_size:
+        raise ValueError('bad shard request: n_chains=%r rank=%r world=%r'
+                         % (n_chains, rank, world_size))
+    base, extra = divmod(n_chains, world_size)
+    count = base + (1 if rank < extra else 0)
+    start = rank * base + min(rank, extra)
+    return start, count
+
+
+def gather_chains(local, n_chains_total=None, group=None):
+    """All-gather a per-chain tensor along dim 0 (chains).  ``local`` is
+    ``[C_local, ...]``; returns ``[C_total, ...]`` on every rank, rows in
+    global chain order.  Uneven shards (see :func:`shard_chains`) are padded to
+    the largest shard for the collective and trimmed afterwards."""
+    dist = _dist()
+    if not (dist.is_available() and dist.is_initialized()):
+        return local
+    ws = dist.get_world_size(group)
+    if ws == 1:
+        return local
+    c_local = local.shape[0]
+    if n_chains_total is None:
+        counts = [c_local] * ws
+        same = torch.tensor([c_local], dtype=torch.int64, device=local.device)
+        lo, hi = same.clone(), same.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
+        if int(lo) != int(hi):
+            raise ValueError('uneven shards need n_chains_total')
+    else:
+        counts = [shard_chains(n_chains_total, r, ws)[1] for r in range(ws)]
+        if counts[dist.get_rank(group)] != c_local:
+            raise ValueError('local shard has %d chains, expected %d'
+                             % (c_local, counts[dist.get_rank(group)]))
+    cmax = max(counts)
+    send = local.contiguous()
+    if c_local < cmax:
+        pad = torch.zeros((cmax - c_local,) + tuple(local.shape[1:]),
+                          dtype=local.dtype, device=local.device)
+        send = torch.cat([send, pad], dim=0)
+    out = torch.empty((ws * cmax,) + tuple(local.shape[1:]), dtype=local.dtype,
+                      device=local.device)
+    dist.all_gather_into_tensor(out, send, group=group)
+    if all(c == cmax for c in counts):
+        return out
+    parts = [out[r * cmax:r * cmax + counts[r]] for r in range(ws)]
+    return torch.cat(parts, dim=0)
+
+
+class SampleStore(object):
+    """Thinned on-device record of drawn samples with one deferred gather.
+
+    ``record(x)`` is called after every ``sample()``; every ``thin``-th call
+    (after ``burn_in`` calls) copies the ``[C_local x D]`` state into a
+    preallocated ``[capacity, C_local, D]`` buffer in HBM -- replaces the
+    Python list of deep-copied states of ``example_script.py:32-34``.
+    ``gather()`` returns ``[n_kept, C_total, D]`` on every rank.
+    """
+
+    def __init__(self, capacity, n_chains_local, n_dims, thin=1, burn_in=0,
+                 device=None, dtype=torch.float64):
+        if capacity < 1 or thin < 1 or burn_in < 0:
+            raise ValueError('capacity >= 1, thin >= 1, burn_in >= 0 required')
+        self.thin = thin
+        self.burn_in = burn_in
+        self.buffer = torch.empty((capacity, n_chains_local, n_dims),
+                                  dtype=dtype, device=device)
+        self.n_seen = 0
+        self.n_kept = 0
+
+    def record(self, x):
+        """Returns True if the draw was kept."""
+        i = self.n_seen
+        self.n_seen += 1
+        if i < self.burn_in or (i - self.burn_in) % self.thin != 0:
+            return False
+        if self.n_kept >= self.buffer.shape[0]:
+            raise IndexError('SampleStore is full (%d draws)' % self.n_kept)
+        self.buffer[self.n_kept].copy_(x.reshape(self.buffer.shape[1:]))
+        self.n_kept += 1
+        return True
+
+    def local(self):
+        return self.buffer[:self.n_kept]
+
+    def gather(self, n_chains_total=None, group=None):
+        kept = self.local()
+        if kept.shape[0] == 0:
+            return kept
+        # chains to dim 0 for the collective, back afterwards
+        g = gather_chains(kept.transpose(0, 1).contiguous(), n_chains_total,
+                          group)
+        return g.transpose(0, 1).contiguous()
