@@ -45,6 +45,13 @@ def parse():
     ap.add_argument('--pool', type=int, default=16,
                     help='momentum-draw buffers cycled through (pool*C*D*8 B; '
                          '16 -> 512 MiB, larger than the 256 MiB Infinity Cache)')
+    ap.add_argument('--fuse', type=int, default=32,
+                    help='transitions per launch: 1 = one HMCSampler.sample() '
+                         'per launch; n > 1 = HMCSampler.sample_n(n), the '
+                         'persistent kernel (same draws, bit-identical results, '
+                         'every transition\'s state still written to HBM)')
+    ap.add_argument('--thin', type=int, default=1,
+                    help='with --fuse > 1: record every thin-th state')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-chains', type=int, default=64)
     ap.add_argument('--cpu-calls', type=int, default=400)
@@ -134,15 +141,34 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(W):
-        sampler.sample(p0=p_pool[i % P], u=u_pool[i % P])
+    F = max(1, args.fuse)
+    if F > 1:
+        # one step is still ONE transition; they are issued F per launch
+        K = ((K + F - 1) // F) * F
+        W = ((W + F - 1) // F) * F
+        nchunk = max(2, P // F)
+        p_chunks = [torch.randn((F, C, D), dtype=torch.float64, device=dev,
+                                generator=gen) for _ in range(nchunk)]
+        u_chunks = [torch.rand((F, C), dtype=torch.float64, device=dev,
+                               generator=gen) for _ in range(nchunk)]
+        del p_pool, u_pool
+
+        def run(nsteps):
+            for i in range(nsteps // F):
+                sampler.sample_n(F, thin=args.thin, p0=p_chunks[i % nchunk],
+                                 u=u_chunks[i % nchunk], record=True)
+    else:
+        def run(nsteps):
+            for i in range(nsteps):
+                sampler.sample(p0=p_pool[i % P], u=u_pool[i % P])
+
+    run(W)
     barrier()
     ev0 = torch.cuda.Event(enable_timing=True)
     ev1 = torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record()
-    for i in range(K):
-        sampler.sample(p0=p_pool[i % P], u=u_pool[i % P])
+    run(K)
     ev1.record()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -168,8 +194,21 @@ def main():
         steps_total = float(world) * C * L * K
         value = steps_total / elapsed
         bytes_per_launch = (24.0 * D + 25.0) * C
+        # per transition (= per launch when --fuse 1)
         launch_s = dev_ms * 1e-3 / K
         achieved = bytes_per_launch / launch_s / 1e9
+        # HBM traffic from the committed PMC summary of this exact configuration
+        traffic, traffic_src = None, None
+        try:
+            pm = json.load(open(os.path.join(ROOT, 'profiles', 'r01_c_pmc_traffic.json')))
+            c = pm['config']
+            if (c['chains'], c['dims'], c['nsteps'], c['fuse'], c['thin'], c['mode']) == \
+                    (C, D, L, F, args.thin if F > 1 else 1, args.mode):
+                traffic = pm['hbm_bytes_per_transition']
+                traffic_src = 'profiles/r01_c_pmc_traffic.json (rocprofv3 --pmc ' \
+                              'FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2)'
+        except (OSError, ValueError, KeyError):
+            pass
         res = {
             'metric': 'chain*leapfrog-steps/sec, 1024-d Gaussian',
             'value': value,
@@ -183,8 +222,9 @@ def main():
             'data': 'synthetic',
             'config': {'workload': 'C2: %d-d isotropic Gaussian (k=1, x0=0), '
                                    '%d chains/GPU, %d leapfrog steps, dt=%g, '
-                                   'fused HMC transition, mode=%s'
-                                   % (D, C, L, dt, args.mode),
+                                   'fused HMC transition, mode=%s, %d '
+                                   'transition(s) per launch'
+                                   % (D, C, L, dt, args.mode, F),
                        'chains_per_gpu': C, 'n_dims': D, 'leapfrog_steps': L,
                        'parallelism': 'chains sharded x%d, no data-path '
                                       'collective' % world,
@@ -194,8 +234,13 @@ def main():
                          'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS,
                          'frac_of_measured_copy_ceiling': achieved / HBM_COPY_GBS,
-                         'traffic': None,
-                         'kernel': 'hmc_gauss_wave_kernel',
+                         'traffic': traffic, 'traffic_source': traffic_src,
+                         'per': 'transition (one HMCSampler.sample() worth of work)',
+                         'kernel': 'hmc_gauss_wave_kernel' if F == 1
+                         else 'hmc_gauss_persist_kernel',
+                         'transitions_per_launch': F,
+                         'states_recorded': 'every transition' if F == 1
+                         else 'every %d. transition' % args.thin,
                          'algorithmic_bytes_per_launch': bytes_per_launch,
                          'avg_launch_us': launch_s * 1e6},
         }

@@ -10,7 +10,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libbinf_hip.so')
+LIB_PATH = os.environ.get('BINF_LIB_OVERRIDE') or \
+    os.path.join(_HERE, 'csrc', 'libbinf_hip.so')   # override: A/B of builds
 
 MODE_EXACT = 0
 MODE_FMA = 1
@@ -38,6 +39,10 @@ SIGNATURES = {
     'binf_hmc_sample_gauss_f64': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                          _f64, _vp, _i64, _i64, _i32, _f64,
                                          _f64, _i32, _f64, _f64, _i32, _vp]),
+    'binf_hmc_sample_n_gauss_f64': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                           _vp, _vp, _f64, _vp, _i64, _i64,
+                                           _i32, _i32, _i32, _f64, _f64, _i32,
+                                           _f64, _f64, _i32, _vp]),
     'binf_row_sum_f64': (_i32, [_vp, _vp, _i64, _i64, _i32, _f64, _f64, _vp]),
     'binf_leapfrog_kick_f64': (_i32, [_vp, _vp, _f64, _vp, _i32, _i64, _i64,
                                       _i32, _vp]),
@@ -359,3 +364,26 @@ def gamma_precision_update(g, lp_unit, prior_rate):
         float(prior_rate), dptr(out), C, stream_handle(g.device))
     check(rc, 'binf_gamma_precision_update_f64')
     return out
+
+
+def hmc_sample_n_gauss(q0, p0, u, q_out, samples, accepted, n_accepted,
+                       e_before, e_after, timestep, dt_chain, nsteps, n, thin,
+                       k, x0, n_adapt, uprate, downrate, mode=MODE_EXACT):
+    """binf_hmc_sample_n_gauss_f64 on torch's current stream."""
+    C, D = _cd(q0)
+    n = int(n)
+    thin = int(thin)
+    nrec = n // thin
+    rc = lib().binf_hmc_sample_n_gauss_f64(
+        dptr(q0, numel=C * D, name='q0'),
+        dptr(p0, numel=n * C * D, name='p0'), dptr(u, numel=n * C, name='u'),
+        dptr(q_out, numel=C * D, name='q_out'),
+        dptr(samples, numel=nrec * C * D, name='samples'),
+        dptr(accepted, torch.uint8, n * C, 'accepted'),
+        dptr(n_accepted, torch.int64, C, 'n_accepted'),
+        dptr(e_before, numel=n * C, name='e_before'),
+        dptr(e_after, numel=n * C, name='e_after'), float(timestep),
+        dptr(dt_chain, numel=C, name='dt_chain'), C, D, int(nsteps), n, thin,
+        float(k), float(x0), int(n_adapt), float(uprate), float(downrate),
+        int(mode), stream_handle(q0.device))
+    check(rc, 'binf_hmc_sample_n_gauss_f64')

@@ -22,7 +22,7 @@
 // leaf (numpy's ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7))), the leaf's tail
 // elements, then xor-shuffles 8,16,32 up the leaf tree: bit-identical to
 // np.sum.
-#include "common.hpp"
+#include "gauss_common.hpp"
 
 namespace binf {
 
@@ -47,78 +47,6 @@ struct GaussArgs {
     int32_t H;      // tree height, G = 8 << H lanes per chain
     int32_t adapt;
 };
-
-// In-lane part of np.sum: numpy's j-th accumulator of a leaf adds a[8t+j] for
-// t = 0..T-1 in order; element t == T (if the lane has one) is a tail element
-// and is added after the leaf's accumulators have been combined.
-struct LaneSum {
-    double r;
-    double tail;
-};
-
-template <bool REGULAR>
-__device__ inline void lane_sum_add(LaneSum &s, double v, int t, int T)
-{
-    if (REGULAR) {
-        s.r = (t == 0) ? v : s.r + v;
-    } else {
-        const double n = s.r + v;
-        s.r = (t == 0) ? v : ((t < T) ? n : s.r);
-        s.tail = (t == T) ? v : s.tail;
-    }
-}
-
-// Cross-lane part of np.sum.  All lanes of the wave must call this (the
-// shuffles need a full exec mask).
-template <bool REGULAR>
-__device__ inline double chain_sum_finish(const LaneSum &s, int T, int rem,
-                                          int lane, int H, int leafdepth)
-{
-    double r = s.r;
-    // ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7))
-    r = r + shfl_xor_f64(r, 1);
-    r = r + shfl_xor_f64(r, 2);
-    r = r + shfl_xor_f64(r, 4);
-    double res = r;
-    if (!REGULAR) {
-        // n < 8: no accumulators, numpy starts from -0.0 and adds in order
-        res = (T > 0) ? r : -0.0;
-        const int leafbase = lane & ~7;
-#pragma unroll
-        for (int i = 0; i < 7; ++i) {
-            const double v = shfl_f64(s.tail, leafbase + i);
-            const double n = res + v;
-            res = (i < rem) ? n : res;
-        }
-    }
-    // join the leaves: level l combines the two depth-(H-l) subtrees
-    for (int l = 0; l < H; ++l) {
-        const double o = shfl_xor_f64(res, 8 << l);
-        const double n = res + o;
-        res = (leafdepth >= H - l) ? n : res;
-    }
-    return 0.0 + res;   // np.add.reduce starts from the identity +0.0
-}
-
-template <bool UNIT>
-__device__ inline double gauss_grad(double q, double k, double x0)
-{
-    // k*(x - x0), binf/pdf/__init__.py:191.  For k == 1, x0 == 0 both
-    // operations are exact identities, so skipping them changes no bit.
-    return UNIT ? q : k * (q - x0);
-}
-
-template <bool FMA>
-__device__ inline double kick(double p, double dt, double g)
-{
-    return FMA ? __builtin_fma(-dt, g, p) : p - dt * g;   // hmc.py:116,120,123
-}
-
-template <bool FMA>
-__device__ inline double drift(double q, double p, double dt)
-{
-    return FMA ? __builtin_fma(p, dt, q) : q + p * dt;    // hmc.py:119,122
-}
 
 template <int TMAX, bool REGULAR, bool UNIT, bool FMA, int NCH>
 __global__ void __launch_bounds__(256)
@@ -190,6 +118,12 @@ hmc_gauss_wave_kernel(const GaussArgs a)
         LaneSum sqa = {0.0, 0.0}, spa = {0.0, 0.0};   // E_after parts
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
+            // pin this group's values here (see hmc_gauss_persist.hip)
+#pragma unroll
+            for (int i = 0; i < GS; ++i) {
+                const int t = g * GS + i;
+                asm volatile("" : "+v"(p[c][t]), "+v"(q[c][t]));
+            }
             // E_before terms: (q-x0)**2, p**2                   hmc.py:148
 #pragma unroll
             for (int i = 0; i < GS; ++i) {

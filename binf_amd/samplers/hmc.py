@@ -157,6 +157,79 @@ class HMCSampler(object):
         self.state = q_out
         return q_out
 
+    # -- n transitions in one launch -------------------------------------------
+    def sample_n(self, n, thin=1, p0=None, u=None, record=True):
+        """``n`` consecutive ``sample()`` calls (the ``for i in range(n)`` loop
+        of the reference's ``example_script.py:33-34``), returning the recorded
+        states ``[n // thin, C, D]`` -- the state after transitions ``thin,
+        2*thin, ...`` -- or None if ``record`` is false.  Results are
+        bit-identical to calling ``sample()`` n times with the same draws.
+
+        For PDFs with a fused kernel this is ONE launch of the persistent
+        kernel (state kept in registers between transitions); otherwise it
+        loops over ``sample()``.  ``p0`` is ``[n, C, D]``, ``u`` is ``[n, C]``.
+        """
+        name = self._variable_name
+        if not isinstance(name, str):
+            raise TypeError('HMCSampler needs variable_name to sample()')
+        n, thin = int(n), int(thin)
+        if n < 1 or thin < 1:
+            raise ValueError('sample_n: n >= 1 and thin >= 1 required')
+        state = self.state
+        shape = state.shape
+        q0 = state if state.dim() == 2 else state.reshape(1, -1)
+        C, D = q0.shape
+        dev = q0.device
+        if p0 is None:
+            p0 = self.rng.normal((n, C, D), dev)
+        if u is None:
+            u = self.rng.uniform(n * C, dev)
+        p0 = p0.reshape(n, C, D)
+        u = u.reshape(n, C)
+        spec = None
+        get_spec = getattr(self.pdf, 'native_hmc_spec', None)
+        if get_spec is not None:
+            spec = get_spec(name)
+        nrec = n // thin
+        if not (spec is not None and spec[0] == 'gauss' and
+                _gauss_kernel_covers(D)):
+            out = []
+            for i in range(n):
+                x = self.sample(p0=p0[i], u=u[i])
+                if record and (i + 1) % thin == 0:
+                    out.append(x)
+            return torch.stack(out) if (record and out) else None
+
+        _, k, x0 = spec
+        n_adapt = max(0, min(n, self.timestep_adaption_limit - 1 - self.counter))
+        if n_adapt > 0 and self._dt_chain is None:
+            self._dt_chain = torch.full((C,), float(self._timestep),
+                                        dtype=torch.float64, device=dev)
+        if not isinstance(self.n_accepted, torch.Tensor):
+            self.n_accepted = torch.zeros(C, dtype=torch.int64, device=dev)
+        q_out = torch.empty_like(q0)
+        samples = torch.empty((nrec, C, D), dtype=torch.float64, device=dev) \
+            if (record and nrec > 0) else None
+        accepted = torch.empty((n, C), dtype=torch.uint8, device=dev)
+        eb = ea = None
+        if self.record_energies:
+            eb = torch.empty((n, C), dtype=torch.float64, device=dev)
+            ea = torch.empty((n, C), dtype=torch.float64, device=dev)
+        _native.hmc_sample_n_gauss(q0, p0.contiguous(), u.contiguous(), q_out,
+                                   samples, accepted, self.n_accepted, eb, ea,
+                                   self._timestep, self._dt_chain, self.nsteps,
+                                   n, thin, k, x0, n_adapt,
+                                   self.adaption_uprate,
+                                   self.adaption_downrate, _MODES[self.mode])
+        self.last_e_before, self.last_e_after = eb, ea
+        self._last_move_accepted = accepted[-1].view(torch.bool)
+        self.accepted_history = accepted.view(torch.bool)
+        self.counter += n
+        self.state = q_out.view(shape)
+        if samples is None:
+            return None
+        return samples if state.dim() == 2 else samples.reshape((nrec,) + tuple(shape))
+
     # -- fused tier ----------------------------------------------------------
     def _sample_fused_gauss(self, spec, q0, p0, u, accepted, adapt):
         _, k, x0 = spec

@@ -88,6 +88,36 @@ int32_t binf_hmc_sample_gauss_f64(const double *q0, const double *p0,
                                   int32_t mode, void *stream);
 
 /* ------------------------------------------------------------------------
+ * Persistent variant: n consecutive transitions of every chain in ONE launch
+ * -- the `for i in range(n): sampler.sample()` loop of example_script.py:33-34
+ * for the same Gaussian.  Bit-identical to n calls of
+ * binf_hmc_sample_gauss_f64 (same arithmetic, same order); the state stays in
+ * registers between transitions, so HBM sees only the momentum draws in and
+ * the recorded states out.
+ *
+ *   p0        device, [n*C*D]   draw s at p0 + s*C*D
+ *   u         device, [n*C]
+ *   q_out     device, [C*D]     state after the n-th transition (may be == q0)
+ *   samples   device, [(n/thin)*C*D] or NULL: the state after transitions
+ *             thin, 2*thin, ... (thin >= 1; thinning as example_script.py:41)
+ *   accepted, e_before, e_after   device, [n*C] or NULL (per transition)
+ *   n_accepted device, [C] or NULL: += number of accepted transitions
+ *   n_adapt   the first n_adapt transitions adapt dt_chain (hmc.py:156-157:
+ *             a caller with `counter` samples drawn and adaption limit `lim`
+ *             passes max(0, min(n, lim - 1 - counter)))
+ * ---------------------------------------------------------------------- */
+int32_t binf_hmc_sample_n_gauss_f64(const double *q0, const double *p0,
+                                    const double *u, double *q_out,
+                                    double *samples, uint8_t *accepted,
+                                    int64_t *n_accepted, double *e_before,
+                                    double *e_after, double timestep,
+                                    double *dt_chain, int64_t C, int64_t D,
+                                    int32_t nsteps, int32_t n, int32_t thin,
+                                    double k, double x0, int32_t n_adapt,
+                                    double uprate, double downrate,
+                                    int32_t mode, void *stream);
+
+/* ------------------------------------------------------------------------
  * Generic per-step tier: the pieces of HMCSampler.sample() as separate
  * chain-batched launches, for posteriors whose gradient comes from other code
  * (any plug-in with log_prob / gradient, reference binf/samplers/hmc.py:114,143).

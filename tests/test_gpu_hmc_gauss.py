@@ -398,3 +398,60 @@ def test_sampler_never_mutates_tensors_it_handed_out(device):
     torch.cuda.synchronize()
     assert torch.equal(q0, keep)          # quirk Q9: caller's array untouched
     assert torch.equal(a, a_copy)
+
+
+# --------------------------------------------------------------------------
+# persistent kernel: n transitions per launch == n single launches, bitwise
+# --------------------------------------------------------------------------
+@pytest.mark.parametrize('D,C,L,k,x0,dt,n,thin,limit', [
+    (1024, 40, 20, 1.0, 0.0, 0.2, 6, 1, 0),
+    (1024, 9, 5, 2.5, 0.3, 0.12, 7, 2, 0),
+    (768, 33, 20, 1.0, 0.0, 0.22, 5, 5, 0),
+    (33, 100, 7, 2.5, 0.3, 0.45, 9, 3, 6),
+    (4, 17, 3, 1.0, 0.0, 0.8, 8, 1, 100),
+    (258, 6, 4, 1.0, 0.1, 0.3, 4, 1, 3),
+    (200, 12, 10, 1.0, 0.0, 0.55, 3, 1, 0),
+])
+def test_sample_n_equals_n_single_launches(device, D, C, L, k, x0, dt, n, thin, limit):
+    rs = np.random.RandomState(D + n)
+    q0 = rs.standard_normal((C, D))
+    p0 = rs.standard_normal((n, C, D))
+    u = rs.uniform(size=(n, C))
+    a = HMCSampler(IsotropicGaussian(k, x0), dev_t(q0, device), dt, L,
+                   timestep_adaption_limit=limit, variable_name='x',
+                   record_energies=True)
+    singles, acc1, eb1, ea1 = [], [], [], []
+    for i in range(n):
+        singles.append(a.sample(p0=dev_t(p0[i], device), u=dev_t(u[i], device)).cpu().numpy())
+        acc1.append(a.last_move_accepted.cpu().numpy())
+        eb1.append(a.last_e_before.cpu().numpy())
+        ea1.append(a.last_e_after.cpu().numpy())
+    b = HMCSampler(IsotropicGaussian(k, x0), dev_t(q0, device), dt, L,
+                   timestep_adaption_limit=limit, variable_name='x',
+                   record_energies=True)
+    rec = b.sample_n(n, thin=thin, p0=dev_t(p0, device), u=dev_t(u, device))
+    torch.cuda.synchronize()
+    assert rec.shape == (n // thin, C, D)
+    for r in range(n // thin):
+        assert np.array_equal(rec[r].cpu().numpy(), singles[(r + 1) * thin - 1]), r
+    assert np.array_equal(b.state.cpu().numpy(), singles[-1])
+    assert np.array_equal(b.accepted_history.cpu().numpy(), np.stack(acc1))
+    assert np.array_equal(b.last_e_before.cpu().numpy(), np.stack(eb1))
+    assert np.array_equal(b.last_e_after.cpu().numpy(), np.stack(ea1))
+    assert np.array_equal(b.n_accepted.cpu().numpy(), a.n_accepted.cpu().numpy())
+    assert b.counter == a.counter == n
+    if limit:
+        assert np.array_equal(b.timestep.cpu().numpy(), a.timestep.cpu().numpy())
+    assert 0 < np.stack(acc1).mean() < 1 or D <= 4
+
+
+def test_sample_n_generic_pdf_falls_back_to_a_loop(device):
+    C, D, n = 5, 3000, 3
+    rs = np.random.RandomState(0)
+    q0, p0, u = rs.standard_normal((C, D)), rs.standard_normal((n, C, D)), rs.uniform(size=(n, C))
+    s = HMCSampler(IsotropicGaussian(), dev_t(q0, device), 0.1, 3, variable_name='x')
+    rec = s.sample_n(n, p0=dev_t(p0, device), u=dev_t(u, device))
+    want = q0
+    for i in range(n):
+        want = c_oracle.hmc_sample_gauss(want, p0[i], u[i], 0.1, 3)['q_out']
+    assert np.array_equal(rec[-1].cpu().numpy(), want)
