@@ -35,8 +35,9 @@ HBM_COPY_GBS = 6290.0        # measured float4 copy ceiling, same table
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=200)
-    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--steps', type=int, default=1024,
+                    help='timed transitions (HMCSampler.sample() calls worth of work)')
+    ap.add_argument('--warmup', type=int, default=128)
     ap.add_argument('--chains', type=int, default=4096, help='chains per GPU')
     ap.add_argument('--dims', type=int, default=1024)
     ap.add_argument('--nsteps', type=int, default=20, help='leapfrog steps')
@@ -45,7 +46,7 @@ def parse():
     ap.add_argument('--pool', type=int, default=16,
                     help='momentum-draw buffers cycled through (pool*C*D*8 B; '
                          '16 -> 512 MiB, larger than the 256 MiB Infinity Cache)')
-    ap.add_argument('--fuse', type=int, default=32,
+    ap.add_argument('--fuse', type=int, default=64,
                     help='transitions per launch: 1 = one HMCSampler.sample() '
                          'per launch; n > 1 = HMCSampler.sample_n(n), the '
                          'persistent kernel (same draws, bit-identical results, '
