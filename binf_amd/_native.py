@@ -64,6 +64,10 @@ SIGNATURES = {
     'binf_poly_gauss_grad_f64': (_i32, [_vp, _vp, _vp, _f64, _vp, _vp, _vp,
                                         _i64, _i64, _i64, _i64, _vp]),
     'binf_gamma_precision_update_f64': (_i32, [_vp, _vp, _f64, _vp, _i64, _vp]),
+    'binf_pairdist_forward_f64': (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i64,
+                                         _vp]),
+    'binf_pairdist_gauss_grad_f64': (_i32, [_vp, _vp, _f64, _vp, _vp, _i64,
+                                            _i64, _vp]),
     'binf_pairwise_tree_height': (_i32, [_i64]),
     'binf_pairwise_leaf': (_i32, [_i64, _i32, _i32,
                                   ctypes.POINTER(_i64), ctypes.POINTER(_i64),
@@ -387,3 +391,32 @@ def hmc_sample_n_gauss(q0, p0, u, q_out, samples, accepted, n_accepted,
         float(k), float(x0), int(n_adapt), float(uprate), float(downrate),
         int(mode), stream_handle(q0.device))
     check(rc, 'binf_hmc_sample_n_gauss_f64')
+
+
+def pairdist_forward(x, pair_i, pair_j):
+    C, D = _cd(x)
+    if D % 3:
+        raise ValueError('coordinates must be [n_chains, 3 * n_beads]')
+    P = pair_i.numel()
+    out = torch.empty((C, P), dtype=torch.float64, device=x.device)
+    rc = lib().binf_pairdist_forward_f64(
+        dptr(x, numel=C * D, name='x'), dptr(pair_i, torch.int32, P, 'pair_i'),
+        dptr(pair_j, torch.int32, P, 'pair_j'), dptr(out), C, D // 3, P,
+        stream_handle(x.device))
+    check(rc, 'binf_pairdist_forward_f64')
+    return out
+
+
+def pairdist_gauss_grad(x, ymat, precision):
+    C, D = _cd(x)
+    if D % 3:
+        raise ValueError('coordinates must be [n_chains, 3 * n_beads]')
+    n = D // 3
+    tau, tau_chain = _precision_args(precision, C, x.device)
+    out = torch.empty_like(x)
+    rc = lib().binf_pairdist_gauss_grad_f64(
+        dptr(x, numel=C * D, name='x'), dptr(ymat, numel=n * n, name='ymat'),
+        tau, dptr(tau_chain, numel=C, name='precision'), dptr(out), C, n,
+        stream_handle(x.device))
+    check(rc, 'binf_pairdist_gauss_grad_f64')
+    return out

@@ -1,0 +1,120 @@
+"""
+Pairwise-distance-restraint model (BASELINE config C5).  BUILD-DEFINED: the
+reference only names the chromatin application (``README.rst:9``) and holds no
+code for it, so this follows the shape of the reference's plug-in surface
+(``AbstractForwardModel`` / ``AbstractErrorModel``) and its Gaussian error
+model (``binf/example/likelihood.py:40-68``); parity is against the numpy
+formulation in ``oracle/ref_distance.py`` only.
+
+``coordinates`` is ``[C x 3n]`` (bead-major: x, y, z of bead 0, then bead 1 ...);
+the mock data are the n(n-1)/2 pair distances in ``numpy.triu_indices(n, 1)``
+order.
+"""
+import numpy as np
+import torch
+
+from binf_amd import ArrayParameter, _native
+from binf_amd.example.likelihood import GaussianErrorModel
+from binf_amd.model.forwardmodels import AbstractForwardModel
+
+
+class DistanceForwardModel(AbstractForwardModel):
+
+    def __init__(self, n_beads):
+        super(DistanceForwardModel, self).__init__('pair_distances')
+        self.n_beads = int(n_beads)
+        self._pairs = np.triu_indices(self.n_beads, 1)
+        self._dev = {}
+        self._register_variable('coordinates', differentiable=True)
+        self.update_var_param_types(coordinates=ArrayParameter)
+        self._set_original_variables()
+
+    @property
+    def n_pairs(self):
+        return len(self._pairs[0])
+
+    def pair_index(self, device):
+        if device not in self._dev:
+            I, J = self._pairs
+            self._dev[device] = (
+                torch.from_numpy(I.astype(np.int32)).to(device),
+                torch.from_numpy(J.astype(np.int32)).to(device))
+        return self._dev[device]
+
+    def _evaluate(self, coordinates):
+        if isinstance(coordinates, torch.Tensor) and coordinates.is_cuda:
+            x = coordinates if coordinates.dim() == 2 else coordinates.reshape(1, -1)
+            I, J = self.pair_index(x.device)
+            out = _native.pairdist_forward(x.contiguous(), I, J)
+            return out if coordinates.dim() == 2 else out.reshape(-1)
+        x = np.asarray(coordinates).reshape(-1, 3)
+        I, J = self._pairs
+        return np.sqrt(np.sum((x[I] - x[J]) ** 2, axis=1))
+
+    def _evaluate_jacobi_matrix(self, coordinates):
+        raise NotImplementedError(
+            'the [3n x n(n-1)/2] Jacobian is never formed; the Likelihood uses '
+            'the fused all-pairs gradient kernel')
+
+    def clone(self):
+        copy = self.__class__(self.n_beads)
+        copy._dev = self._dev
+        self._set_parameters(copy)
+        return copy
+
+    def native_spec(self):
+        return ('pairdist', self)
+
+
+class DistanceErrorModel(GaussianErrorModel):
+    """Gaussian error model on the pair distances; ``ys`` are the target
+    distances in pair order.  Keeps a symmetric ``[n x n]`` copy for the
+    all-pairs gradient kernel."""
+
+    def __init__(self, ys, n_beads):
+        super(DistanceErrorModel, self).__init__(ys)
+        self.n_beads = int(n_beads)
+        self._ymat = {}
+
+    def ymat_device(self, device):
+        if device not in self._ymat:
+            n = self.n_beads
+            y = self.ys.detach().cpu().numpy() if isinstance(self.ys, torch.Tensor) \
+                else np.asarray(self.ys, dtype=np.float64)
+            m = np.zeros((n, n))
+            I, J = np.triu_indices(n, 1)
+            m[I, J] = y
+            m[J, I] = y
+            self._ymat[device] = torch.from_numpy(m).to(device)
+        return self._ymat[device]
+
+    def clone(self):
+        copy = self.__class__(self.ys, self.n_beads)
+        copy._dev = self._dev
+        copy._ymat = self._ymat
+        copy.set_fixed_variables_from_pdf(self)
+        return copy
+
+    def native_spec(self):
+        return ('gaussian_pairdist', self)
+
+
+def make_distance_likelihood(target_distances, n_beads):
+    from binf_amd.pdf.likelihoods import Likelihood
+    return Likelihood('restraints', DistanceForwardModel(n_beads),
+                      DistanceErrorModel(target_distances, n_beads))
+
+
+def native_gradient(likelihood, fwm, em, fwm_vars, em_vars):
+    """Fused all-pairs force for the (DistanceForwardModel, DistanceErrorModel)
+    pair; None if the inputs are not device tensors."""
+    fwm_vars, em_vars = dict(fwm_vars), dict(em_vars)
+    fwm._complete_variables(fwm_vars)
+    em._complete_variables(em_vars)
+    x = fwm_vars.get('coordinates')
+    if not (isinstance(x, torch.Tensor) and x.is_cuda) or 'precision' not in em_vars:
+        return None
+    x2 = x if x.dim() == 2 else x.reshape(1, -1)
+    out = _native.pairdist_gauss_grad(x2.contiguous(), em.ymat_device(x.device),
+                                      em_vars['precision'])
+    return out if x.dim() == 2 else out.reshape(-1)

@@ -109,6 +109,14 @@ class Likelihood(AbstractBinfPDF):
             out = native_poly.gradient(self, pair, fwm_vars, em_vars)
             if out is not None:
                 return out
+        fs = getattr(self.forward_model, 'native_spec', lambda: None)()
+        es = getattr(self.error_model, 'native_spec', lambda: None)()
+        if fs is not None and es is not None and fs[0] == 'pairdist' and \
+                es[0] == 'gaussian_pairdist':
+            from binf_amd.example import distance
+            out = distance.native_gradient(self, fs[1], es[1], fwm_vars, em_vars)
+            if out is not None:
+                return out
         mock_data = self.forward_model(**fwm_vars)
         dfm = self.forward_model.jacobi_matrix(**fwm_vars)
         emgrad = self.error_model.gradient(mock_data=mock_data, **em_vars)

@@ -227,6 +227,29 @@ int32_t binf_gamma_precision_update_f64(const double *g, const double *lp_unit,
                                         void *stream);
 
 /* ------------------------------------------------------------------------
+ * Pairwise-distance-restraint model (BASELINE config C5; build-defined, the
+ * reference has no code for it -- it follows the reference's forward-model /
+ * error-model plug-in shape, binf/model/forwardmodels.py:10-66).
+ * Coordinates x[c, 3*bead + axis]; pairs (i<j) in numpy.triu_indices order.
+ * ---------------------------------------------------------------------- */
+
+/* out[c,p] = sqrt(((x_i - x_j)**2).sum()) for p = (pair_i[p], pair_j[p]);
+ * bit-identical to the numpy expression.  pair_i / pair_j device int32 [n_pairs]. */
+int32_t binf_pairdist_forward_f64(const double *x, const int32_t *pair_i,
+                                  const int32_t *pair_j, double *out, int64_t C,
+                                  int64_t n_beads, int64_t n_pairs, void *stream);
+
+/* Energy gradient of the Gaussian restraint likelihood,
+ *   out[c, 3i+a] = precision_c * sum_{j != i} (d_ij - ymat[j][i]) (x_i - x_j)[a] / d_ij,
+ * i.e. Likelihood._evaluate_gradient (binf/pdf/likelihoods.py:148-155) without
+ * forming the [3n x n(n-1)/2] Jacobian: all-pairs loop, coordinates in LDS.
+ * ymat: device, symmetric [n_beads x n_beads] target distances. */
+int32_t binf_pairdist_gauss_grad_f64(const double *x, const double *ymat,
+                                     double precision, const double *precision_chain,
+                                     double *out, int64_t C, int64_t n_beads,
+                                     void *stream);
+
+/* ------------------------------------------------------------------------
  * Host-side helpers exposing the reduction geometry the kernels use, so that
  * CPU tests can check it against numpy's pairwise summation (no GPU needed).
  * ---------------------------------------------------------------------- */

@@ -1,0 +1,113 @@
+"""GPU parity tests of the pairwise-distance-restraint posterior (BASELINE
+config C5).  The model is BUILD-DEFINED (the reference has no code for it):
+parity is against the numpy formulation in oracle/ref_distance.py only --
+"parity unpinned by the reference".  Distances and chi^2 are bit-exact; the
+all-pairs force is held to 1e-10 (different summation order than np.add.at)."""
+import numpy as np
+import pytest
+import torch
+
+from binf_amd import _native
+from binf_amd.example.distance import (DistanceErrorModel, DistanceForwardModel,
+                                       make_distance_likelihood)
+from binf_amd.pdf import IsotropicGaussian
+from binf_amd.pdf.posteriors import Posterior
+from binf_amd.samplers.hmc import HMCSampler
+from oracle import ref_distance as RD
+from oracle import ref_numpy as R
+
+pytestmark = pytest.mark.gpu
+
+
+def dev_t(a, device):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(device)
+
+
+def synth(n, C, seed):
+    rs = np.random.RandomState(seed)
+    truth = rs.standard_normal((n, 3)) * 2.0
+    ys = RD.forward(truth.reshape(-1), n) + 0.05 * rs.standard_normal(n * (n - 1) // 2)
+    ys = np.abs(ys)
+    x = truth.reshape(-1)[None, :] + 0.3 * rs.standard_normal((C, 3 * n))
+    return ys, x
+
+
+@pytest.mark.parametrize('n,C', [(2, 3), (3, 5), (10, 17), (64, 9), (256, 6), (300, 2)])
+def test_forward_distances_bitwise(device, n, C):
+    ys, x = synth(n, C, n)
+    fwm = DistanceForwardModel(n)
+    got = fwm(coordinates=dev_t(x, device)).cpu().numpy()
+    want = np.stack([RD.forward(x[c], n) for c in range(C)])
+    assert got.shape == (C, n * (n - 1) // 2)
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize('n,C', [(3, 5), (10, 17), (64, 9), (256, 6), (300, 2)])
+def test_likelihood_logp_and_force(device, n, C):
+    ys, x = synth(n, C, n + 1)
+    L = make_distance_likelihood(ys, n)
+    assert L.variables == {'coordinates', 'precision'}
+    tx = dev_t(x, device)
+    lp1 = L.log_prob(coordinates=tx, precision=1.0).cpu().numpy()
+    assert np.array_equal(lp1, np.array([RD.log_prob(x[c], ys, 1.0, n) for c in range(C)]))
+    taus = np.random.RandomState(0).uniform(0.5, 3.0, size=C)
+    lp = L.log_prob(coordinates=tx, precision=dev_t(taus, device)).cpu().numpy()
+    want = np.array([RD.log_prob(x[c], ys, taus[c], n) for c in range(C)])
+    assert np.allclose(lp, want, rtol=1e-13)
+    for prec, tarr in ((2.5, np.full(C, 2.5)), (dev_t(taus, device), taus)):
+        g = L.gradient(coordinates=tx, precision=prec).cpu().numpy()
+        for c in range(C):
+            w = RD.gradient(x[c], ys, tarr[c], n)
+            assert np.abs(g[c] - w).max() <= 1e-10 * max(np.abs(w).max(), 1.0), (n, c)
+    # translation invariance: the restraint force sums to zero over the beads
+    g = L.gradient(coordinates=tx, precision=2.5).cpu().numpy().reshape(C, n, 3)
+    assert np.abs(g.sum(axis=1)).max() <= 1e-9 * np.abs(g).max()
+
+
+def make_post(ys, n, k=0.05):
+    L = make_distance_likelihood(ys, n)
+    prior = IsotropicGaussian(k, 0.0, name='coordinates_prior', variable_name='coordinates')
+    return Posterior({L.name: L}, {prior.name: prior})
+
+
+@pytest.mark.parametrize('n,C,L,dt', [(8, 12, 10, 0.02), (256, 3, 4, 0.002)])
+def test_hmc_on_distance_posterior_vs_restatement(device, n, C, L, dt):
+    ys, x = synth(n, C, 3 * n)
+    rs = np.random.RandomState(n)
+    p0 = rs.standard_normal((C, 3 * n))
+    u = rs.uniform(size=C)
+    cond = make_post(ys, n).conditional_factory(precision=4.0)
+    assert cond.variables == {'coordinates'}
+    s = HMCSampler(cond, dev_t(x, device), dt, L, variable_name='coordinates')
+    out = s.sample(p0=dev_t(p0, device), u=dev_t(u, device)).cpu().numpy()
+    acc = s.last_move_accepted.cpu().numpy()
+    for c in range(C):
+        ref = R.RefHMCSampler(RD.DistancePosterior(ys, 4.0, n, prior_k=0.05), x[c].copy(),
+                              dt, L, variable_name='coordinates',
+                              normal=lambda size, c=c: p0[c].copy(), uniform=lambda c=c: u[c])
+        want = ref.sample()
+        assert bool(acc[c]) == bool(ref.last_move_accepted)
+        assert np.abs(out[c] - want).max() <= 1e-9 * np.abs(want).max()
+        assert abs(float(s.last_e_before[c]) - ref.last_E_before) <= 1e-10 * abs(ref.last_E_before)
+
+
+def test_c5_size_properties(device):
+    """BASELINE C5 per-GPU share: 3 x 256 coordinates, 256 chains (2048 / 8)."""
+    n, C = 256, 256
+    ys, x = synth(n, C, 99)
+    L = make_distance_likelihood(ys, n)
+    tx = dev_t(x, device)
+    g = L.gradient(coordinates=tx, precision=2.0)
+    torch.cuda.synchronize()
+    gn = g.cpu().numpy().reshape(C, n, 3)
+    assert np.abs(gn.sum(axis=1)).max() <= 1e-9 * np.abs(gn).max()
+    # rotation invariance of the log-prob (distances only)
+    th = 0.7
+    Rm = np.array([[np.cos(th), -np.sin(th), 0], [np.sin(th), np.cos(th), 0], [0, 0, 1.0]])
+    xr = (x.reshape(C, n, 3) @ Rm.T).reshape(C, -1)
+    a = L.log_prob(coordinates=tx, precision=2.0).cpu().numpy()
+    b = L.log_prob(coordinates=dev_t(xr, device), precision=2.0).cpu().numpy()
+    assert np.allclose(a, b, rtol=1e-11)
+    for c in (0, 255):
+        w = RD.gradient(x[c], ys, 2.0, n)
+        assert np.abs(g[c].cpu().numpy() - w).max() <= 1e-10 * np.abs(w).max()
