@@ -111,12 +111,21 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit('bench.py needs a GPU (binf_amd has no CPU path)')
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+    # BINF_BENCH_BACKEND=gloo: rehearsal of the multi-rank control flow on a box
+    # with fewer GPUs than ranks (ranks then share devices); real runs use
+    # nccl (= RCCL on ROCm), one rank per GPU.
+    backend = os.environ.get('BINF_BENCH_BACKEND', 'nccl')
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank if backend == 'nccl' else local_rank % max(1, ndev)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device('cuda', dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=dev)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from binf_amd.pdf import IsotropicGaussian
     from binf_amd.samplers.hmc import HMCSampler
@@ -178,16 +187,18 @@ def main():
     acc_rate = float(sampler.acceptance_rate.mean())
     gather_ms = None
     if dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64,
+                            device=dev if backend == 'nccl' else 'cpu')
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax[0])
         # the only collective of the path: gather one recorded draw (RCCL)
         from binf_amd.dist import gather_chains
-        gather_chains(sampler.state)
+        state = sampler.state if backend == 'nccl' else sampler.state.cpu()
+        gather_chains(state)
         barrier()
         t1 = time.perf_counter()
         for _ in range(5):
-            gather_chains(sampler.state)
+            gather_chains(state)
         barrier()
         gather_ms = (time.perf_counter() - t1) / 5 * 1e3
 
