@@ -206,8 +206,10 @@ def main():
         steps_total = float(world) * C * L * K
         value = steps_total / elapsed
         bytes_per_launch = (24.0 * D + 25.0) * C
-        # per transition (= per launch when --fuse 1)
-        launch_s = dev_ms * 1e-3 / K
+        n_launches = K // F
+        launch_s = dev_ms * 1e-3 / n_launches             # per kernel launch
+        trans_s = dev_ms * 1e-3 / K                       # per transition
+        bytes_per_launch = bytes_per_launch * F           # F transitions per launch
         achieved = bytes_per_launch / launch_s / 1e9
         # HBM traffic from the committed PMC summary of this exact configuration
         traffic, traffic_src = None, None
@@ -216,7 +218,7 @@ def main():
             c = pm['config']
             if (c['chains'], c['dims'], c['nsteps'], c['fuse'], c['thin'], c['mode']) == \
                     (C, D, L, F, args.thin if F > 1 else 1, args.mode):
-                traffic = pm['hbm_bytes_per_transition']
+                traffic = pm['hbm_bytes_per_transition'] * F
                 traffic_src = 'profiles/r01_c_pmc_traffic.json (rocprofv3 --pmc ' \
                               'FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2)'
         except (OSError, ValueError, KeyError):
@@ -247,14 +249,16 @@ def main():
                          'frac': achieved / HBM_PEAK_GBS,
                          'frac_of_measured_copy_ceiling': achieved / HBM_COPY_GBS,
                          'traffic': traffic, 'traffic_source': traffic_src,
-                         'per': 'transition (one HMCSampler.sample() worth of work)',
+                         'per': 'kernel launch = %d transition(s), each one '
+                                'HMCSampler.sample() worth of work' % F,
                          'kernel': 'hmc_gauss_wave_kernel' if F == 1
                          else 'hmc_gauss_persist_kernel',
                          'transitions_per_launch': F,
                          'states_recorded': 'every transition' if F == 1
                          else 'every %d. transition' % args.thin,
                          'algorithmic_bytes_per_launch': bytes_per_launch,
-                         'avg_launch_us': launch_s * 1e6},
+                         'avg_launch_us': launch_s * 1e6,
+                         'avg_transition_us': trans_s * 1e6},
         }
         if gather_ms is not None:
             res['sample_gather_ms'] = gather_ms

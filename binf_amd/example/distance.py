@@ -4,7 +4,7 @@ reference only names the chromatin application (``README.rst:9``) and holds no
 code for it, so this follows the shape of the reference's plug-in surface
 (``AbstractForwardModel`` / ``AbstractErrorModel``) and its Gaussian error
 model (``binf/example/likelihood.py:40-68``); parity is against the numpy
-formulation in ``oracle/ref_distance.py`` only.
+formulation kept with the test infrastructure only.
 
 ``coordinates`` is ``[C x 3n]`` (bead-major: x, y, z of bead 0, then bead 1 ...);
 the mock data are the n(n-1)/2 pair distances in ``numpy.triu_indices(n, 1)``

@@ -104,3 +104,27 @@ def test_fused_kernel_coverage_claim():
     # header: every D <= 920 and all multiples of 8 up to 1024 have height <= 3
     for D in list(range(1, 921)) + list(range(928, 1025, 8)):
         assert _native.pairwise_tree_height(D) <= 3, D
+
+
+def test_product_package_never_touches_the_oracle():
+    """oracle/ is test infrastructure: nothing under binf_amd/ may import,
+    load or execute it (a product path through the oracle would void every
+    parity claim)."""
+    import glob
+    pkg = os.path.join(ROOT, 'binf_amd')
+    files = glob.glob(os.path.join(pkg, '**', '*.py'), recursive=True) + \
+        glob.glob(os.path.join(pkg, 'csrc', '*'))
+    assert len(files) > 15
+    for f in files:
+        if f.endswith('.so'):
+            continue
+        text = open(f, errors='replace').read()
+        assert 'oracle' not in text, f
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    from binf_amd import _native as N
+    monkeypatch.setattr(N, '_lib', None)
+    monkeypatch.setattr(N, 'LIB_PATH', '/nonexistent/libbinf_hip.so')
+    with pytest.raises(N.NativeLibraryError):
+        N.lib()
