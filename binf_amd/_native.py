@@ -68,6 +68,15 @@ SIGNATURES = {
                                          _vp]),
     'binf_pairdist_gauss_grad_f64': (_i32, [_vp, _vp, _f64, _vp, _vp, _i64,
                                             _i64, _vp]),
+    'binf_rng_uniform_f64': (_i32, [_vp, _i64, ctypes.c_uint64, ctypes.c_uint64,
+                                    _vp]),
+    'binf_rng_normal_f64': (_i32, [_vp, _i64, ctypes.c_uint64, ctypes.c_uint64,
+                                   _vp]),
+    'binf_rng_gamma_f64': (_i32, [_vp, _i64, _f64, ctypes.c_uint64,
+                                  ctypes.c_uint64, _vp]),
+    'binf_rng_philox4x32_10': (_i32, [ctypes.POINTER(ctypes.c_uint32),
+                                      ctypes.POINTER(ctypes.c_uint32),
+                                      ctypes.POINTER(ctypes.c_uint32)]),
     'binf_pairwise_tree_height': (_i32, [_i64]),
     'binf_pairwise_leaf': (_i32, [_i64, _i32, _i32,
                                   ctypes.POINTER(_i64), ctypes.POINTER(_i64),
@@ -419,4 +428,31 @@ def pairdist_gauss_grad(x, ymat, precision):
         tau, dptr(tau_chain, numel=C, name='precision'), dptr(out), C, n,
         stream_handle(x.device))
     check(rc, 'binf_pairdist_gauss_grad_f64')
+    return out
+
+
+def philox4x32_10(counter, key):
+    c = (ctypes.c_uint32 * 4)(*[int(x) & 0xffffffff for x in counter])
+    k = (ctypes.c_uint32 * 2)(*[int(x) & 0xffffffff for x in key])
+    o = (ctypes.c_uint32 * 4)()
+    check(lib().binf_rng_philox4x32_10(c, k, o), 'binf_rng_philox4x32_10')
+    return [int(x) for x in o]
+
+
+def rng_fill(kind, out, seed, offset, shape=None):
+    """Fill the contiguous f64 device tensor `out` with uniform / normal /
+    gamma(shape) draws of the Philox stream (seed, offset)."""
+    n = out.numel()
+    p = dptr(out, numel=n, name='out')
+    st = stream_handle(out.device)
+    seed, offset = int(seed) & (2 ** 64 - 1), int(offset) & (2 ** 64 - 1)
+    if kind == 'uniform':
+        rc = lib().binf_rng_uniform_f64(p, n, seed, offset, st)
+    elif kind == 'normal':
+        rc = lib().binf_rng_normal_f64(p, n, seed, offset, st)
+    elif kind == 'gamma':
+        rc = lib().binf_rng_gamma_f64(p, n, float(shape), seed, offset, st)
+    else:
+        raise ValueError('unknown draw kind %r' % (kind,))
+    check(rc, 'binf_rng_%s_f64' % kind)
     return out

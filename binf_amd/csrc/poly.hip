@@ -138,12 +138,19 @@ struct GradArgs {
 
 constexpr int LDA = 17;      // padded row length of the staged A tile (doubles)
 
-// KS = ceil(K/4) forward k-steps, RT = ceil(K/16) backward row tiles.
-template <int KS, int RT>
+// KS forward k-steps (coefficients 0 .. 4*KS-1), RT backward row tiles
+// (coefficients 0 .. 16*RT-1) on the MFMA pipe; KV trailing coefficients
+// (indices KB .. KB+KV-1, KB = 4*KS = 16*RT when KV > 0) on the VALU, which
+// runs beside the MFMA pipe: for K = 33 that is 16 MFMAs + 8 FMAs per tile
+// instead of 21 MFMAs.
+template <int KS, int RT, int KV>
 __global__ void __launch_bounds__(256) poly_grad_mfma_kernel(const GradArgs a)
 {
-    constexpr int ROWS = (4 * KS > 16 * RT) ? 4 * KS : 16 * RT;
+    constexpr int KB = 4 * KS;                       // first VALU coefficient
+    constexpr int ROWS0 = (4 * KS > 16 * RT) ? 4 * KS : 16 * RT;
+    constexpr int ROWS = ROWS0 + KV;
     constexpr int PASSES = (ROWS + 15) / 16;
+    static_assert(KV == 0 || 4 * KS == 16 * RT, "VALU tail needs 4*KS == 16*RT");
     __shared__ double sA[2][ROWS][LDA];
     __shared__ double sY[2][16];
 
@@ -162,6 +169,12 @@ __global__ void __launch_bounds__(256) poly_grad_mfma_kernel(const GradArgs a)
     for (int s = 0; s < KS; ++s) {
         const int k = 4 * s + lk;
         th[s] = (cvalid && k < K) ? a.theta[chain * K + k] : 0.0;
+    }
+    double thv[KV > 0 ? KV : 1], gv[KV > 0 ? KV : 1];
+#pragma unroll
+    for (int v = 0; v < KV; ++v) {
+        thv[v] = (cvalid && KB + v < K) ? a.theta[chain * K + KB + v] : 0.0;
+        gv[v] = 0.0;
     }
     const double tau = cvalid ? (a.tau_chain ? a.tau_chain[chain] : a.tau) : 0.0;
 
@@ -209,6 +222,12 @@ __global__ void __launch_bounds__(256) poly_grad_mfma_kernel(const GradArgs a)
 #pragma unroll
         for (int s = 0; s < KS; ++s)
             acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sA[buf][4 * s + lk][lc], th[s], acc, 0, 0, 0);
+        // trailing coefficients on the VALU: lane holds (n = lk + 4r, c = lc)
+#pragma unroll
+        for (int v = 0; v < KV; ++v)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                acc[r] = __builtin_fma(thv[v], sA[buf][KB + v][lk + 4 * r], acc[r]);
         // error-model gradient in place: r[n][c] = (mock - y[n]) * tau_c
         double rr[4];
 #pragma unroll
@@ -223,8 +242,19 @@ __global__ void __launch_bounds__(256) poly_grad_mfma_kernel(const GradArgs a)
 #pragma unroll
             for (int s = 0; s < 4; ++s)
                 G[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(sA[buf][16 * rt + lc][4 * s + lk], rr[s], G[rt], 0, 0, 0);
+#pragma unroll
+        for (int v = 0; v < KV; ++v)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                gv[v] = __builtin_fma(sA[buf][KB + v][lk + 4 * r], rr[r], gv[v]);
         if (t + 1 < t1) stash(buf ^ 1);
         __syncthreads();
+    }
+    // the VALU rows: sum the four lk partials of each chain
+#pragma unroll
+    for (int v = 0; v < KV; ++v) {
+        gv[v] = gv[v] + shfl_xor_f64(gv[v], 16);
+        gv[v] = gv[v] + shfl_xor_f64(gv[v], 32);
     }
     if (cvalid) {
         double *dst = a.part + ((int64_t)blockIdx.y * a.C + chain) * K;
@@ -235,6 +265,11 @@ __global__ void __launch_bounds__(256) poly_grad_mfma_kernel(const GradArgs a)
                 const int i = 16 * rt + lk + 4 * r;
                 if (i < K) dst[i] = G[rt][r];
             }
+        if (lk == 0) {
+#pragma unroll
+            for (int v = 0; v < KV; ++v)
+                if (KB + v < K) dst[KB + v] = gv[v];
+        }
     }
 }
 
@@ -254,17 +289,23 @@ static int grad_splits(int64_t C, int64_t N)
     // aim at ~4 workgroups per CU; never more splits than data tiles
     const int64_t wgx = (C + 63) / 64;
     const int64_t ntiles = (N + 15) / 16;
-    int64_t ns = (1024 + wgx - 1) / wgx;
-    if (ns > 16) ns = 16;
+    static int target = -1;                  // BINF_POLY_GRAD_WGS: experiment knob
+    if (target < 0) {
+        const char *e = getenv("BINF_POLY_GRAD_WGS");
+        target = e ? atoi(e) : 1024;
+        if (target < 1) target = 1024;
+    }
+    int64_t ns = (target + wgx - 1) / wgx;
+    if (ns > 64) ns = 64;
     if (ns > ntiles) ns = ntiles;
     if (ns < 1) ns = 1;
     return (int)ns;
 }
 
-template <int KS, int RT>
+template <int KS, int RT, int KV>
 static hipError_t grad_launch(const GradArgs &a, dim3 grid, hipStream_t st)
 {
-    poly_grad_mfma_kernel<KS, RT><<<grid, 256, 0, st>>>(a);
+    poly_grad_mfma_kernel<KS, RT, KV><<<grid, 256, 0, st>>>(a);
     return hipGetLastError();
 }
 
@@ -408,13 +449,19 @@ extern "C" int32_t binf_poly_gauss_grad_f64(const double *coeffs, const double *
     dim3 grid((unsigned)((C + 63) / 64), (unsigned)ns);
     hipStream_t st = (hipStream_t)stream;
     hipError_t e;
-    if (K <= 4)       e = grad_launch<1, 1>(a, grid, st);
-    else if (K <= 8)  e = grad_launch<2, 1>(a, grid, st);
-    else if (K <= 16) e = grad_launch<4, 1>(a, grid, st);
-    else if (K <= 32) e = grad_launch<8, 2>(a, grid, st);
-    else if (K <= 36) e = grad_launch<9, 3>(a, grid, st);
-    else if (K <= 48) e = grad_launch<12, 3>(a, grid, st);
-    else              e = grad_launch<16, 4>(a, grid, st);
+    if (K <= 4)       e = grad_launch<1, 1, 0>(a, grid, st);
+    else if (K <= 8)  e = grad_launch<2, 1, 0>(a, grid, st);
+    else if (K <= 16) e = grad_launch<4, 1, 0>(a, grid, st);
+    else if (K == 17) e = grad_launch<4, 1, 1>(a, grid, st);
+    else if (K == 18) e = grad_launch<4, 1, 2>(a, grid, st);
+    else if (K <= 32) e = grad_launch<8, 2, 0>(a, grid, st);
+    else if (K == 33) e = grad_launch<8, 2, 1>(a, grid, st);
+    else if (K == 34) e = grad_launch<8, 2, 2>(a, grid, st);
+    else if (K <= 36) e = grad_launch<9, 3, 0>(a, grid, st);
+    else if (K <= 48) e = grad_launch<12, 3, 0>(a, grid, st);
+    else if (K == 49) e = grad_launch<12, 3, 1>(a, grid, st);
+    else if (K == 50) e = grad_launch<12, 3, 2>(a, grid, st);
+    else              e = grad_launch<16, 4, 0>(a, grid, st);
     if (e != hipSuccess) return hip_fail(e, "poly_gauss_grad launch");
     if (ns > 1) {
         const int64_t n = C * K;

@@ -1,0 +1,179 @@
+// Device random draws for throughput mode: the momentum draw
+// np.random.normal(size=q.shape) and the acceptance draw np.random.uniform()
+// of HMCSampler.sample (binf/samplers/hmc.py:146,151) and the
+// np.random.gamma(shape) of GammaSampler.sample (binf/example/samplers.py:47),
+// generated in HBM so that nothing crosses PCIe.  gfx950, wave64.
+//
+// Counter-based Philox4x32-10 (Salmon et al., "Parallel random numbers: as
+// easy as 1, 2, 3", SC'11): element i of a call uses counter (i, stream
+// offset) under key = seed, so results do not depend on the launch geometry
+// and consecutive calls never overlap.  NOT stream-compatible with numpy's
+// MT19937 -- parity runs take their draws from the host (samplers/rng.py).
+#include "common.hpp"
+
+namespace binf {
+
+struct Philox4 {
+    uint32_t v[4];
+};
+
+__host__ __device__ inline Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2,
+                                                 uint32_t c3, uint32_t k0, uint32_t k1)
+{
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+    const uint32_t W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)M0 * c0;
+        const uint64_t p1 = (uint64_t)M1 * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        const uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += W0; k1 += W1;
+    }
+    Philox4 o;
+    o.v[0] = c0; o.v[1] = c1; o.v[2] = c2; o.v[3] = c3;
+    return o;
+}
+
+// 53-bit uniform in [0, 1) from two 32-bit words (numpy's random_sample recipe)
+__host__ __device__ inline double u53(uint32_t a, uint32_t b)
+{
+    return ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) * (1.0 / 9007199254740992.0);
+}
+
+// two uniforms per Philox call: element pair index i -> counter (lo, hi, offset lo, offset hi)
+__device__ inline void uniforms2(int64_t i, uint64_t seed, uint64_t offset, double &a, double &b)
+{
+    const Philox4 r = philox4x32_10((uint32_t)i, (uint32_t)((uint64_t)i >> 32),
+                                    (uint32_t)offset, (uint32_t)(offset >> 32),
+                                    (uint32_t)seed, (uint32_t)(seed >> 32));
+    a = u53(r.v[0], r.v[1]);
+    b = u53(r.v[2], r.v[3]);
+}
+
+__global__ void __launch_bounds__(256)
+rng_uniform_kernel(double *out, int64_t n, uint64_t seed, uint64_t offset)
+{
+    const int64_t np = (n + 1) / 2;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < np;
+         i += (int64_t)gridDim.x * 256) {
+        double a, b;
+        uniforms2(i, seed, offset, a, b);
+        out[2 * i] = a;
+        if (2 * i + 1 < n) out[2 * i + 1] = b;
+    }
+}
+
+// Box-Muller: two normals from two uniforms
+__device__ inline void normals2(int64_t i, uint64_t seed, uint64_t offset, double &a, double &b)
+{
+    double u1, u2;
+    uniforms2(i, seed, offset, u1, u2);
+    const double r = sqrt(-2.0 * log(1.0 - u1));       // 1-u1 in (0, 1]
+    double s, c;
+    sincospi(2.0 * u2, &s, &c);
+    a = r * c;
+    b = r * s;
+}
+
+__global__ void __launch_bounds__(256)
+rng_normal_kernel(double *out, int64_t n, uint64_t seed, uint64_t offset)
+{
+    const int64_t np = (n + 1) / 2;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < np;
+         i += (int64_t)gridDim.x * 256) {
+        double a, b;
+        normals2(i, seed, offset, a, b);
+        out[2 * i] = a;
+        if (2 * i + 1 < n) out[2 * i + 1] = b;
+    }
+}
+
+// Gamma(shape, 1), Marsaglia & Tsang (2000); shape < 1 via Gamma(shape+1)*U^(1/shape).
+// Attempt k of element i uses counter i under offset + k (bounded retries).
+__global__ void __launch_bounds__(256)
+rng_gamma_kernel(double *out, int64_t n, double shape, uint64_t seed, uint64_t offset)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * 256) {
+        const double alpha = shape < 1.0 ? shape + 1.0 : shape;
+        const double d = alpha - 1.0 / 3.0;
+        const double c = 1.0 / sqrt(9.0 * d);
+        double g = d;                                   // fallback after 64 rejections
+        for (int k = 0; k < 64; ++k) {
+            double x, unused, u1, u2;
+            normals2(i, seed, offset + 2 * (uint64_t)k, x, unused);
+            uniforms2(i, seed, offset + 2 * (uint64_t)k + 1, u1, u2);
+            const double t = 1.0 + c * x;
+            if (t <= 0.0) continue;
+            const double v = t * t * t;
+            const double uu = 1.0 - u1;                 // (0, 1]
+            if (log(uu) < 0.5 * x * x + d - d * v + d * log(v)) {
+                g = d * v;
+                if (shape < 1.0) g *= pow(1.0 - u2, 1.0 / shape);
+                break;
+            }
+        }
+        out[i] = g;
+    }
+}
+
+static unsigned rng_grid(int64_t work)
+{
+    int64_t b = (work + 255) / 256;
+    if (b > 4096) b = 4096;
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+
+}  // namespace binf
+
+using namespace binf;
+
+extern "C" int32_t binf_rng_philox4x32_10(const uint32_t counter[4], const uint32_t key[2],
+                                          uint32_t out[4])
+{
+    if (!counter || !key || !out) return fail(BINF_E_ARG, "rng_philox: null pointer");
+    const Philox4 r = philox4x32_10(counter[0], counter[1], counter[2], counter[3], key[0], key[1]);
+    for (int i = 0; i < 4; ++i) out[i] = r.v[i];
+    return 0;
+}
+
+extern "C" int32_t binf_rng_uniform_f64(double *out, int64_t n, uint64_t seed,
+                                        uint64_t offset, void *stream)
+{
+    if (n < 0) return fail(BINF_E_ARG, "rng_uniform: negative size");
+    if (n == 0) return 0;
+    if (!out) return fail(BINF_E_ARG, "rng_uniform: null buffer");
+    rng_uniform_kernel<<<dim3(rng_grid((n + 1) / 2)), 256, 0, (hipStream_t)stream>>>(out, n, seed, offset);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "rng_uniform launch");
+    return 0;
+}
+
+extern "C" int32_t binf_rng_normal_f64(double *out, int64_t n, uint64_t seed,
+                                       uint64_t offset, void *stream)
+{
+    if (n < 0) return fail(BINF_E_ARG, "rng_normal: negative size");
+    if (n == 0) return 0;
+    if (!out) return fail(BINF_E_ARG, "rng_normal: null buffer");
+    rng_normal_kernel<<<dim3(rng_grid((n + 1) / 2)), 256, 0, (hipStream_t)stream>>>(out, n, seed, offset);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "rng_normal launch");
+    return 0;
+}
+
+extern "C" int32_t binf_rng_gamma_f64(double *out, int64_t n, double shape, uint64_t seed,
+                                      uint64_t offset, void *stream)
+{
+    if (n < 0 || !(shape > 0.0)) return fail(BINF_E_ARG, "rng_gamma: need n >= 0 and shape > 0");
+    if (n == 0) return 0;
+    if (!out) return fail(BINF_E_ARG, "rng_gamma: null buffer");
+    rng_gamma_kernel<<<dim3(rng_grid(n)), 256, 0, (hipStream_t)stream>>>(out, n, shape, seed, offset);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "rng_gamma launch");
+    return 0;
+}

@@ -24,17 +24,29 @@ class HostLegacyRNG(object):
 
 
 class DeviceRNG(object):
-    """Throughput source: draws generated in HBM by the device generator, so
-    nothing crosses PCIe.  Not stream-compatible with numpy."""
+    """Throughput source: draws generated in HBM by the library's Philox
+    kernels (``csrc/rng.hip``), so nothing crosses PCIe.  Deterministic in
+    (seed, call order), independent of launch geometry; NOT stream-compatible
+    with numpy."""
 
     def __init__(self, seed=0, device='cuda'):
-        self._gen = torch.Generator(device=device)
-        self._gen.manual_seed(int(seed))
+        self.seed = int(seed)
+        self.offset = 0
+        self.device = torch.device(device)
+
+    def _fill(self, kind, dims, device, advance, **kw):
+        from binf_amd import _native
+        out = torch.empty(tuple(dims), dtype=torch.float64, device=device)
+        _native.rng_fill(kind, out, self.seed, self.offset, **kw)
+        self.offset += advance
+        return out
 
     def normal(self, shape, device):
-        return torch.randn(tuple(shape), dtype=torch.float64, device=device,
-                           generator=self._gen)
+        return self._fill('normal', shape, device, 1)
 
     def uniform(self, n, device):
-        return torch.rand(int(n), dtype=torch.float64, device=device,
-                          generator=self._gen)
+        return self._fill('uniform', (int(n),), device, 1)
+
+    def gamma(self, shape, n, device):
+        """Gamma(shape, 1) variates, one per chain (GammaSampler's ``gamma=``)."""
+        return self._fill('gamma', (int(n),), device, 128, shape=shape)

@@ -250,6 +250,24 @@ int32_t binf_pairdist_gauss_grad_f64(const double *x, const double *ymat,
                                      void *stream);
 
 /* ------------------------------------------------------------------------
+ * Device random draws (throughput mode): counter-based Philox4x32-10, key =
+ * seed, element i of a call uses counter (i, offset).  Replace the
+ * np.random.normal / uniform / gamma draws of binf/samplers/hmc.py:146,151 and
+ * binf/example/samplers.py:47 when bit-parity with numpy's stream is not
+ * required.  A caller advances `offset` by 1 per uniform / normal call and by
+ * 128 per gamma call so that calls never reuse a counter.
+ * ---------------------------------------------------------------------- */
+int32_t binf_rng_uniform_f64(double *out, int64_t n, uint64_t seed, uint64_t offset,
+                             void *stream);                 /* [0, 1), 53 bits  */
+int32_t binf_rng_normal_f64(double *out, int64_t n, uint64_t seed, uint64_t offset,
+                            void *stream);                  /* Box-Muller        */
+int32_t binf_rng_gamma_f64(double *out, int64_t n, double shape, uint64_t seed,
+                           uint64_t offset, void *stream);  /* Marsaglia-Tsang   */
+/* Host-side evaluation of the generator's block function (known-answer tests). */
+int32_t binf_rng_philox4x32_10(const uint32_t counter[4], const uint32_t key[2],
+                               uint32_t out[4]);
+
+/* ------------------------------------------------------------------------
  * Host-side helpers exposing the reduction geometry the kernels use, so that
  * CPU tests can check it against numpy's pairwise summation (no GPU needed).
  * ---------------------------------------------------------------------- */

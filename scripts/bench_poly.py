@@ -67,13 +67,8 @@ res['C3_hmc_sample_ms'] = t_hmc * 1e3
 res['C3_chain_leapfrog_steps_per_s'] = C * L / t_hmc
 res['C3_acceptance'] = float(s.acceptance_rate.mean())
 
-gen = torch.Generator(device=dev)
-gen.manual_seed(5)
-shape = 0.5 * N + 1.0 - 1
-
-
-def gamma(sh, n, d):
-    return torch._standard_gamma(torch.full((n,), float(sh), dtype=torch.float64, device=d), generator=gen)
+grng = DeviceRNG(5, dev)
+gamma = grng.gamma
 
 
 start = BinfState(dict(coefficients=q0, precision=torch.full((C,), 2.5, dtype=torch.float64, device=dev)))

@@ -128,3 +128,16 @@ def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(N, 'LIB_PATH', '/nonexistent/libbinf_hip.so')
     with pytest.raises(N.NativeLibraryError):
         N.lib()
+
+
+def test_philox4x32_10_known_answers():
+    """Random123's published known-answer vectors for philox4x32-10."""
+    kat = [([0, 0, 0, 0], [0, 0],
+            [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]),
+           ([0xffffffff] * 4, [0xffffffff] * 2,
+            [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]),
+           ([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344],
+            [0xa4093822, 0x299f31d0],
+            [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1])]
+    for ctr, key, want in kat:
+        assert _native.philox4x32_10(ctr, key) == want
