@@ -1,41 +1,46 @@
-// Fused HMC transition on an isotropic Gaussian, one launch = one
-// HMCSampler.sample() for every chain.  gfx950 (MI355X), wave64.
-//
-// Replaces (reference paths): binf/samplers/hmc.py:92-164,183-191 and the
-// TestHO log_prob/gradient of binf/pdf/__init__.py:181-191.
+// Fused HMC on an isotropic Gaussian (the reference's TestHO,
+// binf/pdf/__init__.py:181-191): ONE launch = n consecutive HMCSampler.sample()
+// transitions of every chain (n = 1: binf_hmc_sample_gauss_f64; n > 1: the
+// `for i in range(n): sampler.sample()` loop of example_script.py:33-34).
+// Replaces binf/samplers/hmc.py:92-164,183-191.  gfx950 (MI355X), wave64.
 //
 // Mapping.  A chain's D coordinates are owned by G = 8 * 2^H lanes of ONE wave
 // (H = height of numpy's pairwise-sum tree for length D), so 64/G chains share
 // a wave.  Lane (leaf path g, accumulator j) owns elements off_g + 8t + j,
 // t = 0..TMAX-1 -- exactly the elements numpy's j-th strided accumulator of
-// that leaf adds up, in order.  The whole trajectory (q, p) stays in VGPRs;
-// HBM sees q0, p0 once in and q_out once out (8-byte accesses in 64-byte
-// segments: measured at the same 6.3 TB/s as 16-byte coalesced streaming).
+// that leaf adds up, in order -- so the energy reductions are an in-lane
+// running sum, xor-shuffles 1,2,4 inside the leaf (numpy's
+// ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7))), the leaf's tail elements, then
+// xor-shuffles 8,16,32 up the leaf tree: bit-identical to np.sum, no LDS.
+// HBM accesses are 8 bytes per lane in 64-byte segments (measured at the same
+// 6.3 TB/s as 16-byte coalesced streaming).
 //
-// Schedule.  The Gaussian is separable, so the nsteps-long trajectory of a
-// group of GS elements per lane is run to completion as soon as that group's
-// loads have landed, while the later loads of the wave are still in flight
-// ("element-group-major" order); the in-lane partial sums of the four energy
-// reductions are carried along in t order.  A wave owns NCH chain slots whose
-// loads are all issued up front, so the stores of slot 0 overlap the compute
-// of slot 1.  Energy reductions finish with xor-shuffles 1,2,4 inside the
-// leaf (numpy's ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7))), the leaf's tail
-// elements, then xor-shuffles 8,16,32 up the leaf tree: bit-identical to
-// np.sum.
+// Where the state lives between transitions:
+//   * q stays in VGPRs across transitions (no q0 re-read, no q_out write unless
+//     the draw is recorded);
+//   * the state before the transition is stashed in LDS (8 KiB per wave) and
+//     read back only on rejection;
+//   * V(q) of the current state is carried over instead of being re-reduced
+//     (re-reducing the same bits gives the same bits);
+//   * the Gaussian is separable, so each group of 4 elements per lane runs its
+//     whole trajectory on its own; the momentum streams in one group at a
+//     time, the next group's draw (or the next transition's first group)
+//     being fetched while the current group integrates.
 #include "gauss_common.hpp"
 
 namespace binf {
 
-struct GaussArgs {
+struct GaussNArgs {
     const double *q0;
-    const double *p0;
-    const double *u;
-    double *q_out;
-    uint8_t *accepted;
-    int64_t *n_accepted;
-    double *e_before;
-    double *e_after;
-    double *dt_chain;
+    const double *p0;        // [n x C x D]
+    const double *u;         // [n x C]
+    double *q_out;           // [C x D]
+    double *samples;         // [n/thin x C x D] or null
+    uint8_t *accepted;       // [n x C] or null
+    int64_t *n_accepted;     // [C] or null
+    double *e_before;        // [n x C] or null
+    double *e_after;         // [n x C] or null
+    double *dt_chain;        // [C] or null
     double timestep;
     double k;
     double x0;
@@ -44,20 +49,26 @@ struct GaussArgs {
     int64_t C;
     int32_t D;
     int32_t nsteps;
-    int32_t H;      // tree height, G = 8 << H lanes per chain
-    int32_t adapt;
+    int32_t H;
+    int32_t n;               // transitions per launch
+    int32_t thin;            // record every thin-th state (>= 1)
+    int32_t n_adapt;         // the first n_adapt transitions adapt the timestep
+    int32_t stagger;         // start delay per hardware wave slot, in s_sleep(127) units
 };
 
-template <int TMAX, bool REGULAR, bool UNIT, bool FMA, int NCH>
+template <int TMAX, bool REGULAR, bool UNIT, bool FMA>
 __global__ void __launch_bounds__(256)
-hmc_gauss_wave_kernel(const GaussArgs a)
+hmc_gauss_persist_kernel(const GaussNArgs a)
 {
-    constexpr int GS = (TMAX % 4 == 0) ? 4 : TMAX;   // elements per group
+    constexpr int GS = (TMAX % 4 == 0) ? 4 : TMAX;
     constexpr int NG = TMAX / GS;
+    __shared__ double stash[4][TMAX][64];
+
     const int lane = threadIdx.x & 63;
-    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int wib = threadIdx.x >> 6;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + wib;
     const int H = a.H;
-    const int lg = 3 + H;                  // log2(lanes per chain)
+    const int lg = 3 + H;
     const int slot = lane & ((1 << lg) - 1);
     const int j = slot & 7;
 
@@ -77,205 +88,235 @@ hmc_gauss_wave_kernel(const GaussArgs a)
     const int T = (n >= 8) ? (n >> 3) : 0;
     const int rem = (n >= 8) ? (n & 7) : n;
 
-    // ---- issue every load of every chain slot up front ---------------------
-    int64_t chain[NCH];
-    bool cvalid[NCH];
-    double dtv[NCH], uv[NCH];
-    double q[NCH][TMAX], p[NCH][TMAX];
-    // per-chain scalars first: loads return in order, so a scalar issued
-    // behind the bulk loads would make its first use wait for all of them
-#pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-        const int64_t raw = ((wave * NCH + c) << (6 - lg)) + (lane >> lg);
-        cvalid[c] = raw < a.C;
-        chain[c] = cvalid[c] ? raw : a.C - 1;
-        dtv[c] = a.dt_chain ? a.dt_chain[chain[c]] : a.timestep;
-        uv[c] = a.u[chain[c]];
-    }
+    const int64_t raw = (wave << (6 - lg)) + (lane >> lg);
+    const bool cvalid = raw < a.C;
+    const int64_t chain = cvalid ? raw : a.C - 1;
+    const int64_t CD = a.C * (int64_t)a.D;
+    const int64_t base = chain * (int64_t)a.D + off + j;
+
+    double dt = a.dt_chain ? a.dt_chain[chain] : a.timestep;
+    double uu = a.u[chain];
     __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-        const int64_t base = chain[c] * (int64_t)a.D + off + j;
-        const double *gq = a.q0 + base;
-        const double *gp = a.p0 + base;
-#pragma unroll
-        for (int t = 0; t < TMAX; ++t) {
-            const bool m = REGULAR || (8 * t + j < n);
-            q[c][t] = m ? gq[8 * t] : 0.0;
-            p[c][t] = m ? gp[8 * t] : 0.0;
-        }
+
+    // One-time start stagger: the waves sharing a SIMD run the same program
+    // from the same start and would reach the serial reduce -> exp tail of
+    // every transition together, leaving the FP64 pipe idle.  Offsetting them
+    // by their hardware wave slot once makes one wave's tail overlap the
+    // others' trajectories for the rest of the launch.
+    if (a.stagger > 0) {
+        // HW_REG_HW_ID (id 4), WAVE_ID = bits [3:0]
+        const unsigned slot_id = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 4) & 3u;
+        for (unsigned i = 0; i < slot_id * (unsigned)a.stagger; ++i)
+            __builtin_amdgcn_s_sleep(127);
     }
 
-    const double c_lp = -0.5 * a.k;           // "-0.5 * k", pdf/__init__.py:185
-
+    // q lives in registers for the whole launch; the momentum is needed one
+    // element group at a time, so it streams through a 2-deep register ring
+    // (pa / pb): while group g runs its trajectory, group g+1's draw (or group
+    // 0 of the next transition) is in flight.
+    double q[TMAX], pa[GS], pb[GS];
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-        const double dt = dtv[c];
-        const double hdt = 0.5 * dt;          // "0.5 * timestep" formed first
-        const double uu = uv[c];
+    for (int t = 0; t < TMAX; ++t) {
+        const bool m = REGULAR || (8 * t + j < n);
+        q[t] = m ? a.q0[base + 8 * t] : 0.0;
+    }
+#pragma unroll
+    for (int i = 0; i < GS; ++i) {
+        const bool m = REGULAR || (8 * i + j < n);
+        pa[i] = m ? a.p0[base + 8 * i] : 0.0;
+    }
 
-        LaneSum sqb = {0.0, 0.0}, spb = {0.0, 0.0};   // E_before parts
-        LaneSum sqa = {0.0, 0.0}, spa = {0.0, 0.0};   // E_after parts
+    const double c_lp = -0.5 * a.k;
+    // np.sum((q - x0)**2) of the CURRENT state, carried across transitions
+    LaneSum s0 = {0.0, 0.0};
+#pragma unroll
+    for (int t = 0; t < TMAX; ++t) {
+        const double d = UNIT ? q[t] : q[t] - a.x0;
+        lane_sum_add<REGULAR>(s0, d * d, t, T);
+    }
+    double Sq_state = chain_sum_finish<REGULAR>(s0, T, rem, lane, H, leafdepth);
+    int64_t nacc = 0;
+
+    for (int s = 0; s < a.n; ++s) {
+        const double hdt = 0.5 * dt;
+        // state before the transition -> LDS (read back only on rejection)
+#pragma unroll
+        for (int t = 0; t < TMAX; ++t) stash[wib][t][lane] = q[t];
+
+        // Prefetches are issued UNCONDITIONALLY (on the last transition they
+        // re-read this transition's data and are ignored): a load under a
+        // branch makes the compiler's vmcnt bookkeeping assume it may not have
+        // been issued, and the next counted wait then also waits for it.
+        const bool more = s + 1 < a.n;
+        const double *pc = a.p0 + (int64_t)s * CD + base;
+        const double *pn = more ? pc + CD : pc;
+        const double un = a.u[(int64_t)(more ? s + 1 : s) * a.C + chain];
+
+        LaneSum spb = {0.0, 0.0}, sqa = {0.0, 0.0}, spa = {0.0, 0.0};
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
-            // pin this group's values here (see hmc_gauss_persist.hip)
+            double(&cur)[GS] = (g & 1) ? pb : pa;
+            double(&nxt)[GS] = (g & 1) ? pa : pb;
+            // fetch the next group's draw (next transition's group 0 at the end)
+            if (g + 1 < NG) {
 #pragma unroll
-            for (int i = 0; i < GS; ++i) {
-                const int t = g * GS + i;
-                asm volatile("" : "+v"(p[c][t]), "+v"(q[c][t]));
-            }
-            // E_before terms: (q-x0)**2, p**2                   hmc.py:148
+                for (int i = 0; i < GS; ++i) {
+                    const int t = (g + 1) * GS + i;
+                    const bool m = REGULAR || (8 * t + j < n);
+                    nxt[i] = m ? pc[8 * t] : 0.0;
+                }
+            } else {
 #pragma unroll
-            for (int i = 0; i < GS; ++i) {
-                const int t = g * GS + i;
-                const double d = UNIT ? q[c][t] : q[c][t] - a.x0;
-                lane_sum_add<REGULAR>(sqb, d * d, t, T);
-                lane_sum_add<REGULAR>(spb, p[c][t] * p[c][t], t, T);
+                for (int i = 0; i < GS; ++i) {
+                    const bool m = REGULAR || (8 * i + j < n);
+                    nxt[i] = m ? pn[8 * i] : 0.0;
+                }
             }
-            __builtin_amdgcn_sched_barrier(0);   // keep q0**2 out of the loop's way
-            // _leapfrog                                         hmc.py:116-123
+            // pin this group's values to this point: without it the compiler
+            // forms the p*p / q*q products of every group early and keeps
+            // them alive until the group's turn
 #pragma unroll
-            for (int i = 0; i < GS; ++i) {
+            for (int i = 0; i < GS; ++i)
+                asm volatile("" : "+v"(cur[i]), "+v"(q[g * GS + i]));
+#pragma unroll
+            for (int i = 0; i < GS; ++i)                      // hmc.py:148
+                lane_sum_add<REGULAR>(spb, cur[i] * cur[i], g * GS + i, T);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < GS; ++i) {                    // hmc.py:116
                 const int t = g * GS + i;
-                p[c][t] = kick<FMA>(p[c][t], hdt, gauss_grad<UNIT>(q[c][t], a.k, a.x0));
+                cur[i] = kick<FMA>(cur[i], hdt, gauss_grad<UNIT>(q[t], a.k, a.x0));
             }
-            for (int s = 0; s < a.nsteps - 1; ++s) {
+            for (int l = 0; l < a.nsteps - 1; ++l) {          // hmc.py:118-120
 #pragma unroll
                 for (int i = 0; i < GS; ++i) {
                     const int t = g * GS + i;
-                    q[c][t] = drift<FMA>(q[c][t], p[c][t], dt);
-                    p[c][t] = kick<FMA>(p[c][t], dt, gauss_grad<UNIT>(q[c][t], a.k, a.x0));
+                    q[t] = drift<FMA>(q[t], cur[i], dt);
+                    cur[i] = kick<FMA>(cur[i], dt, gauss_grad<UNIT>(q[t], a.k, a.x0));
                 }
             }
 #pragma unroll
-            for (int i = 0; i < GS; ++i) {
+            for (int i = 0; i < GS; ++i) {                    // hmc.py:122-123
                 const int t = g * GS + i;
-                q[c][t] = drift<FMA>(q[c][t], p[c][t], dt);
-                p[c][t] = kick<FMA>(p[c][t], hdt, gauss_grad<UNIT>(q[c][t], a.k, a.x0));
+                q[t] = drift<FMA>(q[t], cur[i], dt);
+                cur[i] = kick<FMA>(cur[i], hdt, gauss_grad<UNIT>(q[t], a.k, a.x0));
             }
-            // E_after terms                                     hmc.py:150
 #pragma unroll
-            for (int i = 0; i < GS; ++i) {
+            for (int i = 0; i < GS; ++i) {                    // hmc.py:150
                 const int t = g * GS + i;
-                const double d = UNIT ? q[c][t] : q[c][t] - a.x0;
+                const double d = UNIT ? q[t] : q[t] - a.x0;
                 lane_sum_add<REGULAR>(sqa, d * d, t, T);
-                lane_sum_add<REGULAR>(spa, p[c][t] * p[c][t], t, T);
+                lane_sum_add<REGULAR>(spa, cur[i] * cur[i], t, T);
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
-        const double Sqb = chain_sum_finish<REGULAR>(sqb, T, rem, lane, H, leafdepth);
+        if (NG & 1) {
+            // odd group count: the next transition's group 0 landed in pb
+#pragma unroll
+            for (int i = 0; i < GS; ++i) pa[i] = pb[i];
+        }
         const double Spb = chain_sum_finish<REGULAR>(spb, T, rem, lane, H, leafdepth);
         const double Sqa = chain_sum_finish<REGULAR>(sqa, T, rem, lane, H, leafdepth);
         const double Spa = chain_sum_finish<REGULAR>(spa, T, rem, lane, H, leafdepth);
-        const double Eb = -(c_lp * Sqb) + 0.5 * Spb;
+        const double Eb = -(c_lp * Sq_state) + 0.5 * Spb;
         const double Ea = -(c_lp * Sqa) + 0.5 * Spa;
 
-        // acc = uniform < exp(-(E_after - E_before)), csb clipped exp  hmc.py:151
-        double x = -(Ea - Eb);
+        double x = -(Ea - Eb);                                // hmc.py:151
         x = (x < -308.0) ? -308.0 : x;
-        x = (x > 709.0) ? 709.0 : x;      // NaN falls through both, as np.clip
+        x = (x > 709.0) ? 709.0 : x;
         const bool acc = uu < exp(x);
 
-        if (cvalid[c] && slot == 0) {
-            a.accepted[chain[c]] = acc ? 1 : 0;
-            if (a.n_accepted && acc) a.n_accepted[chain[c]] += 1;   // hmc.py:161
-            if (a.e_before) a.e_before[chain[c]] = Eb;
-            if (a.e_after) a.e_after[chain[c]] = Ea;
-            if (a.adapt)                                     // hmc.py:188-191
-                a.dt_chain[chain[c]] = acc ? dt * a.uprate : dt * a.downrate;
+        const double dt_used = dt;
+        if (s < a.n_adapt)                                    // hmc.py:188-191
+            dt = acc ? dt * a.uprate : dt * a.downrate;
+        if (cvalid && slot == 0) {
+            const int64_t o = (int64_t)s * a.C + chain;
+            if (a.accepted) a.accepted[o] = acc ? 1 : 0;
+            if (a.e_before) a.e_before[o] = Eb;
+            if (a.e_after) a.e_after[o] = Ea;
         }
+        (void)dt_used;
+        if (acc) {
+            Sq_state = Sqa;
+            nacc += 1;
+        } else {
+#pragma unroll
+            for (int t = 0; t < TMAX; ++t) q[t] = stash[wib][t][lane];
+        }
+        if (a.samples && (s + 1) % a.thin == 0 && cvalid && canonical) {
+            double *go = a.samples + (int64_t)((s + 1) / a.thin - 1) * CD + base;
+#pragma unroll
+            for (int t = 0; t < TMAX; ++t)
+                if (REGULAR || (8 * t + j < n)) go[8 * t] = q[t];
+        }
+        uu = un;
+    }
 
-        // return value: the proposal if accepted, else the old state  hmc.py:159-164
-        const int64_t base = chain[c] * (int64_t)a.D + off + j;
+    if (cvalid && slot == 0) {
+        if (a.n_accepted) a.n_accepted[chain] += nacc;
+        if (a.n_adapt > 0 && a.dt_chain) a.dt_chain[chain] = dt;
+    }
+    if (cvalid && canonical) {
         double *go = a.q_out + base;
-        const double *gq = a.q0 + base;
-        if (cvalid[c] && canonical) {
-            if (acc) {
 #pragma unroll
-                for (int t = 0; t < TMAX; ++t)
-                    if (REGULAR || (8 * t + j < n)) go[8 * t] = q[c][t];
-            } else if (a.q_out != a.q0) {
-#pragma unroll
-                for (int t = 0; t < TMAX; ++t)
-                    if (REGULAR || (8 * t + j < n)) go[8 * t] = gq[8 * t];
-            }
-        }
+        for (int t = 0; t < TMAX; ++t)
+            if (REGULAR || (8 * t + j < n)) go[8 * t] = q[t];
     }
 }
 
-template <int TMAX, bool REGULAR, int NCH>
-static hipError_t launch_trn(const GaussArgs &a, bool unit, bool fma,
-                             dim3 grid, hipStream_t st)
+template <int TMAX, bool REGULAR>
+static hipError_t launch_n_tr(const GaussNArgs &a, bool unit, bool fma, dim3 grid,
+                              hipStream_t st)
 {
     if (unit) {
-        if (fma) hmc_gauss_wave_kernel<TMAX, REGULAR, true, true, NCH><<<grid, 256, 0, st>>>(a);
-        else     hmc_gauss_wave_kernel<TMAX, REGULAR, true, false, NCH><<<grid, 256, 0, st>>>(a);
+        if (fma) hmc_gauss_persist_kernel<TMAX, REGULAR, true, true><<<grid, 256, 0, st>>>(a);
+        else     hmc_gauss_persist_kernel<TMAX, REGULAR, true, false><<<grid, 256, 0, st>>>(a);
     } else {
-        if (fma) hmc_gauss_wave_kernel<TMAX, REGULAR, false, true, NCH><<<grid, 256, 0, st>>>(a);
-        else     hmc_gauss_wave_kernel<TMAX, REGULAR, false, false, NCH><<<grid, 256, 0, st>>>(a);
+        if (fma) hmc_gauss_persist_kernel<TMAX, REGULAR, false, true><<<grid, 256, 0, st>>>(a);
+        else     hmc_gauss_persist_kernel<TMAX, REGULAR, false, false><<<grid, 256, 0, st>>>(a);
     }
     return hipGetLastError();
 }
 
 template <int TMAX>
-static hipError_t launch_t(const GaussArgs &a, bool regular, int nch, bool unit,
-                           bool fma, dim3 grid, hipStream_t st)
+static hipError_t launch_n_t(const GaussNArgs &a, bool regular, bool unit, bool fma,
+                             dim3 grid, hipStream_t st)
 {
-    if (nch == 2)
-        return regular ? launch_trn<TMAX, true, 2>(a, unit, fma, grid, st)
-                       : launch_trn<TMAX, false, 2>(a, unit, fma, grid, st);
-    return regular ? launch_trn<TMAX, true, 1>(a, unit, fma, grid, st)
-                   : launch_trn<TMAX, false, 1>(a, unit, fma, grid, st);
+    return regular ? launch_n_tr<TMAX, true>(a, unit, fma, grid, st)
+                   : launch_n_tr<TMAX, false>(a, unit, fma, grid, st);
 }
 
 }  // namespace binf
 
 using namespace binf;
 
-// Number of chain slots per wave.  Measured on MI355X at C2 (4096 chains,
-// D = 1024, L = 20, random data): NCH = 1 25.0 us, NCH = 2 29.1 us per launch
-// (profiles/r01_b_notes.md), so 1 is the default; BINF_GAUSS_NCH=2 selects
-// the two-slot variant for experiments.
-static int pick_nch(int64_t waves1, int tneed)
-{
-    static int forced = -1;
-    if (forced < 0) {
-        const char *e = getenv("BINF_GAUSS_NCH");
-        forced = e ? atoi(e) : 0;
-    }
-    (void)waves1;
-    (void)tneed;
-    return forced == 2 ? 2 : 1;
-}
-
-extern "C" int32_t binf_hmc_sample_gauss_f64(
+extern "C" int32_t binf_hmc_sample_n_gauss_f64(
     const double *q0, const double *p0, const double *u, double *q_out,
-    uint8_t *accepted, int64_t *n_accepted, double *e_before, double *e_after,
-    double timestep, double *dt_chain, int64_t C, int64_t D, int32_t nsteps,
-    double k, double x0, int32_t adapt, double uprate, double downrate,
-    int32_t mode, void *stream)
+    double *samples, uint8_t *accepted, int64_t *n_accepted, double *e_before,
+    double *e_after, double timestep, double *dt_chain, int64_t C, int64_t D,
+    int32_t nsteps, int32_t n, int32_t thin, double k, double x0,
+    int32_t n_adapt, double uprate, double downrate, int32_t mode, void *stream)
 {
-    if (C < 0 || D < 1 || nsteps < 1)
-        return fail(BINF_E_ARG, "hmc_sample_gauss: need C>=0, D>=1, nsteps>=1 (C=%lld D=%lld nsteps=%d)",
-                    (long long)C, (long long)D, nsteps);
+    if (C < 0 || D < 1 || nsteps < 1 || n < 1 || thin < 1 || n_adapt < 0)
+        return fail(BINF_E_ARG, "hmc_sample_gauss: need C>=0, D>=1, nsteps>=1, n>=1, thin>=1, n_adapt>=0");
     if (mode != BINF_MODE_EXACT && mode != BINF_MODE_FMA)
         return fail(BINF_E_ARG, "hmc_sample_gauss: unknown mode %d", mode);
     if (C == 0) return 0;
-    if (!q0 || !p0 || !u || !q_out || !accepted)
+    if (!q0 || !p0 || !u || !q_out)
         return fail(BINF_E_ARG, "hmc_sample_gauss: null buffer");
-    if (adapt && !dt_chain)
-        return fail(BINF_E_ARG, "hmc_sample_gauss: adapt needs dt_chain");
-    const int64_t bytes = C * D * (int64_t)sizeof(double);
-    const char *qo = (const char *)q_out, *qi = (const char *)q0, *pi = (const char *)p0;
-    if ((qo != qi && qo < qi + bytes && qi < qo + bytes) ||
-        (qo < pi + bytes && pi < qo + bytes))
-        return fail(BINF_E_ALIAS, "hmc_sample_gauss: q_out overlaps q0/p0 (only q_out == q0 is allowed)");
+    if (n_adapt > 0 && !dt_chain)
+        return fail(BINF_E_ARG, "hmc_sample_gauss: adaption needs dt_chain");
     if (D > 1024)
         return fail(BINF_E_UNSUPPORTED, "hmc_sample_gauss: D=%lld > 1024 not covered by the fused kernel", (long long)D);
     const int32_t H = pairwise_tree_height(D);
     if (H > 3)
         return fail(BINF_E_UNSUPPORTED, "hmc_sample_gauss: pairwise tree height %d > 3 for D=%lld", H, (long long)D);
+    const int64_t bytes = C * D * (int64_t)sizeof(double);
+    const char *qo = (const char *)q_out, *qi = (const char *)q0, *pi = (const char *)p0;
+    if ((qo != qi && qo < qi + bytes && qi < qo + bytes) ||
+        (qo < pi + bytes * n && pi < qo + bytes))
+        return fail(BINF_E_ALIAS, "hmc_sample_gauss: q_out overlaps q0/p0 (only q_out == q0 is allowed)");
 
-    // widest leaf decides how many elements a lane owns
     int tneed = 1;
     bool regular = true;
     int32_t len0 = -1;
@@ -286,18 +327,21 @@ extern "C" int32_t binf_hmc_sample_gauss_f64(
         if (len0 < 0) len0 = L.len;
         if (L.len != len0 || L.depth != H || (L.len & 7)) regular = false;
     }
-    GaussArgs a;
-    a.q0 = q0; a.p0 = p0; a.u = u; a.q_out = q_out; a.accepted = accepted;
-    a.n_accepted = n_accepted;
-    a.e_before = e_before; a.e_after = e_after; a.dt_chain = dt_chain;
-    a.timestep = timestep; a.k = k; a.x0 = x0; a.uprate = uprate;
-    a.downrate = downrate; a.C = C; a.D = (int32_t)D; a.nsteps = nsteps;
-    a.H = H; a.adapt = adapt;
+    GaussNArgs a;
+    a.q0 = q0; a.p0 = p0; a.u = u; a.q_out = q_out; a.samples = samples;
+    a.accepted = accepted; a.n_accepted = n_accepted; a.e_before = e_before;
+    a.e_after = e_after; a.dt_chain = dt_chain; a.timestep = timestep; a.k = k;
+    a.x0 = x0; a.uprate = uprate; a.downrate = downrate; a.C = C;
+    a.D = (int32_t)D; a.nsteps = nsteps; a.H = H; a.n = n; a.thin = thin;
+    a.n_adapt = n_adapt < n ? n_adapt : n;
+    {
+        static int stg = -1;
+        if (stg < 0) { const char *e = getenv("BINF_GAUSS_STAGGER"); stg = e ? atoi(e) : 0; }
+        a.stagger = n >= 4 ? stg : 0;
+    }
 
     const int64_t chains_per_wave = 64 >> (3 + H);
-    const int64_t waves1 = (C + chains_per_wave - 1) / chains_per_wave;
-    const int nch = pick_nch(waves1, tneed);
-    const int64_t waves = (waves1 + nch - 1) / nch;
+    const int64_t waves = (C + chains_per_wave - 1) / chains_per_wave;
     const int64_t blocks = (waves + 3) / 4;
     if (blocks > 0x7fffffffLL)
         return fail(BINF_E_UNSUPPORTED, "hmc_sample_gauss: too many chains");
@@ -306,12 +350,29 @@ extern "C" int32_t binf_hmc_sample_gauss_f64(
     const bool unit = (k == 1.0 && x0 == 0.0);
     const bool fma = (mode == BINF_MODE_FMA);
     hipError_t e;
-    if (tneed <= 1)       e = launch_t<1>(a, regular && tneed == 1, nch, unit, fma, grid, st);
-    else if (tneed <= 2)  e = launch_t<2>(a, regular && tneed == 2, nch, unit, fma, grid, st);
-    else if (tneed <= 4)  e = launch_t<4>(a, regular && tneed == 4, nch, unit, fma, grid, st);
-    else if (tneed <= 8)  e = launch_t<8>(a, regular && tneed == 8, nch, unit, fma, grid, st);
-    else if (tneed <= 12) e = launch_t<12>(a, regular && tneed == 12, nch, unit, fma, grid, st);
-    else                  e = launch_t<16>(a, regular && tneed == 16, nch, unit, fma, grid, st);
-    if (e != hipSuccess) return hip_fail(e, "hmc_gauss_wave_kernel launch");
+    if (tneed <= 1)       e = launch_n_t<1>(a, regular && tneed == 1, unit, fma, grid, st);
+    else if (tneed <= 2)  e = launch_n_t<2>(a, regular && tneed == 2, unit, fma, grid, st);
+    else if (tneed <= 4)  e = launch_n_t<4>(a, regular && tneed == 4, unit, fma, grid, st);
+    else if (tneed <= 8)  e = launch_n_t<8>(a, regular && tneed == 8, unit, fma, grid, st);
+    else if (tneed <= 12) e = launch_n_t<12>(a, regular && tneed == 12, unit, fma, grid, st);
+    else                  e = launch_n_t<16>(a, regular && tneed == 16, unit, fma, grid, st);
+    if (e != hipSuccess) return hip_fail(e, "hmc_gauss_persist_kernel launch");
     return 0;
+}
+
+// One transition per launch: HMCSampler.sample() for every chain.
+extern "C" int32_t binf_hmc_sample_gauss_f64(
+    const double *q0, const double *p0, const double *u, double *q_out,
+    uint8_t *accepted, int64_t *n_accepted, double *e_before, double *e_after,
+    double timestep, double *dt_chain, int64_t C, int64_t D, int32_t nsteps,
+    double k, double x0, int32_t adapt, double uprate, double downrate,
+    int32_t mode, void *stream)
+{
+    if (C > 0 && D >= 1 && nsteps >= 1 && q0 && p0 && u && q_out && !accepted)
+        return fail(BINF_E_ARG, "hmc_sample_gauss: null buffer");
+    return binf_hmc_sample_n_gauss_f64(q0, p0, u, q_out, nullptr, accepted,
+                                       n_accepted, e_before, e_after, timestep,
+                                       dt_chain, C, D, nsteps, 1, 1, k, x0,
+                                       adapt ? 1 : 0, uprate, downrate, mode,
+                                       stream);
 }
