@@ -60,7 +60,7 @@ template <int TMAX, bool REGULAR, bool UNIT, bool FMA>
 __global__ void __launch_bounds__(256)
 hmc_gauss_persist_kernel(const GaussNArgs a)
 {
-    constexpr int GS = (TMAX % 4 == 0) ? 4 : TMAX;
+    constexpr int GS = (TMAX % 8 == 0) ? 8 : ((TMAX % 4 == 0) ? 4 : TMAX);   // measured: 8 beats 4 and 16
     constexpr int NG = TMAX / GS;
     __shared__ double stash[4][TMAX][64];
 
