@@ -53,7 +53,6 @@ struct GaussNArgs {
     int32_t n;               // transitions per launch
     int32_t thin;            // record every thin-th state (>= 1)
     int32_t n_adapt;         // the first n_adapt transitions adapt the timestep
-    int32_t stagger;         // start delay per hardware wave slot, in s_sleep(127) units
 };
 
 template <int TMAX, bool REGULAR, bool UNIT, bool FMA>
@@ -97,18 +96,6 @@ hmc_gauss_persist_kernel(const GaussNArgs a)
     double dt = a.dt_chain ? a.dt_chain[chain] : a.timestep;
     double uu = a.u[chain];
     __builtin_amdgcn_sched_barrier(0);
-
-    // One-time start stagger: the waves sharing a SIMD run the same program
-    // from the same start and would reach the serial reduce -> exp tail of
-    // every transition together, leaving the FP64 pipe idle.  Offsetting them
-    // by their hardware wave slot once makes one wave's tail overlap the
-    // others' trajectories for the rest of the launch.
-    if (a.stagger > 0) {
-        // HW_REG_HW_ID (id 4), WAVE_ID = bits [3:0]
-        const unsigned slot_id = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 4) & 3u;
-        for (unsigned i = 0; i < slot_id * (unsigned)a.stagger; ++i)
-            __builtin_amdgcn_s_sleep(127);
-    }
 
     // q lives in registers for the whole launch; the momentum is needed one
     // element group at a time, so it streams through a 2-deep register ring
@@ -334,11 +321,6 @@ extern "C" int32_t binf_hmc_sample_n_gauss_f64(
     a.x0 = x0; a.uprate = uprate; a.downrate = downrate; a.C = C;
     a.D = (int32_t)D; a.nsteps = nsteps; a.H = H; a.n = n; a.thin = thin;
     a.n_adapt = n_adapt < n ? n_adapt : n;
-    {
-        static int stg = -1;
-        if (stg < 0) { const char *e = getenv("BINF_GAUSS_STAGGER"); stg = e ? atoi(e) : 0; }
-        a.stagger = n >= 4 ? stg : 0;
-    }
 
     const int64_t chains_per_wave = 64 >> (3 + H);
     const int64_t waves = (C + chains_per_wave - 1) / chains_per_wave;
