@@ -26,10 +26,14 @@ __device__ inline void lane_sum_add(LaneSum &s, double v, int t, int T)
 }
 
 // Cross-lane part of np.sum.  All lanes of the wave must call this (the
-// shuffles need a full exec mask).
-template <bool REGULAR>
+// shuffles need a full exec mask).  LW = log2(waves per chain): levels 0..2 of
+// the leaf tree live inside a wave (xor-shuffles 8, 16, 32), levels >= 3 join
+// the waves of a chain through the LDS slots `xch` (one per wave of the
+// block; every wave of the block must call this the same number of times).
+template <bool REGULAR, int LW = 0>
 __device__ inline double chain_sum_finish(const LaneSum &s, int T, int rem,
-                                          int lane, int H, int leafdepth)
+                                          int lane, int H, int leafdepth,
+                                          double *xch = nullptr, int wib = 0)
 {
     double r = s.r;
     // ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7))
@@ -49,10 +53,22 @@ __device__ inline double chain_sum_finish(const LaneSum &s, int T, int rem,
         }
     }
     // join the leaves: level l combines the two depth-(H-l) subtrees
-    for (int l = 0; l < H; ++l) {
+    const int hin = (LW > 0) ? 3 : H;
+    for (int l = 0; l < hin; ++l) {
         const double o = shfl_xor_f64(res, 8 << l);
         const double n = res + o;
         res = (leafdepth >= H - l) ? n : res;
+    }
+    if (LW > 0) {
+#pragma unroll
+        for (int l = 3; l < 3 + LW; ++l) {
+            __syncthreads();
+            if (lane == 0) xch[wib] = res;
+            __syncthreads();
+            const double o = xch[wib ^ (1 << (l - 3))];
+            const double n = res + o;
+            res = (leafdepth >= H - l) ? n : res;
+        }
     }
     return 0.0 + res;   // np.add.reduce starts from the identity +0.0
 }

@@ -55,30 +55,40 @@ struct GaussNArgs {
     int32_t n_adapt;         // the first n_adapt transitions adapt the timestep
 };
 
-template <int TMAX, bool REGULAR, bool UNIT, bool FMA>
-__global__ void __launch_bounds__(256)
+// LW = log2(waves per chain).  LW = 0: a chain is G = 8 << H <= 64 lanes of one
+// wave (several chains per wave when G < 64).  LW > 0 (D > 1024): a chain spans
+// 2 / 4 / 8 whole waves of the workgroup; the leaf-tree levels above a wave are
+// joined through LDS (chain_sum_finish).
+template <int TMAX, bool REGULAR, bool UNIT, bool FMA, int LW>
+__global__ void __launch_bounds__(LW == 3 ? 512 : 256)
 hmc_gauss_persist_kernel(const GaussNArgs a)
 {
+    constexpr int WPB = (LW == 3) ? 8 : 4;           // waves per workgroup
+    constexpr int WPC = 1 << LW;                     // waves per chain
+    __shared__ double xch[WPB];
     constexpr int GS = (TMAX % 8 == 0) ? 8 : ((TMAX % 4 == 0) ? 4 : TMAX);   // measured: 8 beats 4 and 16
     constexpr int NG = TMAX / GS;
-    __shared__ double stash[4][TMAX][64];
+    __shared__ double stash[WPB][TMAX][64];
 
     const int lane = threadIdx.x & 63;
     const int wib = threadIdx.x >> 6;
-    const int64_t wave = (int64_t)blockIdx.x * 4 + wib;
+    const int64_t wave = (int64_t)blockIdx.x * WPB + wib;
     const int H = a.H;
-    const int lg = 3 + H;
+    const int lg = (LW > 0) ? 6 : 3 + H;             // log2(lanes of a chain in this wave)
     const int slot = lane & ((1 << lg) - 1);
     const int j = slot & 7;
+    const int wchain = wib & (WPC - 1);              // wave index inside the chain
+    const int grp = (LW > 0) ? ((wchain << 3) | (lane >> 3)) : (slot >> 3);
+    const bool writer = (LW > 0) ? (wchain == 0 && lane == 0) : (slot == 0);
 
     int off, n, leafdepth, canonical;
     if (REGULAR) {
         n = 8 * TMAX;
-        off = (slot >> 3) * n;
+        off = grp * n;
         leafdepth = H;
         canonical = 1;
     } else {
-        const Leaf L = pairwise_leaf(a.D, H, slot >> 3);
+        const Leaf L = pairwise_leaf(a.D, H, grp);
         off = L.off;
         n = L.len;
         leafdepth = L.depth;
@@ -87,7 +97,8 @@ hmc_gauss_persist_kernel(const GaussNArgs a)
     const int T = (n >= 8) ? (n >> 3) : 0;
     const int rem = (n >= 8) ? (n & 7) : n;
 
-    const int64_t raw = (wave << (6 - lg)) + (lane >> lg);
+    const int64_t raw = (LW > 0) ? (int64_t)blockIdx.x * (WPB / WPC) + (wib >> LW)
+                                 : (wave << (6 - lg)) + (lane >> lg);
     const bool cvalid = raw < a.C;
     const int64_t chain = cvalid ? raw : a.C - 1;
     const int64_t CD = a.C * (int64_t)a.D;
@@ -121,7 +132,7 @@ hmc_gauss_persist_kernel(const GaussNArgs a)
         const double d = UNIT ? q[t] : q[t] - a.x0;
         lane_sum_add<REGULAR>(s0, d * d, t, T);
     }
-    double Sq_state = chain_sum_finish<REGULAR>(s0, T, rem, lane, H, leafdepth);
+    double Sq_state = chain_sum_finish<REGULAR, LW>(s0, T, rem, lane, H, leafdepth, xch, wib);
     int64_t nacc = 0;
 
     for (int s = 0; s < a.n; ++s) {
@@ -202,9 +213,9 @@ hmc_gauss_persist_kernel(const GaussNArgs a)
 #pragma unroll
             for (int i = 0; i < GS; ++i) pa[i] = pb[i];
         }
-        const double Spb = chain_sum_finish<REGULAR>(spb, T, rem, lane, H, leafdepth);
-        const double Sqa = chain_sum_finish<REGULAR>(sqa, T, rem, lane, H, leafdepth);
-        const double Spa = chain_sum_finish<REGULAR>(spa, T, rem, lane, H, leafdepth);
+        const double Spb = chain_sum_finish<REGULAR, LW>(spb, T, rem, lane, H, leafdepth, xch, wib);
+        const double Sqa = chain_sum_finish<REGULAR, LW>(sqa, T, rem, lane, H, leafdepth, xch, wib);
+        const double Spa = chain_sum_finish<REGULAR, LW>(spa, T, rem, lane, H, leafdepth, xch, wib);
         const double Eb = -(c_lp * Sq_state) + 0.5 * Spb;
         const double Ea = -(c_lp * Sqa) + 0.5 * Spa;
 
@@ -216,7 +227,7 @@ hmc_gauss_persist_kernel(const GaussNArgs a)
         const double dt_used = dt;
         if (s < a.n_adapt)                                    // hmc.py:188-191
             dt = acc ? dt * a.uprate : dt * a.downrate;
-        if (cvalid && slot == 0) {
+        if (cvalid && writer) {
             const int64_t o = (int64_t)s * a.C + chain;
             if (a.accepted) a.accepted[o] = acc ? 1 : 0;
             if (a.e_before) a.e_before[o] = Eb;
@@ -239,7 +250,7 @@ hmc_gauss_persist_kernel(const GaussNArgs a)
         uu = un;
     }
 
-    if (cvalid && slot == 0) {
+    if (cvalid && writer) {
         if (a.n_accepted) a.n_accepted[chain] += nacc;
         if (a.n_adapt > 0 && a.dt_chain) a.dt_chain[chain] = dt;
     }
@@ -251,16 +262,17 @@ hmc_gauss_persist_kernel(const GaussNArgs a)
     }
 }
 
-template <int TMAX, bool REGULAR>
-static hipError_t launch_n_tr(const GaussNArgs &a, bool unit, bool fma, dim3 grid,
-                              hipStream_t st)
+template <int TMAX, bool REGULAR, int LW>
+static hipError_t launch_n_trl(const GaussNArgs &a, bool unit, bool fma, dim3 grid,
+                               hipStream_t st)
 {
+    constexpr int BS = (LW == 3) ? 512 : 256;
     if (unit) {
-        if (fma) hmc_gauss_persist_kernel<TMAX, REGULAR, true, true><<<grid, 256, 0, st>>>(a);
-        else     hmc_gauss_persist_kernel<TMAX, REGULAR, true, false><<<grid, 256, 0, st>>>(a);
+        if (fma) hmc_gauss_persist_kernel<TMAX, REGULAR, true, true, LW><<<grid, BS, 0, st>>>(a);
+        else     hmc_gauss_persist_kernel<TMAX, REGULAR, true, false, LW><<<grid, BS, 0, st>>>(a);
     } else {
-        if (fma) hmc_gauss_persist_kernel<TMAX, REGULAR, false, true><<<grid, 256, 0, st>>>(a);
-        else     hmc_gauss_persist_kernel<TMAX, REGULAR, false, false><<<grid, 256, 0, st>>>(a);
+        if (fma) hmc_gauss_persist_kernel<TMAX, REGULAR, false, true, LW><<<grid, BS, 0, st>>>(a);
+        else     hmc_gauss_persist_kernel<TMAX, REGULAR, false, false, LW><<<grid, BS, 0, st>>>(a);
     }
     return hipGetLastError();
 }
@@ -269,8 +281,17 @@ template <int TMAX>
 static hipError_t launch_n_t(const GaussNArgs &a, bool regular, bool unit, bool fma,
                              dim3 grid, hipStream_t st)
 {
-    return regular ? launch_n_tr<TMAX, true>(a, unit, fma, grid, st)
-                   : launch_n_tr<TMAX, false>(a, unit, fma, grid, st);
+    return regular ? launch_n_trl<TMAX, true, 0>(a, unit, fma, grid, st)
+                   : launch_n_trl<TMAX, false, 0>(a, unit, fma, grid, st);
+}
+
+// chains spanning 2^LW waves: leaves of any length <= 128, so TMAX = 16
+template <int LW>
+static hipError_t launch_n_wide(const GaussNArgs &a, bool regular, bool unit, bool fma,
+                                dim3 grid, hipStream_t st)
+{
+    return regular ? launch_n_trl<16, true, LW>(a, unit, fma, grid, st)
+                   : launch_n_trl<16, false, LW>(a, unit, fma, grid, st);
 }
 
 }  // namespace binf
@@ -293,11 +314,12 @@ extern "C" int32_t binf_hmc_sample_n_gauss_f64(
         return fail(BINF_E_ARG, "hmc_sample_gauss: null buffer");
     if (n_adapt > 0 && !dt_chain)
         return fail(BINF_E_ARG, "hmc_sample_gauss: adaption needs dt_chain");
-    if (D > 1024)
-        return fail(BINF_E_UNSUPPORTED, "hmc_sample_gauss: D=%lld > 1024 not covered by the fused kernel", (long long)D);
+    if (D > 8192)
+        return fail(BINF_E_UNSUPPORTED, "hmc_sample_gauss: D=%lld > 8192 not covered by the fused kernel", (long long)D);
     const int32_t H = pairwise_tree_height(D);
-    if (H > 3)
-        return fail(BINF_E_UNSUPPORTED, "hmc_sample_gauss: pairwise tree height %d > 3 for D=%lld", H, (long long)D);
+    if (H > 6)
+        return fail(BINF_E_UNSUPPORTED, "hmc_sample_gauss: pairwise tree height %d > 6 for D=%lld", H, (long long)D);
+    const int LW = H > 3 ? H - 3 : 0;                // log2(waves per chain)
     const int64_t bytes = C * D * (int64_t)sizeof(double);
     const char *qo = (const char *)q_out, *qi = (const char *)q0, *pi = (const char *)p0;
     if ((qo != qi && qo < qi + bytes && qi < qo + bytes) ||
@@ -322,9 +344,15 @@ extern "C" int32_t binf_hmc_sample_n_gauss_f64(
     a.D = (int32_t)D; a.nsteps = nsteps; a.H = H; a.n = n; a.thin = thin;
     a.n_adapt = n_adapt < n ? n_adapt : n;
 
-    const int64_t chains_per_wave = 64 >> (3 + H);
-    const int64_t waves = (C + chains_per_wave - 1) / chains_per_wave;
-    const int64_t blocks = (waves + 3) / 4;
+    int64_t blocks;
+    if (LW == 0) {
+        const int64_t chains_per_wave = 64 >> (3 + H);
+        const int64_t waves = (C + chains_per_wave - 1) / chains_per_wave;
+        blocks = (waves + 3) / 4;
+    } else {
+        const int64_t chains_per_block = (LW == 3 ? 8 : 4) >> LW;
+        blocks = (C + chains_per_block - 1) / chains_per_block;
+    }
     if (blocks > 0x7fffffffLL)
         return fail(BINF_E_UNSUPPORTED, "hmc_sample_gauss: too many chains");
     dim3 grid((unsigned)blocks);
@@ -332,7 +360,10 @@ extern "C" int32_t binf_hmc_sample_n_gauss_f64(
     const bool unit = (k == 1.0 && x0 == 0.0);
     const bool fma = (mode == BINF_MODE_FMA);
     hipError_t e;
-    if (tneed <= 1)       e = launch_n_t<1>(a, regular && tneed == 1, unit, fma, grid, st);
+    if (LW == 1)          e = launch_n_wide<1>(a, regular && tneed == 16, unit, fma, grid, st);
+    else if (LW == 2)     e = launch_n_wide<2>(a, regular && tneed == 16, unit, fma, grid, st);
+    else if (LW == 3)     e = launch_n_wide<3>(a, regular && tneed == 16, unit, fma, grid, st);
+    else if (tneed <= 1)  e = launch_n_t<1>(a, regular && tneed == 1, unit, fma, grid, st);
     else if (tneed <= 2)  e = launch_n_t<2>(a, regular && tneed == 2, unit, fma, grid, st);
     else if (tneed <= 4)  e = launch_n_t<4>(a, regular && tneed == 4, unit, fma, grid, st);
     else if (tneed <= 8)  e = launch_n_t<8>(a, regular && tneed == 8, unit, fma, grid, st);

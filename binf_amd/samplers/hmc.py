@@ -275,7 +275,8 @@ class HMCSampler(object):
 
 
 def _gauss_kernel_covers(D):
-    return 1 <= D <= 1024 and _native.pairwise_tree_height(D) <= 3
+    # one wave per chain up to tree height 3; 2/4/8 waves per chain up to 6
+    return 1 <= D <= 8192 and _native.pairwise_tree_height(D) <= 6
 
 
 def _as2d(x):

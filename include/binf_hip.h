@@ -74,8 +74,9 @@ int32_t binf_last_error(char *buf, size_t n);
  *                               *downrate on reject (hmc.py:188-191).
  *                               adapt != 0 requires dt_chain != NULL.
  *   mode        BINF_MODE_EXACT | BINF_MODE_FMA
- * Supported: 1 <= D <= 1024 whose numpy pairwise-sum tree has height <= 3
- * (every D <= 920 and all multiples of 8 up to 1024); nsteps >= 1.
+ * Supported: 1 <= D <= 8192 whose numpy pairwise-sum tree has height <= 6
+ * (every D <= 7400 and all multiples of 64 up to 8192; one wave per chain up to
+ * height 3, i.e. D <= ~1024, then 2 / 4 / 8 waves per chain); nsteps >= 1.
  * ---------------------------------------------------------------------- */
 int32_t binf_hmc_sample_gauss_f64(const double *q0, const double *p0,
                                   const double *u, double *q_out,

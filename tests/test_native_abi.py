@@ -41,7 +41,7 @@ def test_error_codes_and_text_without_gpu():
     # never dereferenced: argument validation returns before any launch
     fake = [i << 40 for i in range(1, 6)]
     rc = L.binf_hmc_sample_gauss_f64(fake[0], fake[1], fake[2], fake[3], fake[4],
-                                     None, None, None, 0.1, None, 4, 5000, 1,
+                                     None, None, None, 0.1, None, 4, 9000, 1,
                                      1.0, 0.0, 0, 1.05, 0.95, 0, None)
     assert rc == _native.E_UNSUPPORTED
     with pytest.raises(NotImplementedError):
@@ -101,9 +101,12 @@ def test_tree_walk_matches_numpy_recursion(n):
 
 
 def test_fused_kernel_coverage_claim():
-    # header: every D <= 920 and all multiples of 8 up to 1024 have height <= 3
+    # one wave per chain: every D <= 920 and all multiples of 8 up to 1024
     for D in list(range(1, 921)) + list(range(928, 1025, 8)):
         assert _native.pairwise_tree_height(D) <= 3, D
+    # header: every D <= 7400 and all multiples of 64 up to 8192 have height <= 6
+    for D in list(range(1, 7401)) + list(range(7424, 8193, 64)):
+        assert _native.pairwise_tree_height(D) <= 6, D
 
 
 def test_product_package_never_touches_the_oracle():
