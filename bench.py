@@ -214,12 +214,12 @@ def main():
         # HBM traffic from the committed PMC summary of this exact configuration
         traffic, traffic_src = None, None
         try:
-            pm = json.load(open(os.path.join(ROOT, 'profiles', 'r01_c_pmc_traffic.json')))
+            pm = json.load(open(os.path.join(ROOT, 'profiles', 'r01_d_pmc_traffic.json')))
             c = pm['config']
             if (c['chains'], c['dims'], c['nsteps'], c['fuse'], c['thin'], c['mode']) == \
                     (C, D, L, F, args.thin if F > 1 else 1, args.mode):
                 traffic = pm['hbm_bytes_per_transition'] * F
-                traffic_src = 'profiles/r01_c_pmc_traffic.json (rocprofv3 --pmc ' \
+                traffic_src = 'profiles/r01_d_pmc_traffic.json (rocprofv3 --pmc ' \
                               'FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2)'
         except (OSError, ValueError, KeyError):
             pass
