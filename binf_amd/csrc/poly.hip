@@ -143,7 +143,11 @@ constexpr int LDA = 17;      // padded row length of the staged A tile (doubles)
 // (indices KB .. KB+KV-1, KB = 4*KS = 16*RT when KV > 0) on the VALU, which
 // runs beside the MFMA pipe: for K = 33 that is 16 MFMAs + 8 FMAs per tile
 // instead of 21 MFMAs.
-template <int KS, int RT, int KV>
+// CT = 16-chain tiles per wave: a wave owns CT * 16 chains, a workgroup
+// 64 * CT.  The A-operand LDS reads are shared by the wave's tiles and the
+// tiles' accumulator chains are independent, so the MFMA pipe sees CT times
+// more work per barrier.
+template <int KS, int RT, int KV, int CT>
 __global__ void __launch_bounds__(256) poly_grad_mfma_kernel(const GradArgs a)
 {
     constexpr int KB = 4 * KS;                       // first VALU coefficient
@@ -159,28 +163,33 @@ __global__ void __launch_bounds__(256) poly_grad_mfma_kernel(const GradArgs a)
     const int wave = tid >> 6;
     const int lc = lane & 15;
     const int lk = lane >> 4;
-    const int64_t chain = (int64_t)blockIdx.x * 64 + wave * 16 + lc;
-    const bool cvalid = chain < a.C;
     const int K = a.K, N = a.N;
 
-    // forward B operands: theta[chain][4s + lk]
-    double th[KS];
+    int64_t chain[CT];
+    bool cvalid[CT];
+    double th[CT][KS];
+    double thv[CT][KV > 0 ? KV : 1], gv[CT][KV > 0 ? KV : 1];
+    double tau[CT];
+    v4d G[CT][RT];
 #pragma unroll
-    for (int s = 0; s < KS; ++s) {
-        const int k = 4 * s + lk;
-        th[s] = (cvalid && k < K) ? a.theta[chain * K + k] : 0.0;
+    for (int c = 0; c < CT; ++c) {
+        chain[c] = ((int64_t)blockIdx.x * 4 + wave) * (16 * CT) + 16 * c + lc;
+        cvalid[c] = chain[c] < a.C;
+        // forward B operands: theta[chain][4s + lk]
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int k = 4 * s + lk;
+            th[c][s] = (cvalid[c] && k < K) ? a.theta[chain[c] * K + k] : 0.0;
+        }
+#pragma unroll
+        for (int v = 0; v < KV; ++v) {
+            thv[c][v] = (cvalid[c] && KB + v < K) ? a.theta[chain[c] * K + KB + v] : 0.0;
+            gv[c][v] = 0.0;
+        }
+        tau[c] = cvalid[c] ? (a.tau_chain ? a.tau_chain[chain[c]] : a.tau) : 0.0;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) G[c][rt] = (v4d){0.0, 0.0, 0.0, 0.0};
     }
-    double thv[KV > 0 ? KV : 1], gv[KV > 0 ? KV : 1];
-#pragma unroll
-    for (int v = 0; v < KV; ++v) {
-        thv[v] = (cvalid && KB + v < K) ? a.theta[chain * K + KB + v] : 0.0;
-        gv[v] = 0.0;
-    }
-    const double tau = cvalid ? (a.tau_chain ? a.tau_chain[chain] : a.tau) : 0.0;
-
-    v4d G[RT];
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt) G[rt] = (v4d){0.0, 0.0, 0.0, 0.0};
 
     const int t0 = blockIdx.y * a.tiles_per_split;
     int t1 = t0 + a.tiles_per_split;
@@ -218,57 +227,82 @@ __global__ void __launch_bounds__(256) poly_grad_mfma_kernel(const GradArgs a)
         const int buf = (t - t0) & 1;
         if (t + 1 < t1) fetch(t + 1);          // in flight during the MFMAs
         // forward: M^T[n][c] = sum_k A[k][n] theta[c][k]
-        v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
+        v4d acc[CT];
 #pragma unroll
-        for (int s = 0; s < KS; ++s)
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sA[buf][4 * s + lk][lc], th[s], acc, 0, 0, 0);
+        for (int c = 0; c < CT; ++c) acc[c] = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const double av = sA[buf][4 * s + lk][lc];
+#pragma unroll
+            for (int c = 0; c < CT; ++c)
+                acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, th[c][s], acc[c], 0, 0, 0);
+        }
         // trailing coefficients on the VALU: lane holds (n = lk + 4r, c = lc)
 #pragma unroll
         for (int v = 0; v < KV; ++v)
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                acc[r] = __builtin_fma(thv[v], sA[buf][KB + v][lk + 4 * r], acc[r]);
+            for (int r = 0; r < 4; ++r) {
+                const double av = sA[buf][KB + v][lk + 4 * r];
+#pragma unroll
+                for (int c = 0; c < CT; ++c)
+                    acc[c][r] = __builtin_fma(thv[c][v], av, acc[c][r]);
+            }
         // error-model gradient in place: r[n][c] = (mock - y[n]) * tau_c
-        double rr[4];
+        double rr[CT][4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int nl = lk + 4 * r;
-            rr[r] = (t * 16 + nl < N) ? (acc[r] - sY[buf][nl]) * tau : 0.0;
+            const double yv = sY[buf][nl];
+            const bool nv = t * 16 + nl < N;
+#pragma unroll
+            for (int c = 0; c < CT; ++c)
+                rr[c][r] = nv ? (acc[c][r] - yv) * tau[c] : 0.0;
         }
         // backward: G^T[i][c] += sum_n A[i][n] r[n][c]; the D-layout register r
         // of the forward product is exactly the B operand of k-step r.
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-            for (int s = 0; s < 4; ++s)
-                G[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(sA[buf][16 * rt + lc][4 * s + lk], rr[s], G[rt], 0, 0, 0);
+            for (int s = 0; s < 4; ++s) {
+                const double av = sA[buf][16 * rt + lc][4 * s + lk];
+#pragma unroll
+                for (int c = 0; c < CT; ++c)
+                    G[c][rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, rr[c][s], G[c][rt], 0, 0, 0);
+            }
 #pragma unroll
         for (int v = 0; v < KV; ++v)
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                gv[v] = __builtin_fma(sA[buf][KB + v][lk + 4 * r], rr[r], gv[v]);
+            for (int r = 0; r < 4; ++r) {
+                const double av = sA[buf][KB + v][lk + 4 * r];
+#pragma unroll
+                for (int c = 0; c < CT; ++c)
+                    gv[c][v] = __builtin_fma(av, rr[c][r], gv[c][v]);
+            }
         if (t + 1 < t1) stash(buf ^ 1);
         __syncthreads();
     }
-    // the VALU rows: sum the four lk partials of each chain
 #pragma unroll
-    for (int v = 0; v < KV; ++v) {
-        gv[v] = gv[v] + shfl_xor_f64(gv[v], 16);
-        gv[v] = gv[v] + shfl_xor_f64(gv[v], 32);
-    }
-    if (cvalid) {
-        double *dst = a.part + ((int64_t)blockIdx.y * a.C + chain) * K;
+    for (int c = 0; c < CT; ++c) {
+        // the VALU rows: sum the four lk partials of each chain
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt)
+        for (int v = 0; v < KV; ++v) {
+            gv[c][v] = gv[c][v] + shfl_xor_f64(gv[c][v], 16);
+            gv[c][v] = gv[c][v] + shfl_xor_f64(gv[c][v], 32);
+        }
+        if (cvalid[c]) {
+            double *dst = a.part + ((int64_t)blockIdx.y * a.C + chain[c]) * K;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int i = 16 * rt + lk + 4 * r;
-                if (i < K) dst[i] = G[rt][r];
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = 16 * rt + lk + 4 * r;
+                    if (i < K) dst[i] = G[c][rt][r];
+                }
+            if (lk == 0) {
+#pragma unroll
+                for (int v = 0; v < KV; ++v)
+                    if (KB + v < K) dst[KB + v] = gv[c][v];
             }
-        if (lk == 0) {
-#pragma unroll
-            for (int v = 0; v < KV; ++v)
-                if (KB + v < K) dst[KB + v] = gv[v];
         }
     }
 }
@@ -284,10 +318,22 @@ __global__ void split_reduce_kernel(const double *part, double *out, int64_t n,
     out[j] = s;
 }
 
+static int grad_ct(int64_t C)
+{
+    // two 16-chain tiles per wave once there are enough chains to fill the chip
+    static int forced = -1;
+    if (forced < 0) {
+        const char *e = getenv("BINF_POLY_GRAD_CT");      // development aid
+        forced = e ? atoi(e) : 0;
+    }
+    if (forced == 1 || forced == 2) return forced;
+    return C >= 2048 ? 2 : 1;
+}
+
 static int grad_splits(int64_t C, int64_t N)
 {
     // aim at ~4 workgroups per CU; never more splits than data tiles
-    const int64_t wgx = (C + 63) / 64;
+    const int64_t wgx = (C + 64 * grad_ct(C) - 1) / (64 * grad_ct(C));
     const int64_t ntiles = (N + 15) / 16;
     const int64_t target = 1024;             // measured best on MI355X (512..4096 tried)
     int64_t ns = (target + wgx - 1) / wgx;
@@ -298,9 +344,10 @@ static int grad_splits(int64_t C, int64_t N)
 }
 
 template <int KS, int RT, int KV>
-static hipError_t grad_launch(const GradArgs &a, dim3 grid, hipStream_t st)
+static hipError_t grad_launch(const GradArgs &a, int ct, dim3 grid, hipStream_t st)
 {
-    poly_grad_mfma_kernel<KS, RT, KV><<<grid, 256, 0, st>>>(a);
+    if (ct == 2) poly_grad_mfma_kernel<KS, RT, KV, 2><<<grid, 256, 0, st>>>(a);
+    else         poly_grad_mfma_kernel<KS, RT, KV, 1><<<grid, 256, 0, st>>>(a);
     return hipGetLastError();
 }
 
@@ -441,22 +488,23 @@ extern "C" int32_t binf_poly_gauss_grad_f64(const double *coeffs, const double *
     a.tiles_per_split = (ntiles + ns - 1) / ns;
     if (a.tiles_per_split < 1) a.tiles_per_split = 1;
     a.part = ns > 1 ? (double *)workspace : out;
-    dim3 grid((unsigned)((C + 63) / 64), (unsigned)ns);
+    const int ct = grad_ct(C);
+    dim3 grid((unsigned)((C + 64 * ct - 1) / (64 * ct)), (unsigned)ns);
     hipStream_t st = (hipStream_t)stream;
     hipError_t e;
-    if (K <= 4)       e = grad_launch<1, 1, 0>(a, grid, st);
-    else if (K <= 8)  e = grad_launch<2, 1, 0>(a, grid, st);
-    else if (K <= 16) e = grad_launch<4, 1, 0>(a, grid, st);
-    else if (K == 17) e = grad_launch<4, 1, 1>(a, grid, st);
-    else if (K == 18) e = grad_launch<4, 1, 2>(a, grid, st);
-    else if (K <= 32) e = grad_launch<8, 2, 0>(a, grid, st);
-    else if (K == 33) e = grad_launch<8, 2, 1>(a, grid, st);
-    else if (K == 34) e = grad_launch<8, 2, 2>(a, grid, st);
-    else if (K <= 36) e = grad_launch<9, 3, 0>(a, grid, st);
-    else if (K <= 48) e = grad_launch<12, 3, 0>(a, grid, st);
-    else if (K == 49) e = grad_launch<12, 3, 1>(a, grid, st);
-    else if (K == 50) e = grad_launch<12, 3, 2>(a, grid, st);
-    else              e = grad_launch<16, 4, 0>(a, grid, st);
+    if (K <= 4)       e = grad_launch<1, 1, 0>(a, ct, grid, st);
+    else if (K <= 8)  e = grad_launch<2, 1, 0>(a, ct, grid, st);
+    else if (K <= 16) e = grad_launch<4, 1, 0>(a, ct, grid, st);
+    else if (K == 17) e = grad_launch<4, 1, 1>(a, ct, grid, st);
+    else if (K == 18) e = grad_launch<4, 1, 2>(a, ct, grid, st);
+    else if (K <= 32) e = grad_launch<8, 2, 0>(a, ct, grid, st);
+    else if (K == 33) e = grad_launch<8, 2, 1>(a, ct, grid, st);
+    else if (K == 34) e = grad_launch<8, 2, 2>(a, ct, grid, st);
+    else if (K <= 36) e = grad_launch<9, 3, 0>(a, ct, grid, st);
+    else if (K <= 48) e = grad_launch<12, 3, 0>(a, ct, grid, st);
+    else if (K == 49) e = grad_launch<12, 3, 1>(a, ct, grid, st);
+    else if (K == 50) e = grad_launch<12, 3, 2>(a, ct, grid, st);
+    else              e = grad_launch<16, 4, 0>(a, ct, grid, st);
     if (e != hipSuccess) return hip_fail(e, "poly_gauss_grad launch");
     if (ns > 1) {
         const int64_t n = C * K;
