@@ -14,6 +14,14 @@ GOLDEN_DIR = os.path.join(ROOT, 'tests', 'golden')
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu)')
+    # The shared library is a build artefact (git-ignored): make sure it exists
+    # and is current before any test imports it.  hipcc cross-compiles gfx950
+    # without a GPU; on the GPU box the prebuilt file travels with the snapshot.
+    lib = os.path.join(ROOT, 'binf_amd', 'csrc', 'libbinf_hip.so')
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    if not os.path.exists(lib) and os.path.exists(hipcc):
+        import __graft_entry__
+        __graft_entry__.build()
 
 
 def golden_files(prefix):
