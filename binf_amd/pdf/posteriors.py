@@ -95,7 +95,13 @@ class Posterior(AbstractBinfPDF):
                                   if x in f.variables})
                 total = g if total is None else total + g
         if total is None:
-            raise ValueError('posterior has no differentiable component')
+            # no differentiable component: the reference returns its zero
+            # vector, one entry per element of the differentiable variables
+            # passed in (reference :177-180)
+            import numpy
+            return numpy.zeros(sum(len(variables[v]) if hasattr(variables[v], '__len__')
+                                   else 1 for v in variables
+                                   if v in self.differentiable_variables))
         return total
 
     # -- copies --------------------------------------------------------------

@@ -270,8 +270,10 @@ class DiffForwardModel(MockForwardModel):
 def test_posterior_without_differentiable_component_has_no_force():
     L = make_mock_likelihood()           # X registered non-differentiable
     post = Posterior({L.name: L}, {'a_prior': FlatPrior(0.5)})
-    with pytest.raises(ValueError):
-        post.gradient(X=numpy.array([1.2, 4.2]), a=2.0, b=3.0)
+    # reference posteriors.py:177-187: zeros over the differentiable variables
+    # (none here), nothing added
+    g = post.gradient(X=numpy.array([1.2, 4.2]), a=2.0, b=3.0)
+    assert isinstance(g, numpy.ndarray) and g.shape == (0,)
 
 
 def test_posterior_sums_components_and_skips_nondifferentiable_ones():
