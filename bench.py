@@ -55,7 +55,8 @@ def parse():
                     help='with --fuse > 1: record every thin-th state')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-chains', type=int, default=64)
-    ap.add_argument('--cpu-calls', type=int, default=400)
+    ap.add_argument('--cpu-calls', type=int, default=2000,
+                    help='sample() rounds of the CPU baseline (~10 s on the GPU box)')
     return ap.parse_args()
 
 
