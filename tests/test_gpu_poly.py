@@ -321,3 +321,23 @@ def test_c3_full_size_gradient_properties(device):
     lp = _native.poly_gauss_logp(dev_t(theta, device), dev_t(xs, device), tys, 1.0).cpu().numpy()
     for c in (0, 8191):
         assert lp[c] == -0.5 * np.sum((POLYVAL(xs, theta[c]) - ys) ** 2) * 1.0 + N * 0.5 * np.log(1.0)
+
+
+def test_example_script_counterpart_recovers_the_coefficients(device):
+    """examples/polynomial_fit.py: the reference's example_script.py flow with
+    many chains; the posterior mean must sit near the least-squares fit."""
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                        'examples', 'polynomial_fit.py')
+    spec = importlib.util.spec_from_file_location('polynomial_fit', path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    coeffs, prec = mod.main(['--chains', '256', '--iterations', '300', '--burn-in', '150',
+                             '--thin', '10', '--seed', '0'])
+    assert coeffs.shape == (15, 256, 4) and prec.shape == (15, 256, 1)
+    xs, ys = RE.example_data()
+    lsq = np.polynomial.polynomial.polyfit(xs, ys, 3)
+    mean = coeffs.reshape(-1, 4).mean(0).cpu().numpy()
+    assert np.abs(mean - lsq).max() < 0.25
+    assert 0.5 < float(prec.mean()) < 6.0
