@@ -72,6 +72,8 @@ SIGNATURES = {
                                     _vp]),
     'binf_rng_normal_f64': (_i32, [_vp, _i64, ctypes.c_uint64, ctypes.c_uint64,
                                    _vp]),
+    'binf_rng_normal_zig_f64': (_i32, [_vp, _i64, ctypes.c_uint64,
+                                       ctypes.c_uint64, _vp]),
     'binf_rng_gamma_f64': (_i32, [_vp, _i64, _f64, ctypes.c_uint64,
                                   ctypes.c_uint64, _vp]),
     'binf_rng_philox4x32_10': (_i32, [ctypes.POINTER(ctypes.c_uint32),
@@ -450,6 +452,8 @@ def rng_fill(kind, out, seed, offset, shape=None):
         rc = lib().binf_rng_uniform_f64(p, n, seed, offset, st)
     elif kind == 'normal':
         rc = lib().binf_rng_normal_f64(p, n, seed, offset, st)
+    elif kind == 'normal_zig':
+        rc = lib().binf_rng_normal_zig_f64(p, n, seed, offset, st)
     elif kind == 'gamma':
         rc = lib().binf_rng_gamma_f64(p, n, float(shape), seed, offset, st)
     else:

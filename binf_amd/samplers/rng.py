@@ -29,7 +29,10 @@ class DeviceRNG(object):
     (seed, call order), independent of launch geometry; NOT stream-compatible
     with numpy."""
 
-    def __init__(self, seed=0, device='cuda'):
+    def __init__(self, seed=0, device='cuda', normal='ziggurat'):
+        if normal not in ('ziggurat', 'box_muller'):
+            raise ValueError("normal must be 'ziggurat' or 'box_muller'")
+        self._normal_kind = 'normal_zig' if normal == 'ziggurat' else 'normal'
         self.seed = int(seed)
         self.offset = 0
         self.device = torch.device(device)
@@ -42,7 +45,7 @@ class DeviceRNG(object):
         return out
 
     def normal(self, shape, device):
-        return self._fill('normal', shape, device, 1)
+        return self._fill(self._normal_kind, shape, device, 1)
 
     def uniform(self, n, device):
         return self._fill('uniform', (int(n),), device, 1)

@@ -262,6 +262,9 @@ int32_t binf_rng_uniform_f64(double *out, int64_t n, uint64_t seed, uint64_t off
                              void *stream);                 /* [0, 1), 53 bits  */
 int32_t binf_rng_normal_f64(double *out, int64_t n, uint64_t seed, uint64_t offset,
                             void *stream);                  /* Box-Muller        */
+int32_t binf_rng_normal_zig_f64(double *out, int64_t n, uint64_t seed, uint64_t offset,
+                                void *stream);              /* 256-layer ziggurat;
+                                                               offset < 2^48     */
 int32_t binf_rng_gamma_f64(double *out, int64_t n, double shape, uint64_t seed,
                            uint64_t offset, void *stream);  /* Marsaglia-Tsang   */
 /* Host-side evaluation of the generator's block function (known-answer tests). */

@@ -90,3 +90,32 @@ def test_device_rng_object_advances_and_feeds_the_sampler(device):
     var = float(rec.var())
     assert 0.9 < var < 1.1
     assert 0.5 < float(s.acceptance_rate.mean()) <= 1.0
+
+
+def test_ziggurat_normals(device):
+    """1024-layer ziggurat: distribution (moments, KS distance, tails, layer
+    boundaries), determinism and launch-size independence."""
+    from scipy import stats
+    n = 8_000_000
+    z = fill('normal_zig', n, 21, 5, device)
+    assert np.array_equal(z[:1000], fill('normal_zig', 1000, 21, 5, device))
+    assert not np.array_equal(z[:1000], fill('normal_zig', 1000, 21, 6, device))
+    assert abs(z.mean()) < 2e-3 and abs(z.var() - 1.0) < 3e-3
+    assert abs((z ** 3).mean()) < 6e-3 and abs((z ** 4).mean() - 3.0) < 2e-2
+    assert abs((z ** 6).mean() - 15.0) < 0.3
+    # Kolmogorov-Smirnov distance on a subsample (critical value ~ 1.63/sqrt(n) at 1 %)
+    sub = z[:1_000_000]
+    d = stats.kstest(sub, 'norm').statistic
+    assert d < 1.63 / np.sqrt(sub.size)
+    # tails, including the region beyond the base layer edge R = 4.039
+    for t in (1.0, 2.0, 3.0, 4.038849846109505, 4.5):
+        want = 2 * stats.norm.sf(t)
+        got = (np.abs(z) > t).mean()
+        assert abs(got - want) < 5 * np.sqrt(want / n) + 1e-7, (t, got, want)
+    assert np.abs(z).max() < 7.0
+    assert abs(np.corrcoef(z[0::2], z[1::2])[0, 1]) < 2e-3
+    assert abs((z > 0).mean() - 0.5) < 1e-3
+    rng = DeviceRNG(3, device)                       # ziggurat is the default
+    a = rng.normal((8, 16), device)
+    b = DeviceRNG(3, device, normal='box_muller').normal((8, 16), device)
+    assert a.shape == b.shape and not torch.equal(a, b)
