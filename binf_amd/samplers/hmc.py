@@ -74,6 +74,7 @@ class HMCSampler(object):
         self.counter = 0
         self.last_e_before = None
         self.last_e_after = None
+        self.accepted_history = None      # [n x C] flags of the last sample_n()
 
     # -- reference attributes ----------------------------------------------
     @property
@@ -120,14 +121,14 @@ class HMCSampler(object):
             raise TypeError('HMCSampler needs variable_name to sample()')
         state = self.state
         shape = state.shape                       # quirk Q2: arrays only
-        q0 = state if state.dim() == 2 else state.reshape(1, -1)
+        q0 = (state if state.dim() == 2 else state.reshape(1, -1)).contiguous()
         C, D = q0.shape
         dev = q0.device
         if p0 is None:
             p0 = self.rng.normal((C, D), dev)
             own_p = True
         else:
-            p0 = p0 if p0.dim() == 2 else p0.reshape(1, -1)
+            p0 = (p0 if p0.dim() == 2 else p0.reshape(1, -1)).contiguous()
             own_p = False
         if u is None:
             u = self.rng.uniform(C, dev)
@@ -140,12 +141,8 @@ class HMCSampler(object):
             self.n_accepted = torch.zeros(C, dtype=torch.int64, device=dev)
 
         accepted = torch.empty(C, dtype=torch.uint8, device=dev)
-        spec = None
-        get_spec = getattr(self.pdf, 'native_hmc_spec', None)
-        if get_spec is not None:
-            spec = get_spec(name)
-        if spec is not None and spec[0] == 'gauss' and \
-                _gauss_kernel_covers(D):
+        spec = self._fused_spec(name, D)
+        if spec is not None:
             q_out = self._sample_fused_gauss(spec, q0, p0, u, accepted, adapt)
         else:
             q_out = self._sample_generic(name, state, q0, p0, own_p, u,
@@ -177,7 +174,7 @@ class HMCSampler(object):
             raise ValueError('sample_n: n >= 1 and thin >= 1 required')
         state = self.state
         shape = state.shape
-        q0 = state if state.dim() == 2 else state.reshape(1, -1)
+        q0 = (state if state.dim() == 2 else state.reshape(1, -1)).contiguous()
         C, D = q0.shape
         dev = q0.device
         if p0 is None:
@@ -186,13 +183,9 @@ class HMCSampler(object):
             u = self.rng.uniform(n * C, dev)
         p0 = p0.reshape(n, C, D)
         u = u.reshape(n, C)
-        spec = None
-        get_spec = getattr(self.pdf, 'native_hmc_spec', None)
-        if get_spec is not None:
-            spec = get_spec(name)
+        spec = self._fused_spec(name, D)
         nrec = n // thin
-        if not (spec is not None and spec[0] == 'gauss' and
-                _gauss_kernel_covers(D)):
+        if spec is None:
             out = []
             for i in range(n):
                 x = self.sample(p0=p0[i], u=u[i])
@@ -231,6 +224,15 @@ class HMCSampler(object):
         return samples if state.dim() == 2 else samples.reshape((nrec,) + tuple(shape))
 
     # -- fused tier ----------------------------------------------------------
+    def _fused_spec(self, name, D):
+        """The PDF's fused-kernel descriptor if the library covers this shape,
+        else None (generic per-step tier)."""
+        get_spec = getattr(self.pdf, 'native_hmc_spec', None)
+        spec = get_spec(name) if get_spec is not None else None
+        if spec is not None and spec[0] == 'gauss' and _gauss_kernel_covers(D):
+            return spec
+        return None
+
     def _sample_fused_gauss(self, spec, q0, p0, u, accepted, adapt):
         _, k, x0 = spec
         C, D = q0.shape
@@ -253,8 +255,8 @@ class HMCSampler(object):
         mode = _MODES[self.mode]
         shape = state.shape
         dt, dtc = self._timestep, self._dt_chain
-        V = lambda x: -_as_chain_vector(pdf.log_prob(**{name: x.view(shape)}))
-        grad = lambda x: _as2d(pdf.gradient(**{name: x.view(shape)}))
+        V = lambda x: -_as_chain_vector(pdf.log_prob(**{name: x.view(shape)})).contiguous()
+        grad = lambda x: _as2d(pdf.gradient(**{name: x.view(shape)})).contiguous()
 
         q = q0.clone()
         p = p0 if own_p else p0.clone()

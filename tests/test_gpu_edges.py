@@ -102,3 +102,29 @@ def test_row_sum_many_rows_and_long_rows(device):
     y = rs.standard_normal((2, 300007))
     got = _native.row_sum(dev_t(y, device), _native.ROW_SUMSQ).cpu().numpy()
     assert np.array_equal(got, np.array([np.sum(r ** 2) for r in y]))
+
+
+def test_non_contiguous_inputs_are_accepted(device):
+    """A transposed state / momentum view and a user PDF that returns a
+    non-contiguous gradient must give the same result as contiguous data."""
+    C, D, L, dt = 12, 64, 3, 0.3
+    rs = np.random.RandomState(9)
+    q0, p0, u = rs.standard_normal((C, D)), rs.standard_normal((C, D)), rs.uniform(size=C)
+    want = c_oracle.hmc_sample_gauss(q0, p0, u, dt, L)
+    q_t = dev_t(q0.T.copy(), device).t()            # [C, D] view with swapped strides
+    p_t = dev_t(p0.T.copy(), device).t()
+    assert not q_t.is_contiguous()
+    s = HMCSampler(IsotropicGaussian(), q_t, dt, L, variable_name='x')
+    out = s.sample(p0=p_t, u=dev_t(u, device))
+    assert np.array_equal(out.cpu().numpy(), want['q_out'])
+
+    class Strided(object):
+        def log_prob(self, x):
+            return -0.5 * _native.row_sum(x, _native.ROW_SUMSQ)
+
+        def gradient(self, x):
+            return x.t().contiguous().t()            # same values, non-contiguous
+
+    s2 = HMCSampler(Strided(), dev_t(q0, device), dt, L, variable_name='x')
+    out2 = s2.sample(p0=dev_t(p0, device), u=dev_t(u, device))
+    assert np.array_equal(out2.cpu().numpy(), want['q_out'])
