@@ -68,6 +68,9 @@ SIGNATURES = {
                                          _vp]),
     'binf_pairdist_gauss_grad_f64': (_i32, [_vp, _vp, _f64, _vp, _vp, _i64,
                                             _i64, _vp]),
+    'binf_pairdist_leapfrog_f64': (_i32, [_vp, _vp, _vp, _f64, _vp, _i32, _f64,
+                                          _f64, _i32, _f64, _vp, _i32, _i64,
+                                          _i64, _i32, _vp]),
     'binf_rng_uniform_f64': (_i32, [_vp, _i64, ctypes.c_uint64, ctypes.c_uint64,
                                     _vp]),
     'binf_rng_normal_f64': (_i32, [_vp, _i64, ctypes.c_uint64, ctypes.c_uint64,
@@ -460,3 +463,21 @@ def rng_fill(kind, out, seed, offset, shape=None):
         raise ValueError('unknown draw kind %r' % (kind,))
     check(rc, 'binf_rng_%s_f64' % kind)
     return out
+
+
+def pairdist_leapfrog(q, p, ymat, precision, prior, prior_first, timestep,
+                      dt_chain, nsteps, mode=MODE_EXACT):
+    """In-place leapfrog of (q, p) for the restraint posterior; prior is None
+    or (k, x0) of an isotropic Gaussian on the coordinates."""
+    C, D = _cd(q)
+    n = D // 3
+    tau, tau_chain = _precision_args(precision, C, q.device)
+    k, x0 = prior if prior is not None else (0.0, 0.0)
+    rc = lib().binf_pairdist_leapfrog_f64(
+        dptr(q, numel=C * D, name='q'), dptr(p, numel=C * D, name='p'),
+        dptr(ymat, numel=n * n, name='ymat'), tau,
+        dptr(tau_chain, numel=C, name='precision'), int(prior is not None),
+        float(k), float(x0), int(bool(prior_first)), float(timestep),
+        dptr(dt_chain, numel=C, name='dt_chain'), int(nsteps), C, n, int(mode),
+        stream_handle(q.device))
+    check(rc, 'binf_pairdist_leapfrog_f64')

@@ -37,6 +37,22 @@ pairdist_forward_kernel(const double *x, const int32_t *I, const int32_t *J,
     }
 }
 
+// Restraint weight of one pair: w = (d - y) / d = 1 - y / d with d = |x_i - x_j|.
+// IEEE sqrt + IEEE divide cost ~55 FP64 instructions per pair; instead
+// 1/d = rsqrt(d^2) from the hardware seed (v_rsq_f64) polished by two Newton
+// steps (error below 1 ulp of 1/d), then one FMA.  Used by BOTH force kernels,
+// so the fused leapfrog and the per-step tier stay bit-identical to each other;
+// against the numpy formulation the force is held to 1e-10.
+__device__ inline double pair_weight(double d0, double d1, double d2, double y)
+{
+    const double s = (d0 * d0 + d1 * d1) + d2 * d2;
+    double r = __builtin_amdgcn_rsq(s);
+    const double h = 0.5 * s;
+    r = r * __builtin_fma(-h * r, r, 1.5);
+    r = r * __builtin_fma(-h * r, r, 1.5);
+    return __builtin_fma(-y, r, 1.0);
+}
+
 // out[c, 3i + a] = tau_c * sum_{j != i} (d_ij - y[j][i]) * (x_i - x_j)[a] / d_ij
 // ymat: symmetric [n x n] target distances (diagonal ignored).
 template <int TILE>
@@ -69,8 +85,7 @@ pairdist_grad_kernel(const double *x, const double *ymat, double tau,
                     const double a = xi0 - sx[jj][0];
                     const double b = xi1 - sx[jj][1];
                     const double e = xi2 - sx[jj][2];
-                    const double d = sqrt((a * a + b * b) + e * e);
-                    const double w = (d - ymat[(int64_t)j * n_beads + i]) / d;
+                    const double w = pair_weight(a, b, e, ymat[(int64_t)j * n_beads + i]);
                     f0 += w * a;
                     f1 += w * b;
                     f2 += w * e;
@@ -82,6 +97,128 @@ pairdist_grad_kernel(const double *x, const double *ymat, double tau,
             o[0] = t * f0;
             o[1] = t * f1;
             o[2] = t * f2;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Fused leapfrog for the restraint posterior: the whole _leapfrog() of
+// binf/samplers/hmc.py:92-125 in one launch, one workgroup per chain.  Thread
+// b owns beads b, b + 256, ... (position and momentum in registers); every
+// bead position is mirrored in LDS for the all-pairs force loop.  The force is
+// evaluated exactly like pairdist_grad_kernel (j ascending, j != i) and the
+// gradient is assembled like the Posterior does (component terms in sorted-name
+// order), so the result is bit-identical to the per-step generic tier.
+// ---------------------------------------------------------------------------
+struct PairLeapArgs {
+    double *q;               // [C x 3n] in/out
+    double *p;               // [C x 3n] in/out
+    const double *ymat;      // [n x n]
+    const double *tau_chain; // [C] or null
+    const double *dt_chain;  // [C] or null
+    double tau;
+    double timestep;
+    double prior_k;
+    double prior_x0;
+    int32_t has_prior;
+    int32_t prior_first;     // prior term added before the likelihood term
+    int32_t nsteps;
+    int32_t n_beads;
+};
+
+template <int NB, bool FMA>
+__global__ void __launch_bounds__(256) pairdist_leapfrog_kernel(const PairLeapArgs a)
+{
+    extern __shared__ double sx[];               // [n_beads][3]
+    const int n = a.n_beads;
+    const int64_t c = blockIdx.x;
+    double *qc = a.q + c * 3 * (int64_t)n;
+    double *pc = a.p + c * 3 * (int64_t)n;
+    const double tau = a.tau_chain ? a.tau_chain[c] : a.tau;
+    const double dt = a.dt_chain ? a.dt_chain[c] : a.timestep;
+    const double hdt = 0.5 * dt;
+
+    double q[NB][3], p[NB][3];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const int i = threadIdx.x + 256 * b;
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) {
+            q[b][ax] = (i < n) ? qc[3 * i + ax] : 0.0;
+            p[b][ax] = (i < n) ? pc[3 * i + ax] : 0.0;
+        }
+    }
+    auto publish = [&]() {
+        __syncthreads();
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const int i = threadIdx.x + 256 * b;
+            if (i < n) {
+                sx[3 * i] = q[b][0];
+                sx[3 * i + 1] = q[b][1];
+                sx[3 * i + 2] = q[b][2];
+            }
+        }
+        __syncthreads();
+    };
+    // p -= step * gradient(q)
+    auto kick = [&](double step) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const int i = threadIdx.x + 256 * b;
+            if (i >= n) continue;
+            double f0 = 0.0, f1 = 0.0, f2 = 0.0;
+            for (int j = 0; j < n; ++j) {
+                if (j == i) continue;
+                const double d0 = q[b][0] - sx[3 * j];
+                const double d1 = q[b][1] - sx[3 * j + 1];
+                const double d2 = q[b][2] - sx[3 * j + 2];
+                const double w = pair_weight(d0, d1, d2, a.ymat[(int64_t)j * n + i]);
+                f0 += w * d0;
+                f1 += w * d1;
+                f2 += w * d2;
+            }
+            const double f[3] = {f0, f1, f2};
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) {
+                const double gl = tau * f[ax];
+                double g = gl;
+                if (a.has_prior) {
+                    const double gp = a.prior_k * (q[b][ax] - a.prior_x0);
+                    g = a.prior_first ? gp + gl : gl + gp;
+                }
+                p[b][ax] = FMA ? __builtin_fma(-step, g, p[b][ax]) : p[b][ax] - step * g;
+            }
+        }
+    };
+    auto drift = [&]() {
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax)
+                q[b][ax] = FMA ? __builtin_fma(p[b][ax], dt, q[b][ax]) : q[b][ax] + p[b][ax] * dt;
+    };
+
+    publish();
+    kick(hdt);                                           // hmc.py:116
+    for (int s = 0; s < a.nsteps - 1; ++s) {             // hmc.py:118-120
+        drift();
+        publish();
+        kick(dt);
+    }
+    drift();                                             // hmc.py:122-123
+    publish();
+    kick(hdt);
+
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const int i = threadIdx.x + 256 * b;
+        if (i < n) {
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) {
+                qc[3 * i + ax] = q[b][ax];
+                pc[3 * i + ax] = p[b][ax];
+            }
         }
     }
 }
@@ -125,5 +262,46 @@ extern "C" int32_t binf_pairdist_gauss_grad_f64(const double *x, const double *y
         x, ymat, precision, precision_chain, out, (int32_t)n_beads);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "pairdist_gauss_grad launch");
+    return 0;
+}
+
+extern "C" int32_t binf_pairdist_leapfrog_f64(double *q, double *p, const double *ymat,
+                                              double precision, const double *precision_chain,
+                                              int32_t has_prior, double prior_k, double prior_x0,
+                                              int32_t prior_first, double timestep,
+                                              const double *dt_chain, int32_t nsteps, int64_t C,
+                                              int64_t n_beads, int32_t mode, void *stream)
+{
+    if (C < 0 || n_beads < 1 || nsteps < 1)
+        return fail(BINF_E_ARG, "pairdist_leapfrog: need C>=0, n_beads>=1, nsteps>=1");
+    if (mode != BINF_MODE_EXACT && mode != BINF_MODE_FMA)
+        return fail(BINF_E_ARG, "pairdist_leapfrog: unknown mode %d", mode);
+    if (C == 0) return 0;
+    if (!q || !p || !ymat) return fail(BINF_E_ARG, "pairdist_leapfrog: null buffer");
+    if (n_beads > 1024)
+        return fail(BINF_E_UNSUPPORTED, "pairdist_leapfrog: n_beads=%lld > 1024 not covered by the fused kernel", (long long)n_beads);
+    if (C > 0x7fffffffLL) return fail(BINF_E_UNSUPPORTED, "pairdist_leapfrog: too many chains");
+    PairLeapArgs a;
+    a.q = q; a.p = p; a.ymat = ymat; a.tau_chain = precision_chain; a.dt_chain = dt_chain;
+    a.tau = precision; a.timestep = timestep; a.prior_k = prior_k; a.prior_x0 = prior_x0;
+    a.has_prior = has_prior ? 1 : 0; a.prior_first = prior_first ? 1 : 0;
+    a.nsteps = nsteps; a.n_beads = (int32_t)n_beads;
+    const size_t lds = (size_t)n_beads * 3 * sizeof(double);
+    dim3 grid((unsigned)C);
+    hipStream_t st = (hipStream_t)stream;
+    const bool fma = mode == BINF_MODE_FMA;
+    const int nb = (int)((n_beads + 255) / 256);
+#define LAUNCH(NBV)                                                                   \
+    do {                                                                              \
+        if (fma) pairdist_leapfrog_kernel<NBV, true><<<grid, 256, lds, st>>>(a);      \
+        else     pairdist_leapfrog_kernel<NBV, false><<<grid, 256, lds, st>>>(a);     \
+    } while (0)
+    if (nb <= 1) LAUNCH(1);
+    else if (nb == 2) LAUNCH(2);
+    else if (nb == 3) LAUNCH(3);
+    else LAUNCH(4);
+#undef LAUNCH
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "pairdist_leapfrog launch");
     return 0;
 }

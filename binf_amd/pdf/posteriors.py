@@ -126,3 +126,44 @@ class Posterior(AbstractBinfPDF):
         the HIP library knows how to integrate in a single launch."""
         from binf_amd.example import native_poly
         return native_poly.posterior_hmc_spec(self, variable_name)
+
+    def native_leapfrog_spec(self, variable_name):
+        """Descriptor of a fused leapfrog kernel that integrates
+        ``variable_name`` under THIS posterior's force, or None.
+
+        Recognised: exactly one restraint likelihood (pair-distance forward
+        model + Gaussian error model with the precision fixed) plus at most
+        one isotropic Gaussian prior on the same variable; components without a
+        differentiable variable do not enter the force anyway (quirk Q4).
+        The tuple records the order of the two force terms, which is this
+        class's sorted-component-name order."""
+        from binf_amd.pdf import IsotropicGaussian
+        from binf_amd.pdf.likelihoods import Likelihood
+        lik = prior = None
+        order = []
+        for f in self._ordered_components():
+            if not (len(f.variables) > 0 and len(f.differentiable_variables) > 0):
+                continue
+            if isinstance(f, Likelihood):
+                fs = getattr(f.forward_model, 'native_spec', lambda: None)()
+                es = getattr(f.error_model, 'native_spec', lambda: None)()
+                if lik is not None or fs is None or es is None or \
+                        fs[0] != 'pairdist' or es[0] != 'gaussian_pairdist' or \
+                        f.variables != {variable_name} or \
+                        'precision' not in es[1].parameters:
+                    return None
+                lik = f
+                order.append('lik')
+            elif isinstance(f, IsotropicGaussian):
+                if prior is not None or f.native_hmc_spec(variable_name) is None:
+                    return None
+                prior = f
+                order.append('prior')
+            else:
+                return None
+        if lik is None:
+            return None
+        em = lik.error_model
+        return ('pairdist', em, em['precision'].value,
+                None if prior is None else (float(prior['k'].value), float(prior['x0'].value)),
+                order[0] == 'prior')

@@ -75,6 +75,7 @@ class HMCSampler(object):
         self.last_e_before = None
         self.last_e_after = None
         self.accepted_history = None      # [n x C] flags of the last sample_n()
+        self.fused_leapfrog = True        # use a PDF's fused leapfrog kernel if it has one
 
     # -- reference attributes ----------------------------------------------
     @property
@@ -262,12 +263,22 @@ class HMCSampler(object):
         p = p0 if own_p else p0.clone()
         e_before = V(q) + _native.row_sum(p, _native.ROW_SUMSQ, scale=0.5)
         # _leapfrog, reference hmc.py:116-123
-        _native.leapfrog_kick(p, grad(q), dt, dtc, half=True, mode=mode)
-        for _ in range(self.nsteps - 1):
+        leap = getattr(pdf, 'native_leapfrog_spec', None)
+        leap = leap(name) if (leap is not None and self.fused_leapfrog) else None
+        if leap is not None and leap[0] == 'pairdist' and q.shape[1] % 3 == 0 \
+                and q.shape[1] // 3 <= 1024:
+            # the whole integration in one launch (bit-identical to the loop)
+            _, em, precision, prior, prior_first = leap
+            _native.pairdist_leapfrog(q, p, em.ymat_device(q.device), precision,
+                                      prior, prior_first, dt, dtc, self.nsteps,
+                                      mode)
+        else:
+            _native.leapfrog_kick(p, grad(q), dt, dtc, half=True, mode=mode)
+            for _ in range(self.nsteps - 1):
+                _native.leapfrog_drift(q, p, dt, dtc, mode=mode)
+                _native.leapfrog_kick(p, grad(q), dt, dtc, mode=mode)
             _native.leapfrog_drift(q, p, dt, dtc, mode=mode)
-            _native.leapfrog_kick(p, grad(q), dt, dtc, mode=mode)
-        _native.leapfrog_drift(q, p, dt, dtc, mode=mode)
-        _native.leapfrog_kick(p, grad(q), dt, dtc, half=True, mode=mode)
+            _native.leapfrog_kick(p, grad(q), dt, dtc, half=True, mode=mode)
         e_after = V(q) + _native.row_sum(p, _native.ROW_SUMSQ, scale=0.5)
         _native.accept_select(q, q0, e_before, e_after, u, q, accepted,
                               self.n_accepted, dtc, adapt,

@@ -250,6 +250,20 @@ int32_t binf_pairdist_gauss_grad_f64(const double *x, const double *ymat,
                                      double *out, int64_t C, int64_t n_beads,
                                      void *stream);
 
+/* The whole leapfrog integration HMCSampler._leapfrog (binf/samplers/hmc.py:92-125)
+ * for the restraint posterior in one launch: q, p device [C * 3n], integrated in
+ * place over nsteps steps (half kick, (nsteps-1) x [drift, kick], drift, half
+ * kick).  Gradient = precision_c * restraint force (+ optional isotropic
+ * Gaussian prior term prior_k * (x - prior_x0), added before or after the
+ * likelihood term as prior_first says -- the Posterior's component order).
+ * Bit-identical to the per-step generic tier.  n_beads <= 1024. */
+int32_t binf_pairdist_leapfrog_f64(double *q, double *p, const double *ymat,
+                                   double precision, const double *precision_chain,
+                                   int32_t has_prior, double prior_k, double prior_x0,
+                                   int32_t prior_first, double timestep,
+                                   const double *dt_chain, int32_t nsteps, int64_t C,
+                                   int64_t n_beads, int32_t mode, void *stream);
+
 /* ------------------------------------------------------------------------
  * Device random draws (throughput mode): counter-based Philox4x32-10, key =
  * seed, element i of a call uses counter (i, offset).  Replace the

@@ -111,3 +111,42 @@ def test_c5_size_properties(device):
     for c in (0, 255):
         w = RD.gradient(x[c], ys, 2.0, n)
         assert np.abs(g[c].cpu().numpy() - w).max() <= 1e-10 * np.abs(w).max()
+
+
+@pytest.mark.parametrize('n,C,L,dt,with_prior', [(8, 12, 10, 0.02, True), (256, 5, 6, 0.002, True),
+                                                 (300, 3, 3, 0.002, False), (700, 2, 2, 0.001, True)])
+def test_fused_leapfrog_is_bit_identical_to_the_per_step_tier(device, n, C, L, dt, with_prior):
+    ys, x = synth(n, C, 5 * n)
+    rs = np.random.RandomState(n + 1)
+    p0 = rs.standard_normal((C, 3 * n))
+    u = rs.uniform(size=C)
+    taus = rs.uniform(1.0, 5.0, size=C)
+    outs = []
+    for fused in (True, False):
+        if with_prior:
+            post = make_post(ys, n)
+        else:
+            L_ = make_distance_likelihood(ys, n)
+            post = Posterior({L_.name: L_}, {})
+        cond = post.conditional_factory(precision=dev_t(taus, device))
+        spec = cond.native_leapfrog_spec('coordinates')
+        assert spec is not None and spec[0] == 'pairdist' and (spec[3] is not None) == with_prior
+        s = HMCSampler(cond, dev_t(x, device), dt, L, variable_name='coordinates')
+        s.fused_leapfrog = fused
+        out = s.sample(p0=dev_t(p0, device), u=dev_t(u, device))
+        outs.append((out.cpu().numpy(), s.last_move_accepted.cpu().numpy(),
+                     s.last_e_after.cpu().numpy()))
+    assert np.array_equal(outs[0][0], outs[1][0])
+    assert np.array_equal(outs[0][1], outs[1][1])
+    assert np.array_equal(outs[0][2], outs[1][2])
+
+
+def test_leapfrog_spec_rejects_unsupported_structures(device):
+    ys, x = synth(8, 2, 1)
+    # precision still free -> no fused leapfrog
+    assert make_post(ys, 8).native_leapfrog_spec('coordinates') is None
+    # a polynomial posterior has none either
+    from binf_amd.example.misc import make_posterior
+    from binf_amd.example.likelihood import POLYVAL
+    post = make_posterior(np.linspace(-1, 1, 5), np.zeros(5), POLYVAL)
+    assert post.conditional_factory(precision=1.0).native_leapfrog_spec('coefficients') is None
