@@ -53,6 +53,123 @@ __device__ inline double pair_weight(double d0, double d1, double d2, double y)
     return __builtin_fma(-y, r, 1.0);
 }
 
+// Restraint force on bead i summed by FOUR adjacent lanes: lane quarter qt adds
+// the pairs j in [qt*ceil(n/4), (qt+1)*ceil(n/4)) in ascending order, the four
+// partial sums are joined as (f0 + f1) + (f2 + f3) by xor-shuffles 1 and 2 (all
+// four lanes end up with the total).  With one lane per bead a 256-bead chain
+// is one wave per SIMD and the loop is latency-bound; four lanes per bead give
+// the scheduler four waves per SIMD.  sx: LDS copy of the chain's coordinates.
+// Must be called by all lanes of the wave (shuffles).
+__device__ inline void quartered_force(const double *sx, const double *ymat, int n, int i,
+                                       bool valid, int qt, double x0, double x1, double x2,
+                                       double &f0, double &f1, double &f2)
+{
+    const int per = (n + 3) >> 2;
+    const int jb = qt * per;
+    int je = jb + per;
+    if (je > n) je = n;
+    f0 = 0.0; f1 = 0.0; f2 = 0.0;
+    if (valid) {
+        for (int j = jb; j < je; ++j) {
+            if (j == i) continue;
+            const double d0 = x0 - sx[3 * j];
+            const double d1 = x1 - sx[3 * j + 1];
+            const double d2 = x2 - sx[3 * j + 2];
+            const double w = pair_weight(d0, d1, d2, ymat[(int64_t)j * n + i]);
+            f0 += w * d0;
+            f1 += w * d1;
+            f2 += w * d2;
+        }
+    }
+    f0 = f0 + __shfl_xor(f0, 1, 64); f0 = f0 + __shfl_xor(f0, 2, 64);
+    f1 = f1 + __shfl_xor(f1, 1, 64); f1 = f1 + __shfl_xor(f1, 2, 64);
+    f2 = f2 + __shfl_xor(f2, 1, 64); f2 = f2 + __shfl_xor(f2, 2, 64);
+}
+
+// The same sum by ONE lane: four quarter accumulators advanced in lock-step
+// (four independent chains of FMAs for the scheduler), joined in the same
+// order -- bit-identical to quartered_force, so which variant a launch uses is
+// a pure performance choice (many chains: one lane per bead; few: four).
+__device__ inline void quartered_force_1lane(const double *sx, const double *ymat, int n, int i,
+                                             double x0, double x1, double x2,
+                                             double &f0, double &f1, double &f2)
+{
+    const int per = (n + 3) >> 2;
+    double g[4][3];
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt) { g[qt][0] = 0.0; g[qt][1] = 0.0; g[qt][2] = 0.0; }
+    for (int jj = 0; jj < per; ++jj) {
+#pragma unroll
+        for (int qt = 0; qt < 4; ++qt) {
+            const int j = qt * per + jj;
+            if (j < n && j != i) {
+                const double d0 = x0 - sx[3 * j];
+                const double d1 = x1 - sx[3 * j + 1];
+                const double d2 = x2 - sx[3 * j + 2];
+                const double w = pair_weight(d0, d1, d2, ymat[(int64_t)j * n + i]);
+                g[qt][0] += w * d0;
+                g[qt][1] += w * d1;
+                g[qt][2] += w * d2;
+            }
+        }
+    }
+    f0 = (g[0][0] + g[1][0]) + (g[2][0] + g[3][0]);
+    f1 = (g[0][1] + g[1][1]) + (g[2][1] + g[3][1]);
+    f2 = (g[0][2] + g[1][2]) + (g[2][2] + g[3][2]);
+}
+
+// n_beads <= 1024, one lane per bead (256-thread workgroup per chain)
+__global__ void __launch_bounds__(256)
+pairdist_grad1_kernel(const double *x, const double *ymat, double tau,
+                      const double *tau_chain, double *out, int32_t n_beads)
+{
+    extern __shared__ double sx[];
+    const int n = n_beads;
+    const int64_t c = blockIdx.x;
+    const double *xc = x + c * 3 * (int64_t)n;
+    const double t = tau_chain ? tau_chain[c] : tau;
+    for (int k = threadIdx.x; k < 3 * n; k += 256) sx[k] = xc[k];
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += 256) {
+        double f0, f1, f2;
+        quartered_force_1lane(sx, ymat, n, i, sx[3 * i], sx[3 * i + 1], sx[3 * i + 2], f0, f1, f2);
+        double *o = out + c * 3 * (int64_t)n + 3 * i;
+        o[0] = t * f0;
+        o[1] = t * f1;
+        o[2] = t * f2;
+    }
+}
+
+// n_beads <= 1024: 1024-thread workgroup per chain, thread = (bead tile slot, quarter)
+__global__ void __launch_bounds__(1024)
+pairdist_grad4_kernel(const double *x, const double *ymat, double tau,
+                      const double *tau_chain, double *out, int32_t n_beads)
+{
+    extern __shared__ double sx[];
+    const int n = n_beads;
+    const int64_t c = blockIdx.x;
+    const double *xc = x + c * 3 * (int64_t)n;
+    const double t = tau_chain ? tau_chain[c] : tau;
+    for (int k = threadIdx.x; k < 3 * n; k += 1024) sx[k] = xc[k];
+    __syncthreads();
+    const int qt = threadIdx.x & 3;
+    for (int i0 = 0; i0 < n; i0 += 256) {
+        const int i = i0 + (threadIdx.x >> 2);
+        const bool iv = i < n;
+        const double x0 = iv ? sx[3 * i] : 0.0, x1 = iv ? sx[3 * i + 1] : 0.0,
+                     x2 = iv ? sx[3 * i + 2] : 0.0;
+        double f0, f1, f2;
+        quartered_force(sx, ymat, n, i, iv, qt, x0, x1, x2, f0, f1, f2);
+        if (iv && qt == 0) {
+            double *o = out + c * 3 * (int64_t)n + 3 * i;
+            o[0] = t * f0;
+            o[1] = t * f1;
+            o[2] = t * f2;
+        }
+    }
+}
+
+// n_beads > 1024: one lane per bead, coordinates staged tile by tile.
 // out[c, 3i + a] = tau_c * sum_{j != i} (d_ij - y[j][i]) * (x_i - x_j)[a] / d_ij
 // ymat: symmetric [n x n] target distances (diagonal ignored).
 template <int TILE>
@@ -103,10 +220,11 @@ pairdist_grad_kernel(const double *x, const double *ymat, double tau,
 
 // ---------------------------------------------------------------------------
 // Fused leapfrog for the restraint posterior: the whole _leapfrog() of
-// binf/samplers/hmc.py:92-125 in one launch, one workgroup per chain.  Thread
-// b owns beads b, b + 256, ... (position and momentum in registers); every
-// bead position is mirrored in LDS for the all-pairs force loop.  The force is
-// evaluated exactly like pairdist_grad_kernel (j ascending, j != i) and the
+// binf/samplers/hmc.py:92-125 in one launch, one 1024-thread workgroup per chain.
+// Four adjacent lanes share a bead (slot, slot + 256, ...; position and momentum
+// in registers, identical in the four lanes); every bead position is mirrored in
+// LDS for the all-pairs force loop.  The force is evaluated exactly like
+// pairdist_grad4_kernel (quartered_force) and the
 // gradient is assembled like the Posterior does (component terms in sorted-name
 // order), so the result is bit-identical to the per-step generic tier.
 // ---------------------------------------------------------------------------
@@ -126,8 +244,8 @@ struct PairLeapArgs {
     int32_t n_beads;
 };
 
-template <int NB, bool FMA>
-__global__ void __launch_bounds__(256) pairdist_leapfrog_kernel(const PairLeapArgs a)
+template <int NB, bool FMA, int LANES>
+__global__ void __launch_bounds__(256 * LANES) pairdist_leapfrog_kernel(const PairLeapArgs a)
 {
     extern __shared__ double sx[];               // [n_beads][3]
     const int n = a.n_beads;
@@ -137,11 +255,14 @@ __global__ void __launch_bounds__(256) pairdist_leapfrog_kernel(const PairLeapAr
     const double tau = a.tau_chain ? a.tau_chain[c] : a.tau;
     const double dt = a.dt_chain ? a.dt_chain[c] : a.timestep;
     const double hdt = 0.5 * dt;
+    const int qt = (LANES == 4) ? (threadIdx.x & 3) : 0;              // quarter of the j-range
+    const int slot = (LANES == 4) ? (threadIdx.x >> 2) : threadIdx.x;  // bead inside a tile of 256
 
+    // the four lanes of a bead hold identical copies of its position / momentum
     double q[NB][3], p[NB][3];
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
-        const int i = threadIdx.x + 256 * b;
+        const int i = slot + 256 * b;
 #pragma unroll
         for (int ax = 0; ax < 3; ++ax) {
             q[b][ax] = (i < n) ? qc[3 * i + ax] : 0.0;
@@ -152,8 +273,8 @@ __global__ void __launch_bounds__(256) pairdist_leapfrog_kernel(const PairLeapAr
         __syncthreads();
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
-            const int i = threadIdx.x + 256 * b;
-            if (i < n) {
+            const int i = slot + 256 * b;
+            if (i < n && qt == 0) {
                 sx[3 * i] = q[b][0];
                 sx[3 * i + 1] = q[b][1];
                 sx[3 * i + 2] = q[b][2];
@@ -165,20 +286,17 @@ __global__ void __launch_bounds__(256) pairdist_leapfrog_kernel(const PairLeapAr
     auto kick = [&](double step) {
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
-            const int i = threadIdx.x + 256 * b;
-            if (i >= n) continue;
-            double f0 = 0.0, f1 = 0.0, f2 = 0.0;
-            for (int j = 0; j < n; ++j) {
-                if (j == i) continue;
-                const double d0 = q[b][0] - sx[3 * j];
-                const double d1 = q[b][1] - sx[3 * j + 1];
-                const double d2 = q[b][2] - sx[3 * j + 2];
-                const double w = pair_weight(d0, d1, d2, a.ymat[(int64_t)j * n + i]);
-                f0 += w * d0;
-                f1 += w * d1;
-                f2 += w * d2;
+            const int i = slot + 256 * b;
+            double f[3];
+            if (LANES == 4) {
+                quartered_force(sx, a.ymat, n, i, i < n, qt, q[b][0], q[b][1], q[b][2],
+                                f[0], f[1], f[2]);
+            } else {
+                f[0] = f[1] = f[2] = 0.0;
+                if (i < n)
+                    quartered_force_1lane(sx, a.ymat, n, i, q[b][0], q[b][1], q[b][2],
+                                          f[0], f[1], f[2]);
             }
-            const double f[3] = {f0, f1, f2};
 #pragma unroll
             for (int ax = 0; ax < 3; ++ax) {
                 const double gl = tau * f[ax];
@@ -212,8 +330,8 @@ __global__ void __launch_bounds__(256) pairdist_leapfrog_kernel(const PairLeapAr
 
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
-        const int i = threadIdx.x + 256 * b;
-        if (i < n) {
+        const int i = slot + 256 * b;
+        if (i < n && qt == 0) {
 #pragma unroll
             for (int ax = 0; ax < 3; ++ax) {
                 qc[3 * i + ax] = q[b][ax];
@@ -226,6 +344,10 @@ __global__ void __launch_bounds__(256) pairdist_leapfrog_kernel(const PairLeapAr
 }  // namespace binf
 
 using namespace binf;
+
+// Few chains (less than ~4 workgroups of 256 threads per CU): four lanes per
+// bead; many chains: one.  Both sum in the same order (bit-identical results).
+static int lanes_per_bead(int64_t C) { return C < 1024 ? 4 : 1; }
 
 extern "C" int32_t binf_pairdist_forward_f64(const double *x, const int32_t *pair_i,
                                              const int32_t *pair_j, double *out,
@@ -258,8 +380,16 @@ extern "C" int32_t binf_pairdist_gauss_grad_f64(const double *x, const double *y
     if (!x || !ymat || !out) return fail(BINF_E_ARG, "pairdist_gauss_grad: null buffer");
     if (n_beads > 46340 || C > 0x7fffffffLL)
         return fail(BINF_E_UNSUPPORTED, "pairdist_gauss_grad: too large");
-    pairdist_grad_kernel<256><<<dim3((unsigned)C), 256, 0, (hipStream_t)stream>>>(
-        x, ymat, precision, precision_chain, out, (int32_t)n_beads);
+    const size_t lds = (size_t)n_beads * 3 * sizeof(double);
+    if (n_beads <= 1024 && lanes_per_bead(C) == 4)
+        pairdist_grad4_kernel<<<dim3((unsigned)C), 1024, lds, (hipStream_t)stream>>>(
+            x, ymat, precision, precision_chain, out, (int32_t)n_beads);
+    else if (n_beads <= 1024)
+        pairdist_grad1_kernel<<<dim3((unsigned)C), 256, lds, (hipStream_t)stream>>>(
+            x, ymat, precision, precision_chain, out, (int32_t)n_beads);
+    else
+        pairdist_grad_kernel<256><<<dim3((unsigned)C), 256, 0, (hipStream_t)stream>>>(
+            x, ymat, precision, precision_chain, out, (int32_t)n_beads);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "pairdist_gauss_grad launch");
     return 0;
@@ -291,10 +421,16 @@ extern "C" int32_t binf_pairdist_leapfrog_f64(double *q, double *p, const double
     hipStream_t st = (hipStream_t)stream;
     const bool fma = mode == BINF_MODE_FMA;
     const int nb = (int)((n_beads + 255) / 256);
-#define LAUNCH(NBV)                                                                   \
-    do {                                                                              \
-        if (fma) pairdist_leapfrog_kernel<NBV, true><<<grid, 256, lds, st>>>(a);      \
-        else     pairdist_leapfrog_kernel<NBV, false><<<grid, 256, lds, st>>>(a);     \
+    const bool four = lanes_per_bead(C) == 4;
+#define LAUNCH(NBV)                                                                         \
+    do {                                                                                    \
+        if (four) {                                                                         \
+            if (fma) pairdist_leapfrog_kernel<NBV, true, 4><<<grid, 1024, lds, st>>>(a);    \
+            else     pairdist_leapfrog_kernel<NBV, false, 4><<<grid, 1024, lds, st>>>(a);   \
+        } else {                                                                            \
+            if (fma) pairdist_leapfrog_kernel<NBV, true, 1><<<grid, 256, lds, st>>>(a);     \
+            else     pairdist_leapfrog_kernel<NBV, false, 1><<<grid, 256, lds, st>>>(a);    \
+        }                                                                                   \
     } while (0)
     if (nb <= 1) LAUNCH(1);
     else if (nb == 2) LAUNCH(2);

@@ -150,3 +150,21 @@ def test_leapfrog_spec_rejects_unsupported_structures(device):
     from binf_amd.example.likelihood import POLYVAL
     post = make_posterior(np.linspace(-1, 1, 5), np.zeros(5), POLYVAL)
     assert post.conditional_factory(precision=1.0).native_leapfrog_spec('coefficients') is None
+
+
+def test_force_is_independent_of_the_batch_size(device):
+    """Few chains use four lanes per bead, many chains one; both sum in the
+    same order, so a chain's force and trajectory do not depend on how many
+    other chains share the launch."""
+    n = 64
+    ys, x = synth(n, 1100, 7)
+    L_ = make_distance_likelihood(ys, n)
+    big = L_.gradient(coordinates=dev_t(x, device), precision=2.0).cpu().numpy()       # 1 lane / bead
+    small = L_.gradient(coordinates=dev_t(x[:40], device), precision=2.0).cpu().numpy()  # 4 lanes / bead
+    assert np.array_equal(big[:40], small)
+    q1, p1 = dev_t(x, device), dev_t(x[::-1].copy(), device)
+    q2, p2 = q1[:40].clone(), p1[:40].clone()
+    em = L_.error_model
+    _native.pairdist_leapfrog(q1, p1, em.ymat_device(device), 2.0, (0.05, 0.0), True, 0.002, None, 4)
+    _native.pairdist_leapfrog(q2, p2, em.ymat_device(device), 2.0, (0.05, 0.0), True, 0.002, None, 4)
+    assert torch.equal(q1[:40], q2) and torch.equal(p1[:40], p2)
