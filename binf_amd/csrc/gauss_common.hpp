@@ -73,6 +73,42 @@ __device__ inline double chain_sum_finish(const LaneSum &s, int T, int rem,
     return 0.0 + res;   // np.add.reduce starts from the identity +0.0
 }
 
+// A double constant held in an SGPR pair at the point of use.  The volatile
+// asm keeps LLVM from hoisting it out of the transition loop into a VGPR pair
+// (the hoisted exp() constants alone cost the persistent kernel 20 VGPRs and
+// with them the fourth wave per SIMD).
+__device__ inline double sgpr_const(unsigned long long bits)
+{
+    double c = __longlong_as_double((long long)bits);
+    asm volatile("" : "+s"(c));
+    return c;
+}
+
+// exp(x) for x in [-308, 709] (the clipped exponent of the accept test,
+// hmc.py:151 + csb.numeric.exp).  Same algorithm and coefficients as the
+// device math library's exp (argument reduction by ln2 in two parts, degree-11
+// polynomial, ldexp), so the accept decisions are those of the library call it
+// replaces; written out so that its constants stay in SGPRs.
+__device__ inline double exp_clipped_range(double x)
+{
+    const double n = __builtin_rint(x * sgpr_const(0x3ff71547652b82feULL));     // 1/ln2
+    double r = __builtin_fma(sgpr_const(0xbfe62e42fefa39efULL), n, x);          // -ln2 (hi)
+    r = __builtin_fma(sgpr_const(0xbc7abc9e3b39803fULL), n, r);                 // -ln2 (lo)
+    double p = __builtin_fma(sgpr_const(0x3e5ade156a5dcb37ULL), r,
+                             sgpr_const(0x3e928af3fca7ab0cULL));
+    p = __builtin_fma(r, p, sgpr_const(0x3ec71dee623fde64ULL));
+    p = __builtin_fma(r, p, sgpr_const(0x3efa01997c89e6b0ULL));
+    p = __builtin_fma(r, p, sgpr_const(0x3f2a01a014761f6eULL));
+    p = __builtin_fma(r, p, sgpr_const(0x3f56c16c1852b7b0ULL));
+    p = __builtin_fma(r, p, sgpr_const(0x3f81111111122322ULL));
+    p = __builtin_fma(r, p, sgpr_const(0x3fa55555555502a1ULL));
+    p = __builtin_fma(r, p, sgpr_const(0x3fc5555555555511ULL));
+    p = __builtin_fma(r, p, sgpr_const(0x3fe000000000000bULL));
+    p = __builtin_fma(r, p, 1.0);
+    p = __builtin_fma(r, p, 1.0);
+    return __builtin_ldexp(p, (int)n);
+}
+
 template <bool UNIT>
 __device__ inline double gauss_grad(double q, double k, double x0)
 {

@@ -206,6 +206,10 @@ hmc_gauss_persist_kernel(const GaussNArgs a)
                 lane_sum_add<REGULAR>(sqa, d * d, t, T);
                 lane_sum_add<REGULAR>(spa, cur[i] * cur[i], t, T);
             }
+            // ... and pin the running sums here: otherwise the group's last
+            // half kick and its squares are sunk below the NEXT group's step
+            // loop and its momenta stay live through it
+            asm volatile("" : "+v"(sqa.r), "+v"(spa.r), "+v"(spb.r));
             __builtin_amdgcn_sched_barrier(0);
         }
         if (NG & 1) {
@@ -222,7 +226,7 @@ hmc_gauss_persist_kernel(const GaussNArgs a)
         double x = -(Ea - Eb);                                // hmc.py:151
         x = (x < -308.0) ? -308.0 : x;
         x = (x > 709.0) ? 709.0 : x;
-        const bool acc = uu < exp(x);
+        const bool acc = uu < exp_clipped_range(x);
 
         const double dt_used = dt;
         if (s < a.n_adapt)                                    // hmc.py:188-191
