@@ -3,8 +3,10 @@
 Headline benchmark: chain*leapfrog-steps per second on BASELINE config C2
 (1024-d isotropic Gaussian, 4096 chains per GPU, 20 leapfrog steps, fp64).
 
-A "step" is one HMCSampler.sample() over the whole chain batch = ONE launch of
-the fused HIP trajectory kernel through the C ABI.  Inputs (state, a pool of
+A "step" is one HMC transition (one HMCSampler.sample() worth of work) over the
+whole chain batch; by default 64 of them are issued per launch of the fused HIP
+trajectory kernel (HMCSampler.sample_n, --fuse), every state still recorded,
+through the C ABI.  Inputs (state, a pool of
 pre-generated momentum / uniform draws) are resident in HBM before the timed
 region.  Multi-GPU: chains are sharded (weak scaling, 4096 chains per GPU), no
 collective in the data path; the sample gather is timed separately.
@@ -16,6 +18,7 @@ collective in the data path; the sample gather is timed separately.
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import glob
 import json
 import os
 import sys
@@ -54,6 +57,8 @@ def parse():
     ap.add_argument('--thin', type=int, default=1,
                     help='with --fuse > 1: record every thin-th state')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-other-mode', action='store_true',
+                    help='skip the short extra measurement in the other arithmetic mode')
     ap.add_argument('--cpu-chains', type=int, default=64)
     ap.add_argument('--cpu-calls', type=int, default=2000,
                     help='sample() rounds of the CPU baseline (~10 s on the GPU box)')
@@ -154,9 +159,8 @@ def main():
 
     F = max(1, args.fuse)
     if F > 1:
-        # one step is still ONE transition; they are issued F per launch
-        K = ((K + F - 1) // F) * F
-        W = ((W + F - 1) // F) * F
+        # one step is still ONE transition; they are issued F per launch (a
+        # step count that is not a multiple of F ends with one shorter launch)
         nchunk = max(2, P // F)
         p_chunks = [torch.randn((F, C, D), dtype=torch.float64, device=dev,
                                 generator=gen) for _ in range(nchunk)]
@@ -164,12 +168,16 @@ def main():
                                generator=gen) for _ in range(nchunk)]
         del p_pool, u_pool
 
-        def run(nsteps):
-            for i in range(nsteps // F):
-                sampler.sample_n(F, thin=args.thin, p0=p_chunks[i % nchunk],
-                                 u=u_chunks[i % nchunk], record=True)
+        def run(nsteps, sampler=sampler):
+            i = 0
+            while nsteps > 0:
+                n = min(F, nsteps)
+                sampler.sample_n(n, thin=min(args.thin, n), p0=p_chunks[i % nchunk][:n],
+                                 u=u_chunks[i % nchunk][:n], record=True)
+                nsteps -= n
+                i += 1
     else:
-        def run(nsteps):
+        def run(nsteps, sampler=sampler):
             for i in range(nsteps):
                 sampler.sample(p0=p_pool[i % P], u=u_pool[i % P])
 
@@ -187,6 +195,26 @@ def main():
 
     acc_rate = float(sampler.acceptance_rate.mean())
     gather_ms = None
+
+    # Outside the metric: the same workload in the other arithmetic mode ('fma'
+    # contracts each multiply-add; within 1e-10 of 'exact', not bit-identical).
+    other = None
+    if world == 1 and not args.no_other_mode:
+        om = 'fma' if args.mode == 'exact' else 'exact'
+        s2 = HMCSampler(IsotropicGaussian(1.0, 0.0), q0, dt, L, variable_name='x', mode=om)
+        K2 = min(K, 4 * F)
+        run(min(W, F), s2)
+        torch.cuda.synchronize()
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        run(K2, s2)
+        e1.record()
+        torch.cuda.synchronize()
+        t2 = e0.elapsed_time(e1) * 1e-3 / K2
+        other = {'mode': om, 'value': C * L / t2, 'avg_transition_us': t2 * 1e6,
+                 'roofline_frac': (24.0 * D + 25.0) * C / t2 / 1e9 / HBM_PEAK_GBS,
+                 'steps': K2, 'note': 'device time (HIP events), not the headline value'}
     if dist is not None:
         tmax = torch.tensor([elapsed], dtype=torch.float64,
                             device=dev if backend == 'nccl' else 'cpu')
@@ -206,24 +234,29 @@ def main():
     if rank == 0:
         steps_total = float(world) * C * L * K
         value = steps_total / elapsed
-        bytes_per_launch = (24.0 * D + 25.0) * C
-        n_launches = K // F
+        bytes_per_transition = (24.0 * D + 25.0) * C
+        n_launches = (K + F - 1) // F
         launch_s = dev_ms * 1e-3 / n_launches             # per kernel launch
         trans_s = dev_ms * 1e-3 / K                       # per transition
-        bytes_per_launch = bytes_per_launch * F           # F transitions per launch
-        achieved = bytes_per_launch / launch_s / 1e9
+        bytes_per_launch = bytes_per_transition * min(F, K)   # a full launch
+        # algorithmic bytes of the timed region / device time of the timed
+        # region (= bytes per launch / average launch duration)
+        achieved = bytes_per_transition * K / (dev_ms * 1e-3) / 1e9
         # HBM traffic from the committed PMC summary of this exact configuration
         traffic, traffic_src = None, None
-        try:
-            pm = json.load(open(os.path.join(ROOT, 'profiles', 'r01_d_pmc_traffic.json')))
-            c = pm['config']
-            if (c['chains'], c['dims'], c['nsteps'], c['fuse'], c['thin'], c['mode']) == \
-                    (C, D, L, F, args.thin if F > 1 else 1, args.mode):
-                traffic = pm['hbm_bytes_per_transition'] * F
-                traffic_src = 'profiles/r01_d_pmc_traffic.json (rocprofv3 --pmc ' \
-                              'FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2)'
-        except (OSError, ValueError, KeyError):
-            pass
+        for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_traffic.json')),
+                           reverse=True):
+            try:
+                pm = json.load(open(path))
+                c = pm['config']
+                if (c['chains'], c['dims'], c['nsteps'], c['fuse'], c['thin'], c['mode']) == \
+                        (C, D, L, F, args.thin if F > 1 else 1, args.mode):
+                    traffic = pm['hbm_bytes_per_transition'] * min(F, K)
+                    traffic_src = 'profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, ' \
+                                  'separate passes, FETCH x2)' % os.path.basename(path)
+                    break
+            except (OSError, ValueError, KeyError):
+                continue
         res = {
             'metric': 'chain*leapfrog-steps/sec, 1024-d Gaussian',
             'value': value,
@@ -252,8 +285,7 @@ def main():
                          'traffic': traffic, 'traffic_source': traffic_src,
                          'per': 'kernel launch = %d transition(s), each one '
                                 'HMCSampler.sample() worth of work' % F,
-                         'kernel': 'hmc_gauss_wave_kernel' if F == 1
-                         else 'hmc_gauss_persist_kernel',
+                         'kernel': 'hmc_gauss_persist_kernel',
                          'transitions_per_launch': F,
                          'states_recorded': 'every transition' if F == 1
                          else 'every %d. transition' % args.thin,
@@ -263,6 +295,8 @@ def main():
         }
         if gather_ms is not None:
             res['sample_gather_ms'] = gather_ms
+        if other is not None:
+            res['other_mode'] = other
         if world == 1 and not args.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline(D, L, dt, args.cpu_chains,
                                                args.cpu_calls)

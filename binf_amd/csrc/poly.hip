@@ -196,36 +196,43 @@ __global__ void __launch_bounds__(256) poly_grad_mfma_kernel(const GradArgs a)
     const int ntiles = (N + 15) / 16;
     if (t1 > ntiles) t1 = ntiles;
 
-    // staging: thread (srow, scol) moves A[16*pass + srow][n0 + scol]
+    // staging: thread (srow, scol) moves A[16*pass + srow][n0 + scol].  The
+    // loads are UNCONDITIONAL (indices clamped, invalid entries zeroed when
+    // they are written to LDS): a load under a per-lane branch makes the
+    // compiler wait for it at the join, i.e. before the tile's first MFMA,
+    // and the prefetch would hide nothing.
     const int srow = tid >> 4, scol = tid & 15;
     double pre[PASSES];
     double prey = 0.0;
     auto fetch = [&](int t) {
         const int n = t * 16 + scol;
+        const int nc = n < N ? n : N - 1;
 #pragma unroll
         for (int ps = 0; ps < PASSES; ++ps) {
             const int k = 16 * ps + srow;
-            pre[ps] = (k < K && n < N) ? a.A[(int64_t)k * N + n] : 0.0;
+            pre[ps] = a.A[(int64_t)(k < K ? k : K - 1) * N + nc];
         }
-        if (tid < 16) prey = (t * 16 + tid < N) ? a.ys[t * 16 + tid] : 0.0;
+        prey = a.ys[nc];
     };
-    auto stash = [&](int buf) {
+    auto stash = [&](int buf, int t) {
+        const bool nv = t * 16 + scol < N;
 #pragma unroll
         for (int ps = 0; ps < PASSES; ++ps) {
             const int k = 16 * ps + srow;
-            if (k < ROWS) sA[buf][k][scol] = pre[ps];
+            if (k < ROWS) sA[buf][k][scol] = (k < K && nv) ? pre[ps] : 0.0;
         }
-        if (tid < 16) sY[buf][tid] = prey;
+        if (tid < 16) sY[buf][tid] = nv ? prey : 0.0;
     };
 
     if (t0 < t1) {
         fetch(t0);
-        stash(0);
+        stash(0, t0);
     }
     __syncthreads();
     for (int t = t0; t < t1; ++t) {
         const int buf = (t - t0) & 1;
-        if (t + 1 < t1) fetch(t + 1);          // in flight during the MFMAs
+        fetch(t + 1 < t1 ? t + 1 : t);         // in flight during the MFMAs
+        __builtin_amdgcn_sched_barrier(0);     // ... so keep the loads up here
         // forward: M^T[n][c] = sum_k A[k][n] theta[c][k]
         v4d acc[CT];
 #pragma unroll
@@ -278,7 +285,7 @@ __global__ void __launch_bounds__(256) poly_grad_mfma_kernel(const GradArgs a)
                 for (int c = 0; c < CT; ++c)
                     gv[c][v] = __builtin_fma(av, rr[c][r], gv[c][v]);
             }
-        if (t + 1 < t1) stash(buf ^ 1);
+        if (t + 1 < t1) stash(buf ^ 1, t + 1);
         __syncthreads();
     }
 #pragma unroll
@@ -335,7 +342,11 @@ static int grad_splits(int64_t C, int64_t N)
     // aim at ~4 workgroups per CU; never more splits than data tiles
     const int64_t wgx = (C + 64 * grad_ct(C) - 1) / (64 * grad_ct(C));
     const int64_t ntiles = (N + 15) / 16;
-    const int64_t target = 1024;             // measured best on MI355X (512..4096 tried)
+    static int64_t target = 0;
+    if (target == 0) {
+        const char *e = getenv("BINF_POLY_GRAD_WGS");     // development aid
+        target = e ? atoll(e) : 1024;            // measured best on MI355X (512..4096 tried)
+    }
     int64_t ns = (target + wgx - 1) / wgx;
     if (ns > 64) ns = 64;
     if (ns > ntiles) ns = ntiles;
