@@ -251,34 +251,53 @@ class HMCSampler(object):
         return q_out
 
     # -- generic tier --------------------------------------------------------
+    def _leapfrog(self, q, p, timestep, nsteps):
+        """Velocity-Verlet integration, IN PLACE on ``q`` and ``p`` (reference
+        ``hmc.py:92-125``: half kick, ``nsteps - 1`` x [drift, kick], drift,
+        half kick; ``nsteps + 1`` gradient calls).  ``timestep`` is a float or
+        a ``[C]`` tensor of per-chain step sizes.  Returns ``(q, p)``."""
+        name = self._variable_name
+        pdf = self.pdf
+        mode = _MODES[self.mode]
+        shape = q.shape
+        q2, p2 = _as2d(q), _as2d(p)
+        if not (q2.is_contiguous() and p2.is_contiguous()):
+            raise ValueError('_leapfrog integrates in place: q and p must be contiguous')
+        if isinstance(timestep, torch.Tensor):
+            dt, dtc = 0.0, timestep.reshape(-1).contiguous()
+        else:
+            dt, dtc = float(timestep), None
+        grad = lambda x: _as2d(pdf.gradient(**{name: x.view(shape)})).contiguous()
+
+        leap = getattr(pdf, 'native_leapfrog_spec', None)
+        leap = leap(name) if (leap is not None and self.fused_leapfrog) else None
+        if leap is not None and leap[0] == 'pairdist' and q2.shape[1] % 3 == 0 \
+                and q2.shape[1] // 3 <= 1024:
+            # the whole integration in one launch (bit-identical to the loop)
+            _, em, precision, prior, prior_first = leap
+            _native.pairdist_leapfrog(q2, p2, em.ymat_device(q2.device), precision,
+                                      prior, prior_first, dt, dtc, nsteps, mode)
+            return q, p
+        _native.leapfrog_kick(p2, grad(q2), dt, dtc, half=True, mode=mode)
+        for _ in range(nsteps - 1):
+            _native.leapfrog_drift(q2, p2, dt, dtc, mode=mode)
+            _native.leapfrog_kick(p2, grad(q2), dt, dtc, mode=mode)
+        _native.leapfrog_drift(q2, p2, dt, dtc, mode=mode)
+        _native.leapfrog_kick(p2, grad(q2), dt, dtc, half=True, mode=mode)
+        return q, p
+
     def _sample_generic(self, name, state, q0, p0, own_p, u, accepted, adapt):
         pdf = self.pdf
         mode = _MODES[self.mode]
         shape = state.shape
-        dt, dtc = self._timestep, self._dt_chain
+        dtc = self._dt_chain
         V = lambda x: -_as_chain_vector(pdf.log_prob(**{name: x.view(shape)})).contiguous()
-        grad = lambda x: _as2d(pdf.gradient(**{name: x.view(shape)})).contiguous()
 
         q = q0.clone()
         p = p0 if own_p else p0.clone()
         e_before = V(q) + _native.row_sum(p, _native.ROW_SUMSQ, scale=0.5)
-        # _leapfrog, reference hmc.py:116-123
-        leap = getattr(pdf, 'native_leapfrog_spec', None)
-        leap = leap(name) if (leap is not None and self.fused_leapfrog) else None
-        if leap is not None and leap[0] == 'pairdist' and q.shape[1] % 3 == 0 \
-                and q.shape[1] // 3 <= 1024:
-            # the whole integration in one launch (bit-identical to the loop)
-            _, em, precision, prior, prior_first = leap
-            _native.pairdist_leapfrog(q, p, em.ymat_device(q.device), precision,
-                                      prior, prior_first, dt, dtc, self.nsteps,
-                                      mode)
-        else:
-            _native.leapfrog_kick(p, grad(q), dt, dtc, half=True, mode=mode)
-            for _ in range(self.nsteps - 1):
-                _native.leapfrog_drift(q, p, dt, dtc, mode=mode)
-                _native.leapfrog_kick(p, grad(q), dt, dtc, mode=mode)
-            _native.leapfrog_drift(q, p, dt, dtc, mode=mode)
-            _native.leapfrog_kick(p, grad(q), dt, dtc, half=True, mode=mode)
+        self._leapfrog(q.view(shape), p.view(shape),
+                       self._timestep if dtc is None else dtc, self.nsteps)
         e_after = V(q) + _native.row_sum(p, _native.ROW_SUMSQ, scale=0.5)
         _native.accept_select(q, q0, e_before, e_after, u, q, accepted,
                               self.n_accepted, dtc, adapt,

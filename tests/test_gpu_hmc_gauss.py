@@ -346,6 +346,39 @@ def test_generic_tier_bitwise_vs_oracle(device, D, C, L, k, x0, dt):
         assert np.array_equal(s.last_e_after.cpu().numpy(), want['e_after'])
 
 
+def test_leapfrog_method_has_the_reference_signature(device):
+    """HMCSampler._leapfrog(q, p, timestep, nsteps) integrates in place and
+    returns (q, p) like hmc.py:92-125 -- one chain as a [D] array, or a batch
+    with a per-chain step size; sample() goes through it, so a subclass that
+    overrides it changes the sampler."""
+    rs = np.random.RandomState(5)
+    D, L, dt = 37, 7, 0.11
+    q0, p0 = rs.standard_normal(D), rs.standard_normal(D)
+    ref = R.RefHMCSampler(R.GaussianPDF(2.5, 0.3), q0.copy(), dt, L, variable_name='x')
+    qw, pw = ref._leapfrog(q0.copy(), p0.copy(), dt, L)
+    s = HMCSampler(TorchGaussian(2.5, 0.3), dev_t(q0, device), dt, L, variable_name='x')
+    q, p = dev_t(q0, device), dev_t(p0, device)
+    rq, rp = s._leapfrog(q, p, dt, L)
+    assert rq is q and rp is p
+    assert np.array_equal(q.cpu().numpy(), qw) and np.array_equal(p.cpu().numpy(), pw)
+
+    C = 5
+    Q, P = rs.standard_normal((C, D)), rs.standard_normal((C, D))
+    dts = np.linspace(0.05, 0.2, C)
+    q, p = dev_t(Q, device), dev_t(P, device)
+    s._leapfrog(q, p, dev_t(dts, device), L)
+    for c in range(C):
+        qw, pw = ref._leapfrog(Q[c].copy(), P[c].copy(), dts[c], L)
+        assert np.array_equal(q[c].cpu().numpy(), qw) and np.array_equal(p[c].cpu().numpy(), pw)
+
+    class Frozen(HMCSampler):
+        def _leapfrog(self, q, p, timestep, nsteps):
+            return q, p
+    f = Frozen(TorchGaussian(1.0, 0.0), dev_t(Q, device), dt, L, variable_name='x')
+    out = f.sample()
+    assert torch.equal(out, dev_t(Q, device)) and bool(f.last_move_accepted.all())
+
+
 # --------------------------------------------------------------------------
 # the sampler class (reference surface)
 # --------------------------------------------------------------------------
