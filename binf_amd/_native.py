@@ -43,6 +43,10 @@ SIGNATURES = {
                                            _vp, _vp, _f64, _vp, _i64, _i64,
                                            _i32, _i32, _i32, _f64, _f64, _i32,
                                            _f64, _f64, _i32, _vp]),
+    'binf_hmc_sample_poly_f64': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                        _vp, _vp, _f64, _vp, _vp, _vp, _i32,
+                                        _vp, _vp, _f64, _vp, _i64, _i64, _i64,
+                                        _i32, _i32, _f64, _f64, _i32, _vp]),
     'binf_row_sum_f64': (_i32, [_vp, _vp, _i64, _i64, _i32, _f64, _f64, _vp]),
     'binf_leapfrog_kick_f64': (_i32, [_vp, _vp, _f64, _vp, _i32, _i64, _i64,
                                       _i32, _vp]),
@@ -341,6 +345,33 @@ def poly_gauss_logp(coeffs, xs, ys, precision):
         stream_handle(coeffs.device))
     check(rc, 'binf_poly_gauss_logp_f64')
     return out
+
+
+def hmc_sample_poly(q0, p0, u, q_out, accepted, n_accepted, e_before, e_after,
+                    xs, ys, precision, prior_means, prior_vars, prior_first,
+                    lp_pre, lp_post, timestep, dt_chain, nsteps, adapt, uprate,
+                    downrate, mode=MODE_EXACT):
+    """binf_hmc_sample_poly_f64 on torch's current stream (K <= 16
+    coefficients, <= 128 data points)."""
+    C, K = _cd(q0)
+    N = xs.numel()
+    tau, tau_chain = _precision_args(precision, C, q0.device)
+    rc = lib().binf_hmc_sample_poly_f64(
+        dptr(q0, numel=C * K, name='q0'), dptr(p0, numel=C * K, name='p0'),
+        dptr(u, numel=C, name='u'), dptr(q_out, numel=C * K, name='q_out'),
+        dptr(accepted, torch.uint8, C, 'accepted'),
+        dptr(n_accepted, torch.int64, C, 'n_accepted'),
+        dptr(e_before, numel=C, name='e_before'),
+        dptr(e_after, numel=C, name='e_after'),
+        dptr(xs, numel=N, name='xs'), dptr(ys, numel=N, name='ys'), tau,
+        dptr(tau_chain, numel=C, name='precision'),
+        dptr(prior_means, numel=K, name='prior_means'),
+        dptr(prior_vars, numel=K, name='prior_vars'), int(bool(prior_first)),
+        dptr(lp_pre, numel=C, name='lp_pre'), dptr(lp_post, numel=C, name='lp_post'),
+        float(timestep), dptr(dt_chain, numel=C, name='dt_chain'), C, K, N,
+        int(nsteps), int(bool(adapt)), float(uprate), float(downrate),
+        int(mode), stream_handle(q0.device))
+    check(rc, 'binf_hmc_sample_poly_f64')
 
 
 _grad_ws = {}

@@ -50,7 +50,49 @@ def gradient(likelihood, pair, fwm_vars, em_vars):
     return out if coeffs.dim() == 2 else out.reshape(-1)
 
 
+FUSED_MAX_COEFFS = 16       # binf_hmc_sample_poly_f64 limits (include/binf_hip.h)
+FUSED_MAX_DATA = 128
+
+
 def posterior_hmc_spec(posterior, variable_name):
-    """No fused trajectory kernel for the polynomial posterior yet: HMC runs
-    on the generic tier around the fused log-prob / gradient kernels."""
-    return None
+    """Descriptor of the fused small-data trajectory kernel
+    (``binf_hmc_sample_poly_f64``) if ``posterior`` is one it integrates:
+    a conditional posterior whose only free variable is ``coefficients``, made
+    of ONE polynomial + Gaussian-error likelihood with the precision fixed, at
+    most one :class:`GaussianPrior` on the coefficients, and components without
+    free variables (constants of the energy) before and / or one after them in
+    the posterior's summation order.  Otherwise None (per-step tier).
+
+    ``('poly', forward_model, error_model, precision, prior or None,
+    prior_first, [constants before], constant after or None)``"""
+    from binf_amd.example.priors import GaussianPrior
+    from binf_amd.pdf.likelihoods import Likelihood
+    if variable_name != 'coefficients':
+        return None
+    lik = prior = None
+    kinds, consts = [], []
+    for f in posterior._ordered_components():
+        if len(f.variables) == 0:
+            kinds.append('c')
+            consts.append(f)
+        elif set(f.variables) == {variable_name} and isinstance(f, Likelihood) \
+                and lik is None and f._native_pair() is not None \
+                and 'precision' in f.error_model.parameters:
+            lik = f
+            kinds.append('lik')
+        elif set(f.variables) == {variable_name} and isinstance(f, GaussianPrior) \
+                and prior is None:
+            prior = f
+            kinds.append('prior')
+        else:
+            return None
+    if lik is None or len(lik.error_model.ys) > FUSED_MAX_DATA:
+        return None
+    theta = [i for i, k in enumerate(kinds) if k != 'c']
+    n_pre, n_post = theta[0], len(kinds) - 1 - theta[-1]
+    if theta[-1] - theta[0] + 1 != len(theta) or n_post > 1:
+        return None                  # a constant between the two, or two after
+    return ('poly', lik.forward_model, lik.error_model,
+            lik.error_model['precision'].value, prior,
+            prior is not None and kinds.index('prior') < kinds.index('lik'),
+            consts[:n_pre], consts[n_pre] if n_post else None)

@@ -76,6 +76,7 @@ class HMCSampler(object):
         self.last_e_after = None
         self.accepted_history = None      # [n x C] flags of the last sample_n()
         self.fused_leapfrog = True        # use a PDF's fused leapfrog kernel if it has one
+        self.fused_polynomial = True      # ... and the fused small-data polynomial transition
 
     # -- reference attributes ----------------------------------------------
     @property
@@ -143,7 +144,9 @@ class HMCSampler(object):
 
         accepted = torch.empty(C, dtype=torch.uint8, device=dev)
         spec = self._fused_spec(name, D)
-        if spec is not None:
+        if spec is not None and spec[0] == 'poly':
+            q_out = self._sample_fused_poly(spec, q0, p0, u, accepted, adapt)
+        elif spec is not None:
             q_out = self._sample_fused_gauss(spec, q0, p0, u, accepted, adapt)
         else:
             q_out = self._sample_generic(name, state, q0, p0, own_p, u,
@@ -186,7 +189,7 @@ class HMCSampler(object):
         u = u.reshape(n, C)
         spec = self._fused_spec(name, D)
         nrec = n // thin
-        if spec is None:
+        if spec is None or spec[0] != 'gauss':
             out = []
             for i in range(n):
                 x = self.sample(p0=p0[i], u=u[i])
@@ -232,6 +235,9 @@ class HMCSampler(object):
         spec = get_spec(name) if get_spec is not None else None
         if spec is not None and spec[0] == 'gauss' and _gauss_kernel_covers(D):
             return spec
+        if spec is not None and spec[0] == 'poly' and self.fused_polynomial and \
+                D <= _native_poly_limits()[0]:
+            return spec
         return None
 
     def _sample_fused_gauss(self, spec, q0, p0, u, accepted, adapt):
@@ -247,6 +253,37 @@ class HMCSampler(object):
                                  self.nsteps, k, x0, adapt,
                                  self.adaption_uprate, self.adaption_downrate,
                                  _MODES[self.mode])
+        self.last_e_before, self.last_e_after = eb, ea
+        return q_out
+
+    def _sample_fused_poly(self, spec, q0, p0, u, accepted, adapt):
+        """The example's polynomial posterior with a small data set: the whole
+        transition in one launch (``csrc/hmc_poly.hip``)."""
+        _, fwm, em, precision, prior, prior_first, pre, post = spec
+        C, K = q0.shape
+        dev = q0.device
+
+        def const_term(f):
+            v = f.log_prob()
+            if not isinstance(v, torch.Tensor):
+                return torch.full((C,), float(v), dtype=torch.float64, device=dev)
+            return v.to(device=dev, dtype=torch.float64).reshape(-1).expand(C).contiguous()
+        lp_pre = None
+        for f in pre:                      # numpy.sum of a short list: left to right
+            t = const_term(f)
+            lp_pre = t if lp_pre is None else lp_pre + t
+        lp_post = const_term(post) if post is not None else None
+        means = prior._vec('means', dev) if prior is not None else None
+        variances = prior._vec('variances', dev) if prior is not None else None
+        q_out = torch.empty_like(q0)
+        eb = torch.empty(C, dtype=torch.float64, device=dev)
+        ea = torch.empty(C, dtype=torch.float64, device=dev)
+        _native.hmc_sample_poly(q0, p0, u, q_out, accepted, self.n_accepted, eb, ea,
+                                fwm.xs_device(dev), em.ys_device(dev), precision,
+                                means, variances, prior_first, lp_pre, lp_post,
+                                self._timestep, self._dt_chain, self.nsteps, adapt,
+                                self.adaption_uprate, self.adaption_downrate,
+                                _MODES[self.mode])
         self.last_e_before, self.last_e_after = eb, ea
         return q_out
 
@@ -304,6 +341,11 @@ class HMCSampler(object):
                               self.adaption_uprate, self.adaption_downrate)
         self.last_e_before, self.last_e_after = e_before, e_after
         return q
+
+
+def _native_poly_limits():
+    from binf_amd.example import native_poly
+    return native_poly.FUSED_MAX_COEFFS, native_poly.FUSED_MAX_DATA
 
 
 def _gauss_kernel_covers(D):

@@ -220,6 +220,38 @@ int32_t binf_poly_gauss_grad_f64(const double *coeffs, const double *design,
                                  void *workspace, int64_t workspace_bytes,
                                  int64_t C, int64_t K, int64_t N, void *stream);
 
+/* One HMCSampler.sample() (binf/samplers/hmc.py:136-164,183-191) for every
+ * chain on the example's polynomial posterior with a SMALL data set
+ * (K <= 16 coefficients, N <= 128 data points; else BINF_E_UNSUPPORTED), the
+ * whole transition in one launch (the per-step tier is launch-bound there):
+ *   log p(theta) = [lp_pre] + {prior, likelihood in the order prior_first says} + [lp_post]
+ *   likelihood = -0.5 * sum((polyval(xs, theta) - ys)**2) * precision + N/2 * log(precision)
+ *                (binf/example/likelihood.py:24-26,54-57; precision per chain if
+ *                precision_chain != NULL)
+ *   prior      = -0.5 * sum((theta - prior_means)**2 / prior_vars)
+ *                (binf/example/priors.py:49-54; NULL, NULL = no prior)
+ *   lp_pre / lp_post [C] or NULL: the posterior's theta-independent component
+ *                terms that come before / after in its summation order
+ *                (binf/pdf/posteriors.py:147-151).
+ * The force is the likelihood's gradient only (the prior is registered
+ * non-differentiable, posteriors.py:183).  Energies follow numpy's summation
+ * order and are bit-identical to the per-step tier's; the force is an FMA dot
+ * product (tolerance, like the MFMA path).  Other arguments as
+ * binf_hmc_sample_gauss_f64. */
+int32_t binf_hmc_sample_poly_f64(const double *q0, const double *p0,
+                                 const double *u, double *q_out,
+                                 uint8_t *accepted, int64_t *n_accepted,
+                                 double *e_before, double *e_after,
+                                 const double *xs, const double *ys,
+                                 double precision, const double *precision_chain,
+                                 const double *prior_means, const double *prior_vars,
+                                 int32_t prior_first, const double *lp_pre,
+                                 const double *lp_post, double timestep,
+                                 double *dt_chain, int64_t C, int64_t K,
+                                 int64_t N, int32_t nsteps, int32_t adapt,
+                                 double uprate, double downrate, int32_t mode,
+                                 void *stream);
+
 /* Conjugate precision draw, GammaSampler.sample (binf/example/samplers.py:34-51):
  * out[c] = g[c] / (-lp_unit[c] + prior_rate), g = supplied Gamma(shape) variates,
  * lp_unit = likelihood log-prob evaluated at precision = 1. */

@@ -215,6 +215,92 @@ def test_hmc_on_polynomial_posterior_vs_restatement(device, K, N, C, L, dt, xlim
     assert 0 < acc.mean()
 
 
+def _small_posterior(xs, ys, K, prior, lik_name='points'):
+    from binf_amd.pdf.likelihoods import Likelihood
+    from binf_amd.pdf.posteriors import Posterior
+    lik = Likelihood(lik_name, ForwardModel(xs, POLYVAL), GaussianErrorModel(ys))
+    priors = {'precision_prior': GammaPrior(1.0, 0.2)}
+    if prior:
+        priors['coefficients_prior'] = GaussianPrior(np.linspace(-0.5, 0.5, K),
+                                                     np.linspace(2.0, 5.0, K))
+    return Posterior({lik.name: lik}, priors)
+
+
+@pytest.mark.parametrize('K,N,C,L,prior,lik_name,mode', [
+    (4, 20, 70, 50, True, 'points', 'exact'),      # example_script.py's shape
+    (4, 20, 5, 7, True, 'a_first', 'exact'),       # likelihood sorts before the prior
+    (1, 1, 3, 3, False, 'points', 'exact'),
+    (3, 7, 65, 4, True, 'points', 'fma'),
+    (7, 8, 9, 4, True, 'points', 'exact'),
+    (8, 37, 130, 5, True, 'points', 'exact'),
+    (9, 100, 6, 3, False, 'points', 'exact'),
+    (13, 127, 4, 3, True, 'points', 'fma'),
+    (16, 128, 66, 2, True, 'points', 'exact')])
+def test_fused_small_polynomial_transition_vs_per_step_tier(device, K, N, C, L, prior,
+                                                            lik_name, mode):
+    """binf_hmc_sample_poly_f64 (one launch) against the per-step tier on the
+    same conditional posterior and draws: E_before identical to the bit (same
+    state, numpy's summation order in both), trajectory / E_after to 1e-10
+    (the force is an FMA dot product here, MFMA there), same accept flags;
+    per-chain precision and per-chain adapting step sizes included."""
+    rs = np.random.RandomState(100 * K + N)
+    xs = np.linspace(-1.5, 1.5, N)
+    ys = R.polyval(xs, rs.standard_normal(K)) + 0.5 * rs.standard_normal(N)
+    q0 = 0.2 * rs.standard_normal((C, K))
+    p0 = rs.standard_normal((2, C, K))
+    u = rs.uniform(size=(2, C))
+    tau = 0.5 + rs.uniform(size=C)
+    dt = 0.02 / max(1.0, N / 20.0) / K
+    post = _small_posterior(xs, ys, K, prior, lik_name)
+    cond = post.conditional_factory(precision=dev_t(tau, device))
+    assert cond.native_hmc_spec('coefficients') is not None
+    got = {}
+    for fused in (True, False):
+        s = HMCSampler(cond, dev_t(q0, device), dt, L, timestep_adaption_limit=10,
+                       variable_name='coefficients', mode=mode)
+        s.fused_polynomial = fused
+        res = []
+        for i in range(2):
+            out = s.sample(p0=dev_t(p0[i], device), u=dev_t(u[i], device))
+            res.append((out.cpu().numpy().copy(), s.last_move_accepted.cpu().numpy().copy(),
+                        s.last_e_before.cpu().numpy().copy(),
+                        s.last_e_after.cpu().numpy().copy(), s.timestep.cpu().numpy().copy()))
+        got[fused] = (res, s.n_accepted.cpu().numpy())
+    for i in range(2):
+        (qf, af, ebf, eaf, dtf), (qg, ag, ebg, eag, dtg) = got[True][0][i], got[False][0][i]
+        assert np.array_equal(af, ag) and np.array_equal(dtf, dtg)
+        if i == 0:
+            assert np.array_equal(ebf, ebg)
+        assert np.allclose(ebf, ebg, rtol=RTOL, atol=0)
+        assert np.allclose(eaf, eag, rtol=1e-9, atol=0)
+        assert np.allclose(qf, qg, rtol=RTOL, atol=RTOL * np.abs(qg).max())
+    assert np.array_equal(got[True][1], got[False][1])
+
+
+def test_fused_small_polynomial_limits_and_fallback(device):
+    """More than 128 data points or 16 coefficients: the sampler stays on the
+    per-step tier; the C entry point itself refuses."""
+    rs = np.random.RandomState(0)
+    for K, N in ((4, 129), (17, 20)):
+        xs = np.linspace(-1, 1, N)
+        ys = rs.standard_normal(N)
+        cond = _small_posterior(xs, ys, K, True).conditional_factory(precision=2.0)
+        s = HMCSampler(cond, dev_t(0.1 * rs.standard_normal((3, K)), device), 1e-3, 2,
+                       variable_name='coefficients')
+        assert s._fused_spec('coefficients', K) is None
+        assert s.sample().shape == (3, K)
+        z = torch.zeros((3, K), dtype=torch.float64, device=device)
+        with pytest.raises(NotImplementedError):
+            _native.hmc_sample_poly(z, z.clone(), torch.zeros(3, dtype=torch.float64, device=device),
+                                    z.clone(), torch.zeros(3, dtype=torch.uint8, device=device),
+                                    None, None, None, dev_t(xs, device), dev_t(ys, device), 2.0,
+                                    None, None, True, None, None, 1e-3, None, 2, False,
+                                    1.05, 0.95)
+    # a posterior with another free variable is not the conditional the kernel integrates
+    full = _small_posterior(np.linspace(-1, 1, 20), rs.standard_normal(20), 4, True)
+    assert full.native_hmc_spec('coefficients') is None
+
+
 def test_gamma_sampler_matches_restatement(device):
     xs, ys = RE.example_data()
     K, C = 4, 10
