@@ -271,6 +271,17 @@ def accept_select(q_prop, q_old, e_before, e_after, u, q_out, accepted,
     check(rc, 'binf_accept_select_f64')
 
 
+def require_device(x, what):
+    """The package computes on the GPU only: ``x`` must be a ROCm tensor.
+    Raises TypeError otherwise (there is no numpy / CPU evaluation path)."""
+    if not (isinstance(x, torch.Tensor) and x.is_cuda):
+        raise TypeError('%s must be a ROCm (cuda) fp64 tensor, got %s; binf_amd '
+                        'evaluates on the GPU only (no CPU path)'
+                        % (what, type(x).__name__ if not isinstance(x, torch.Tensor)
+                           else 'a %s tensor' % x.device.type))
+    return x
+
+
 def _precision_args(precision, C, device):
     """(host scalar, per-chain tensor or None) from a float or a [C] tensor."""
     if isinstance(precision, torch.Tensor):

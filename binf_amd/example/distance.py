@@ -42,14 +42,11 @@ class DistanceForwardModel(AbstractForwardModel):
         return self._dev[device]
 
     def _evaluate(self, coordinates):
-        if isinstance(coordinates, torch.Tensor) and coordinates.is_cuda:
-            x = coordinates if coordinates.dim() == 2 else coordinates.reshape(1, -1)
-            I, J = self.pair_index(x.device)
-            out = _native.pairdist_forward(x.contiguous(), I, J)
-            return out if coordinates.dim() == 2 else out.reshape(-1)
-        x = np.asarray(coordinates).reshape(-1, 3)
-        I, J = self._pairs
-        return np.sqrt(np.sum((x[I] - x[J]) ** 2, axis=1))
+        _native.require_device(coordinates, 'coordinates')
+        x = coordinates if coordinates.dim() == 2 else coordinates.reshape(1, -1)
+        I, J = self.pair_index(x.device)
+        out = _native.pairdist_forward(x.contiguous(), I, J)
+        return out if coordinates.dim() == 2 else out.reshape(-1)
 
     def _evaluate_jacobi_matrix(self, coordinates):
         raise NotImplementedError(

@@ -69,18 +69,17 @@ class ForwardModel(AbstractForwardModel):
 
     # -- model interface ------------------------------------------------------
     def _evaluate(self, coefficients):
-        if self.is_native and isinstance(coefficients, torch.Tensor) and \
-                coefficients.is_cuda:
-            out = _native.poly_forward(_as2d(coefficients),
-                                       self.xs_device(coefficients.device))
-            return out if coefficients.dim() == 2 else out.reshape(-1)
-        return self.polynomial(self.xses, coefficients)
+        if not self.is_native:
+            # a user-supplied polynomial callable is applied as given
+            return self.polynomial(self.xses, coefficients)
+        _native.require_device(coefficients, 'coefficients')
+        out = _native.poly_forward(_as2d(coefficients),
+                                   self.xs_device(coefficients.device))
+        return out if coefficients.dim() == 2 else out.reshape(-1)
 
     def _evaluate_jacobi_matrix(self, coefficients):
-        if isinstance(coefficients, torch.Tensor):
-            return self.design_matrix(coefficients.shape[-1],
-                                      coefficients.device)
-        return np.vstack([self.xses ** i for i in range(len(coefficients))])
+        _native.require_device(coefficients, 'coefficients')
+        return self.design_matrix(coefficients.shape[-1], coefficients.device)
 
     def clone(self):
         copy = self.__class__(self.xses, self.polynomial)
@@ -115,20 +114,15 @@ class GaussianErrorModel(AbstractErrorModel):
         return self._dev[device]
 
     def _evaluate_log_prob(self, mock_data, precision):
-        if isinstance(mock_data, torch.Tensor) and mock_data.is_cuda:
-            return _native.gauss_err_logp(_as2d(mock_data),
-                                          self.ys_device(mock_data.device),
-                                          precision)
-        logZ = len(self.ys) * 0.5 * np.log(precision)
-        return -0.5 * np.sum((mock_data - self.ys) ** 2) * precision + logZ
+        _native.require_device(mock_data, 'mock_data')
+        return _native.gauss_err_logp(_as2d(mock_data),
+                                      self.ys_device(mock_data.device), precision)
 
     def _evaluate_gradient(self, mock_data, precision):
-        if isinstance(mock_data, torch.Tensor) and mock_data.is_cuda:
-            out = _native.gauss_err_grad(_as2d(mock_data),
-                                         self.ys_device(mock_data.device),
-                                         precision)
-            return out if mock_data.dim() == 2 else out.reshape(-1)
-        return (mock_data - self.ys) * precision
+        _native.require_device(mock_data, 'mock_data')
+        out = _native.gauss_err_grad(_as2d(mock_data),
+                                     self.ys_device(mock_data.device), precision)
+        return out if mock_data.dim() == 2 else out.reshape(-1)
 
     def clone(self):
         copy = self.__class__(self.ys)

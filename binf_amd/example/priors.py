@@ -64,16 +64,11 @@ class GaussianPrior(AbstractPrior):
         return self._dev[key][1]
 
     def _evaluate_log_prob(self, coefficients):
-        if isinstance(coefficients, torch.Tensor) and coefficients.is_cuda:
-            c2 = coefficients if coefficients.dim() == 2 else \
-                coefficients.reshape(1, -1)
-            dev = c2.device
-            return _native.row_sumsq_diff(c2.contiguous(),
-                                          self._vec('means', dev), scale=-0.5,
-                                          weights=self._vec('variances', dev))
-        means = self['means'].value
-        variances = self['variances'].value
-        return -0.5 * np.sum((coefficients - means) ** 2 / variances)
+        _native.require_device(coefficients, 'coefficients')
+        c2 = coefficients if coefficients.dim() == 2 else coefficients.reshape(1, -1)
+        dev = c2.device
+        return _native.row_sumsq_diff(c2.contiguous(), self._vec('means', dev),
+                                      scale=-0.5, weights=self._vec('variances', dev))
 
     def _evaluate_gradient(self, **variables):
         # the reference's implementation reads parameters that do not exist

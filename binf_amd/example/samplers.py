@@ -55,19 +55,15 @@ class GammaSampler(object):
 
     def sample(self, state=42):
         shape = self._calculate_shape()
-        lp1 = self._unit_precision_log_prob()
-        if isinstance(lp1, torch.Tensor):
-            C = lp1.numel()
-            if self.gamma is not None:
-                g = self.gamma(shape, C, lp1.device)
-            else:
-                g = torch.from_numpy(
-                    np.random.gamma(shape, size=C)).to(lp1.device)
-            self.state = _native.gamma_precision_update(
-                g, lp1.reshape(-1).contiguous(), self._get_prior().rate)
+        lp1 = _native.require_device(self._unit_precision_log_prob(),
+                                     'the likelihood log-prob')
+        C = lp1.numel()
+        if self.gamma is not None:
+            g = self.gamma(shape, C, lp1.device)
         else:
-            rate = -lp1 + self._get_prior().rate
-            self.state = np.random.gamma(shape) / rate
+            g = torch.from_numpy(np.random.gamma(shape, size=C)).to(lp1.device)
+        self.state = _native.gamma_precision_update(
+            g, lp1.reshape(-1).contiguous(), self._get_prior().rate)
         return self.state
 
 
@@ -97,35 +93,25 @@ class RWMCSampler(object):
         return 0.0
 
     def sample(self):
-        state = self.state
+        state = _native.require_device(self.state, 'the RWMC state')
         E_old = -self.pdf.log_prob(coefficients=state)
-        if isinstance(state, torch.Tensor):
-            s2 = state if state.dim() == 2 else state.reshape(1, -1)
-            C, K = s2.shape
-            dev = s2.device
-            shape = (K,) if state.dim() == 1 else (C, K)
-            change = torch.from_numpy(np.random.uniform(
-                low=-self.stepsize, high=self.stepsize, size=shape)).to(dev)
-            proposal = state + change
-            E_new = -self.pdf.log_prob(coefficients=proposal)
-            u = torch.from_numpy(np.random.random(size=C)).to(dev)
-            accepted = torch.empty(C, dtype=torch.uint8, device=dev)
-            if not isinstance(self._n_accepted_moves, torch.Tensor):
-                self._n_accepted_moves = torch.zeros(C, dtype=torch.int64,
-                                                     device=dev)
-            p2 = proposal if proposal.dim() == 2 else proposal.reshape(1, -1)
-            _native.accept_select(p2.contiguous(), s2.contiguous(),
-                                  E_old.reshape(-1), E_new.reshape(-1), u, p2,
-                                  accepted, self._n_accepted_moves)
-            self.state = p2.view(state.shape)
-        else:
-            change = np.random.uniform(low=-self.stepsize, high=self.stepsize,
-                                       size=len(state))
-            proposal = state + change
-            E_new = -self.pdf.log_prob(coefficients=proposal)
-            if np.random.random() < np.exp(-(E_new - E_old)):
-                self.state = proposal
-                self._n_accepted_moves += 1
+        s2 = state if state.dim() == 2 else state.reshape(1, -1)
+        C, K = s2.shape
+        dev = s2.device
+        shape = (K,) if state.dim() == 1 else (C, K)
+        change = torch.from_numpy(np.random.uniform(
+            low=-self.stepsize, high=self.stepsize, size=shape)).to(dev)
+        proposal = state + change
+        E_new = -self.pdf.log_prob(coefficients=proposal)
+        u = torch.from_numpy(np.random.random(size=C)).to(dev)
+        accepted = torch.empty(C, dtype=torch.uint8, device=dev)
+        if not isinstance(self._n_accepted_moves, torch.Tensor):
+            self._n_accepted_moves = torch.zeros(C, dtype=torch.int64, device=dev)
+        p2 = proposal if proposal.dim() == 2 else proposal.reshape(1, -1)
+        _native.accept_select(p2.contiguous(), s2.contiguous(),
+                              E_old.reshape(-1), E_new.reshape(-1), u, p2,
+                              accepted, self._n_accepted_moves)
+        self.state = p2.view(state.shape)
         self._n_moves += 1
         return self.state
 

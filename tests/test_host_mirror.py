@@ -413,3 +413,32 @@ def test_gibbs_stats():
 def test_gibbs_checkstate():
     with pytest.raises(TypeError):
         make_gibbs()._checkstate([1, 2])
+
+
+def test_example_models_and_samplers_have_no_cpu_evaluation_path():
+    """The package's own model classes compute in HIP kernels only: host
+    (numpy) values are refused with a TypeError instead of being evaluated with
+    numpy.  (User plug-ins like the mocks above compute however they like.)"""
+    from binf_amd.example.distance import DistanceForwardModel
+    from binf_amd.example.likelihood import POLYVAL, ForwardModel, GaussianErrorModel
+    from binf_amd.example.priors import GaussianPrior
+    from binf_amd.example.samplers import RWMCSampler
+    np = numpy
+    xs, ys = np.linspace(-1, 1, 5), np.zeros(5)
+    with pytest.raises(TypeError, match='no CPU path'):
+        ForwardModel(xs, POLYVAL)(coefficients=np.ones(3))
+    with pytest.raises(TypeError, match='no CPU path'):
+        ForwardModel(xs, POLYVAL).jacobi_matrix(coefficients=np.ones(3))
+    with pytest.raises(TypeError, match='no CPU path'):
+        GaussianErrorModel(ys).log_prob(mock_data=np.zeros(5), precision=1.0)
+    with pytest.raises(TypeError, match='no CPU path'):
+        GaussianErrorModel(ys).gradient(mock_data=np.zeros(5), precision=1.0)
+    with pytest.raises(TypeError, match='no CPU path'):
+        GaussianPrior(np.zeros(3), np.ones(3)).log_prob(coefficients=np.ones(3))
+    with pytest.raises(TypeError, match='no CPU path'):
+        DistanceForwardModel(4)(coordinates=np.zeros(12))
+    with pytest.raises(TypeError, match='no CPU path'):
+        RWMCSampler(None, np.ones(3), 0.1).sample()
+    import torch
+    with pytest.raises(TypeError, match='a cpu tensor'):
+        GaussianErrorModel(ys).log_prob(mock_data=torch.zeros(5, dtype=torch.float64), precision=1.0)
