@@ -1,0 +1,91 @@
+"""Statistical correctness on the GPU: the samplers must sample their target
+distribution.  Independent of the bitwise oracle (whose HMC numerics are not
+pinned by the reference): a wrong accept rule, energy or
+integrator would pass a restatement-vs-restatement comparison but not these.
+
+All targets have closed forms:
+* isotropic Gaussian N(x0, 1/k) -- C2's PDF, fused persistent kernel with the
+  device RNG (every draw generated on the device);
+* polynomial coefficients given the precision: Gaussian with precision matrix
+  tau * A A^T + diag(1 / prior_var) -- the fused small-data transition;
+* Gibbs over (coefficients, precision) -- checked through the conjugate
+  identity E[tau | theta] averaged over the chain.
+Tolerances are 6 standard errors of the respective Monte-Carlo mean (fixed
+seeds, so the tests are deterministic)."""
+import numpy as np
+import pytest
+import torch
+
+from binf_amd.example.likelihood import POLYVAL, ForwardModel, GaussianErrorModel
+from binf_amd.example.priors import GammaPrior, GaussianPrior
+from binf_amd.pdf import IsotropicGaussian
+from binf_amd.pdf.likelihoods import Likelihood
+from binf_amd.pdf.posteriors import Posterior
+from binf_amd.samplers.hmc import HMCSampler
+from binf_amd.samplers.rng import DeviceRNG
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize('k,x0,mode', [(1.0, 0.0, 'exact'), (2.5, 0.3, 'exact'), (1.0, 0.0, 'fma')])
+def test_gaussian_target_moments(device, k, x0, mode):
+    C, D, L, dt = 2048, 64, 20, 0.3 / np.sqrt(k)
+    rng = DeviceRNG(11, device)
+    q0 = x0 + rng.normal((C, D), device) / np.sqrt(k)          # start in equilibrium
+    s = HMCSampler(IsotropicGaussian(k, x0), q0, dt, L, variable_name='x', rng=rng, mode=mode)
+    draws = s.sample_n(200, thin=10)                            # [20, C, D]
+    assert 0.7 < float(s.acceptance_rate.mean()) < 1.0
+    x = draws.reshape(-1, D).cpu().numpy()
+    n = x.shape[0]                                              # chains are independent
+    se_mean = 1.0 / np.sqrt(k * C)                              # per kept sweep: >= C independent values
+    assert np.abs(x.mean(0) - x0).max() < 6 * se_mean
+    var = ((x - x0) ** 2).mean(0)
+    assert np.abs(var * k - 1.0).max() < 6 * np.sqrt(2.0 / C)
+    # mixing: a long trajectory decorrelates the state from the start
+    first, last = draws[0].cpu().numpy(), draws[-1].cpu().numpy()
+    corr = np.mean((first - x0) * (last - x0)) * k
+    assert abs(corr) < 6 / np.sqrt(C * D)
+    assert n == 20 * C
+
+
+def _conditional(xs, ys, K, tau, device):
+    lik = Likelihood('points', ForwardModel(xs, POLYVAL), GaussianErrorModel(ys))
+    post = Posterior({lik.name: lik},
+                     {'precision_prior': GammaPrior(1.0, 0.2),
+                      'coefficients_prior': GaussianPrior(np.zeros(K), np.full(K, 5.0))})
+    return post, post.conditional_factory(precision=tau)
+
+
+@pytest.mark.parametrize('fused', [True, False])
+def test_polynomial_conditional_matches_its_analytic_gaussian(device, fused):
+    """p(theta | tau, data) is Gaussian; the HMC force omits the prior (quirk
+    Q4) but the energy has it, so the chain must still target the full
+    conditional."""
+    rs = np.random.RandomState(5)
+    K, N, tau = 4, 20, 2.5
+    xs = np.linspace(-2, 2, N)
+    ys = np.polynomial.polynomial.polyval(xs, [2.0, -4.0, 1.0, 1.5]) + rs.standard_normal(N) / np.sqrt(tau)
+    A = np.vstack([xs ** i for i in range(K)])
+    P = tau * A @ A.T + np.eye(K) / 5.0
+    cov = np.linalg.inv(P)
+    mean = cov @ (tau * A @ ys)
+    C = 4096 if fused else 256
+    sweeps, burn = (120, 40) if fused else (40, 15)
+    _, cond = _conditional(xs, ys, K, tau, device)
+    rng = DeviceRNG(3, device)
+    start = torch.from_numpy(mean + rs.standard_normal((C, K)) @ np.linalg.cholesky(cov).T).to(device)
+    s = HMCSampler(cond, start, 0.02, 50, variable_name='coefficients', rng=rng)
+    s.fused_polynomial = fused
+    assert (s._fused_spec('coefficients', K) is not None) == fused
+    kept = []
+    for i in range(sweeps):
+        x = s.sample()
+        if i >= burn and i % 5 == 0:
+            kept.append(x.clone())
+    acc = float(s.acceptance_rate.mean())
+    assert 0.6 < acc <= 1.0
+    x = torch.stack(kept).cpu().numpy()                         # [n, C, K]
+    se = np.sqrt(np.diag(cov) / C)                              # one sweep of C chains at least
+    assert (np.abs(x.mean((0, 1)) - mean) < 6 * se).all()
+    emp = np.cov(x.reshape(-1, K).T)
+    assert np.abs(emp - cov).max() < 0.15 * np.abs(cov).max()
