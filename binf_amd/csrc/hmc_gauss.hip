@@ -22,8 +22,8 @@
 //     read back only on rejection;
 //   * V(q) of the current state is carried over instead of being re-reduced
 //     (re-reducing the same bits gives the same bits);
-//   * the Gaussian is separable, so each group of 4 elements per lane runs its
-//     whole trajectory on its own; the momentum streams in one group at a
+//   * the Gaussian is separable, so each group of GS (8) elements per lane runs
+//     its whole trajectory on its own; the momentum streams in one group at a
 //     time, the next group's draw (or the next transition's first group)
 //     being fetched while the current group integrates.
 #include "gauss_common.hpp"
@@ -228,7 +228,6 @@ hmc_gauss_persist_kernel(const GaussNArgs a)
         x = (x > 709.0) ? 709.0 : x;
         const bool acc = uu < exp_clipped_range(x);
 
-        const double dt_used = dt;
         if (s < a.n_adapt)                                    // hmc.py:188-191
             dt = acc ? dt * a.uprate : dt * a.downrate;
         if (cvalid && writer) {
@@ -237,7 +236,6 @@ hmc_gauss_persist_kernel(const GaussNArgs a)
             if (a.e_before) a.e_before[o] = Eb;
             if (a.e_after) a.e_after[o] = Ea;
         }
-        (void)dt_used;
         if (acc) {
             Sq_state = Sqa;
             nacc += 1;
