@@ -47,6 +47,7 @@ SIGNATURES = {
                                         _vp, _vp, _f64, _vp, _vp, _vp, _i32,
                                         _vp, _vp, _f64, _vp, _i64, _i64, _i64,
                                         _i32, _i32, _f64, _f64, _i32, _vp]),
+    'binf_clipped_exp_f64': (_i32, [_vp, _vp, _i64, _vp]),
     'binf_row_sum_f64': (_i32, [_vp, _vp, _i64, _i64, _i32, _f64, _f64, _vp]),
     'binf_leapfrog_kick_f64': (_i32, [_vp, _vp, _f64, _vp, _i32, _i64, _i64,
                                       _i32, _vp]),
@@ -269,6 +270,17 @@ def accept_select(q_prop, q_old, e_before, e_after, u, q_out, accepted,
         dptr(dt_chain, numel=C, name='dt_chain'), int(bool(adapt)),
         float(uprate), float(downrate), C, D, stream_handle(q_prop.device))
     check(rc, 'binf_accept_select_f64')
+
+
+def clipped_exp(x):
+    """exp(clip(x, -308, 709)) elementwise (csb.numeric.exp)."""
+    require_device(x, 'x')
+    xc = x.contiguous()
+    out = torch.empty_like(xc)
+    rc = lib().binf_clipped_exp_f64(dptr(xc), dptr(out), xc.numel(),
+                                    stream_handle(x.device))
+    check(rc, 'binf_clipped_exp_f64')
+    return out
 
 
 def require_device(x, what):

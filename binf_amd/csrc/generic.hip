@@ -6,6 +6,7 @@
 // :148,150 (energy reductions), :151-164 (accept, adapt, select) and the
 // TestHO gradient binf/pdf/__init__.py:191.
 #include "rowsum.hpp"
+#include "gauss_common.hpp"
 
 namespace binf {
 
@@ -109,7 +110,7 @@ __global__ void __launch_bounds__(256) accept_select_kernel(const AcceptArgs a)
     double x = -(a.e_after[c] - a.e_before[c]);
     x = (x < -308.0) ? -308.0 : x;
     x = (x > 709.0) ? 709.0 : x;
-    const bool acc = a.u[c] < exp(x);
+    const bool acc = a.u[c] < exp_clipped_range(x);
     const double *src = acc ? a.q_prop : a.q_old;
     double *dst = a.q_out + c * a.D;
     if (dst != src + c * a.D)
@@ -124,9 +125,36 @@ __global__ void __launch_bounds__(256) accept_select_kernel(const AcceptArgs a)
     }
 }
 
+// csb.numeric.exp: exp(clip(x, -308, 709))
+__global__ void __launch_bounds__(256)
+clipped_exp_kernel(const double *x, double *out, int64_t n)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * 256) {
+        double v = x[i];
+        v = (v < -308.0) ? -308.0 : v;
+        v = (v > 709.0) ? 709.0 : v;
+        out[i] = exp_clipped_range(v);
+    }
+}
+
 }  // namespace binf
 
 using namespace binf;
+
+extern "C" int32_t binf_clipped_exp_f64(const double *x, double *out, int64_t n,
+                                        void *stream)
+{
+    if (n < 0) return fail(BINF_E_ARG, "clipped_exp: negative size");
+    if (n == 0) return 0;
+    if (!x || !out) return fail(BINF_E_ARG, "clipped_exp: null buffer");
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    clipped_exp_kernel<<<dim3((unsigned)blocks), 256, 0, (hipStream_t)stream>>>(x, out, n);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "clipped_exp launch");
+    return 0;
+}
 
 extern "C" int32_t binf_row_sum_f64(const double *x, double *out, int64_t C,
                                     int64_t D, int32_t op, double shift,

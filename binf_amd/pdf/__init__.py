@@ -42,10 +42,12 @@ class AbstractBinfPDF(ParameterHolder, AbstractBinfNamedCallable):
         lp = self.log_prob(**variables)
         try:
             import torch
-            if isinstance(lp, torch.Tensor):
-                return torch.exp(torch.clamp(lp, -308.0, 709.0))
         except ImportError:  # pragma: no cover
-            pass
+            torch = None
+        if torch is not None and isinstance(lp, torch.Tensor) and lp.is_cuda:
+            from binf_amd import _native
+            return _native.clipped_exp(lp)
+        # host values only come from user plug-ins that compute on the host
         import numpy
         return numpy.exp(numpy.clip(lp, -308.0, 709.0))
 

@@ -153,6 +153,12 @@ int32_t binf_leapfrog_drift_f64(double *q, const double *p, double timestep,
 int32_t binf_gauss_grad_f64(const double *x, double *out, double k, double x0,
                             int64_t C, int64_t D, void *stream);
 
+/* out[i] = exp(clip(x[i], -308, 709)): csb.numeric.exp as the reference uses it
+ * in the accept test (binf/samplers/hmc.py:10,151) and in
+ * AbstractBinfPDF._evaluate (binf/pdf/__init__.py:10,89).  The SAME device
+ * function decides every accept test of this library. */
+int32_t binf_clipped_exp_f64(const double *x, double *out, int64_t n, void *stream);
+
 /* acc[c] = u[c] < exp(clip(-(e_after[c]-e_before[c]), -308, 709));
  * q_out[c,:] = acc ? q_prop[c,:] : q_old[c,:];  optional step-size adaption of
  * dt_chain as in binf_hmc_sample_gauss_f64.       hmc.py:151-164,188-191

@@ -128,3 +128,21 @@ def test_non_contiguous_inputs_are_accepted(device):
     s2 = HMCSampler(Strided(), dev_t(q0, device), dt, L, variable_name='x')
     out2 = s2.sample(p0=dev_t(p0, device), u=dev_t(u, device))
     assert np.array_equal(out2.cpu().numpy(), want['q_out'])
+
+
+def test_clipped_exp_matches_numpy_to_an_ulp(device):
+    """binf_clipped_exp_f64 = csb.numeric.exp = exp(clip(x, -308, 709)); the
+    same device function decides every accept test in the library."""
+    rs = np.random.RandomState(0)
+    x = np.concatenate([rs.uniform(-320, 720, 200000), rs.uniform(-1, 1, 100000),
+                        rs.standard_normal(100000) * 1e-8,
+                        [-1e300, -308.0, -307.9999, 0.0, -0.0, 1.0, 708.9, 709.0, 710.0, 1e300,
+                         np.inf, -np.inf]])
+    got = _native.clipped_exp(dev_t(x, device)).cpu().numpy()
+    want = np.exp(np.clip(x, -308.0, 709.0))
+    assert np.isfinite(got).all() and (got > 0).all()
+    ulp = np.abs(got - want) / np.spacing(want)
+    assert ulp.max() <= 1.0, ulp.max()
+    assert (ulp == 0).mean() > 0.9
+    assert got[x == 0.0].tolist() == [1.0, 1.0]
+    assert np.isnan(_native.clipped_exp(dev_t([np.nan], device)).cpu().numpy()[0])
