@@ -137,7 +137,7 @@ def main():
     from binf_amd.samplers.hmc import HMCSampler
 
     C, D, L, dt = args.chains, args.dims, args.nsteps, args.timestep
-    K, W, P = args.steps, args.warmup, max(1, args.pool)
+    K, W, P = max(1, args.steps), max(0, args.warmup), max(1, args.pool)
 
     # synthetic inputs, resident in HBM before the timed region
     q0 = torch.from_numpy(
