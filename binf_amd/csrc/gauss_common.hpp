@@ -5,6 +5,37 @@
 
 namespace binf {
 
+// Arguments of the fused Gaussian HMC kernels (hmc_gauss.hip, hmc_gauss_split.hip)
+struct GaussNArgs {
+    const double *q0;
+    const double *p0;        // [n x C x D]
+    const double *u;         // [n x C]
+    double *q_out;           // [C x D]
+    double *samples;         // [n/thin x C x D] or null
+    uint8_t *accepted;       // [n x C] or null
+    int64_t *n_accepted;     // [C] or null
+    double *e_before;        // [n x C] or null
+    double *e_after;         // [n x C] or null
+    double *dt_chain;        // [C] or null
+    double timestep;
+    double k;
+    double x0;
+    double uprate;
+    double downrate;
+    int64_t C;
+    int32_t D;
+    int32_t nsteps;
+    int32_t H;
+    int32_t n;               // transitions per launch
+    int32_t thin;            // record every thin-th state (>= 1)
+    int32_t n_adapt;         // the first n_adapt transitions adapt the timestep
+};
+
+// hmc_gauss_split.hip: few chains of D in {768, 1024} spread over 2 / 4 waves each
+int gauss_split_factor(int64_t C, int32_t H, bool regular, int tneed);
+hipError_t launch_gauss_split(const GaussNArgs &a, int tneed, int split, bool unit, bool fma,
+                              hipStream_t st);
+
 // In-lane part of np.sum: numpy's j-th accumulator of a leaf adds a[8t+j] for
 // t = 0..T-1 in order; element t == T (if the lane has one) is a tail element
 // and is added after the leaf's accumulators have been combined.

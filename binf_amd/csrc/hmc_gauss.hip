@@ -30,31 +30,6 @@
 
 namespace binf {
 
-struct GaussNArgs {
-    const double *q0;
-    const double *p0;        // [n x C x D]
-    const double *u;         // [n x C]
-    double *q_out;           // [C x D]
-    double *samples;         // [n/thin x C x D] or null
-    uint8_t *accepted;       // [n x C] or null
-    int64_t *n_accepted;     // [C] or null
-    double *e_before;        // [n x C] or null
-    double *e_after;         // [n x C] or null
-    double *dt_chain;        // [C] or null
-    double timestep;
-    double k;
-    double x0;
-    double uprate;
-    double downrate;
-    int64_t C;
-    int32_t D;
-    int32_t nsteps;
-    int32_t H;
-    int32_t n;               // transitions per launch
-    int32_t thin;            // record every thin-th state (>= 1)
-    int32_t n_adapt;         // the first n_adapt transitions adapt the timestep
-};
-
 // LW = log2(waves per chain).  LW = 0: a chain is G = 8 << H <= 64 lanes of one
 // wave (several chains per wave when G < 64).  LW > 0 (D > 1024): a chain spans
 // 2 / 4 / 8 whole waves of the workgroup; the leaf-tree levels above a wave are
@@ -362,7 +337,9 @@ extern "C" int32_t binf_hmc_sample_n_gauss_f64(
     const bool unit = (k == 1.0 && x0 == 0.0);
     const bool fma = (mode == BINF_MODE_FMA);
     hipError_t e;
-    if (LW == 1)          e = launch_n_wide<1>(a, regular && tneed == 16, unit, fma, grid, st);
+    const int split = (LW == 0) ? gauss_split_factor(C, H, regular, tneed) : 1;
+    if (split > 1)        e = launch_gauss_split(a, tneed, split, unit, fma, st);
+    else if (LW == 1)     e = launch_n_wide<1>(a, regular && tneed == 16, unit, fma, grid, st);
     else if (LW == 2)     e = launch_n_wide<2>(a, regular && tneed == 16, unit, fma, grid, st);
     else if (LW == 3)     e = launch_n_wide<3>(a, regular && tneed == 16, unit, fma, grid, st);
     else if (tneed <= 1)  e = launch_n_t<1>(a, regular && tneed == 1, unit, fma, grid, st);

@@ -488,6 +488,54 @@ def test_sample_n_equals_n_single_launches(device, D, C, L, k, x0, dt, n, thin, 
         assert 0 < np.stack(acc1).mean() < 1
 
 
+@pytest.mark.parametrize('D,C', [(1024, 1), (1024, 7), (1024, 1024), (1024, 1025), (1024, 2047),
+                                 (1024, 2048), (1024, 2049), (768, 3), (768, 1500)])
+@pytest.mark.parametrize('k,x0,mode', [(1.0, 0.0, 'exact'), (2.5, 0.3, 'exact'), (1.0, 0.0, 'fma')])
+def test_few_chains_spread_over_several_waves_same_bits(device, D, C, k, x0, mode):
+    """Up to 1024 / 2048 chains of D = 768 or 1024 run with 4 / 2 waves per
+    chain (csrc/hmc_gauss_split.hip); above that, one wave per chain.  The
+    results must not depend on the layout: several transitions with per-chain
+    adapting step sizes against the C oracle (exact mode), and against the
+    one-wave kernel run on a padded batch (both modes)."""
+    n, L, dt = 3, 6, 0.21
+    rs = np.random.RandomState(D + C)
+    q0 = rs.standard_normal((C, D)) * 1.1 + x0
+    p0 = rs.standard_normal((n, C, D))
+    u = rs.uniform(size=(n, C))
+    assert _native.lib().binf_pairwise_tree_height(D) == 3
+
+    def run(qq, pp, uu):
+        s = HMCSampler(IsotropicGaussian(k, x0), dev_t(qq, device), dt, L,
+                       timestep_adaption_limit=3, variable_name='x', mode=mode,
+                       record_energies=True)
+        rec = s.sample_n(n, p0=dev_t(pp, device), u=dev_t(uu, device))
+        torch.cuda.synchronize()
+        return (rec.cpu().numpy(), s.accepted_history.cpu().numpy(),
+                s.last_e_before.cpu().numpy(), s.last_e_after.cpu().numpy(),
+                s.timestep.cpu().numpy(), s.n_accepted.cpu().numpy())
+    got = run(q0, p0, u)
+    # the same chains inside a batch of more than 2048: one wave per chain
+    pad = 2100
+    qp = np.concatenate([q0, rs.standard_normal((pad, D))])
+    pp = np.concatenate([p0, rs.standard_normal((n, pad, D))], axis=1)
+    up = np.concatenate([u, rs.uniform(size=(n, pad))], axis=1)
+    ref = run(qp, pp, up)
+    for g, r in zip(got, ref):
+        assert np.array_equal(g, r[:, :C] if r.ndim > 1 and r.shape[0] == n else r[:C])
+    assert 0 < got[1].mean() < 1 or C < 4
+    if mode == 'exact':
+        q = q0.copy()
+        dtc = np.full(C, dt)
+        for i in range(n):
+            want = c_oracle.hmc_sample_gauss(q, p0[i], u[i], dtc, L, k, x0,
+                                             adapt=(i < 2), nthreads=8)
+            assert np.array_equal(got[0][i], want['q_out'])
+            assert np.array_equal(got[1][i], want['accepted'].astype(bool))
+            assert np.array_equal(got[2][i], want['e_before'])
+            assert np.array_equal(got[3][i], want['e_after'])
+            q, dtc = want['q_out'], want['timestep_out']
+
+
 def test_sample_n_generic_pdf_falls_back_to_a_loop(device):
     C, D, n = 5, 9000, 3
     rs = np.random.RandomState(0)
