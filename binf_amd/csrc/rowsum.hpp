@@ -43,7 +43,7 @@ __device__ inline double leaf_sum_f(const F &f, int off, int n, int lane,
 struct RowGeom {
     int64_t C;
     int32_t D;
-    int32_t H;       // pairwise tree height for min(D, 8192) elements
+    int32_t H;       // largest pairwise tree height among the row's 8192-element chunks
     double scale;
 };
 
@@ -76,13 +76,16 @@ row_reduce_wave_kernel(const ARGS args, const RowGeom g, double *out)
 
 // Any D: one 256-thread workgroup per row.  numpy's buffered reduction feeds
 // the pairwise loop NPY_BUFSIZE elements at a time and adds the chunk sums up
-// one after the other; a chunk's tree has height <= 6 (64 leaves).
+// one after the other.  A chunk's tree has height <= 7: 6 for a full chunk,
+// 7 for the 441 ragged lengths in [7689, 8191].  g.H is the largest height
+// among the row's chunks; walking a shallower chunk with it only adds
+// redundant paths (pairwise_leaf).
 template <class FM, class ARGS>
 __global__ void __launch_bounds__(256)
 row_reduce_block_kernel(const ARGS args, const RowGeom g, double *out)
 {
-    __shared__ double S[64];
-    __shared__ int dep[64];
+    __shared__ double S[128];
+    __shared__ int dep[128];
     const int H = g.H;
     const int npaths = 1 << H;
     const int lane = threadIdx.x & 63;
@@ -130,6 +133,11 @@ static int32_t row_reduce_launch(const ARGS &args, int64_t C, int64_t D,
     RowGeom g;
     g.C = C; g.D = (int32_t)D; g.scale = scale;
     g.H = pairwise_tree_height(D < NPY_BUFSIZE ? D : NPY_BUFSIZE);
+    if (D > NPY_BUFSIZE && D % NPY_BUFSIZE != 0) {
+        const int32_t h_last = pairwise_tree_height(D % NPY_BUFSIZE);
+        if (h_last > g.H) g.H = h_last;
+    }
+    if (g.H > 7) return fail(BINF_E_UNSUPPORTED, "%s: pairwise tree height %d", what, g.H);
     if (g.H <= 3 && !force_block) {
         const int64_t rows_per_wave = 64 >> (3 + g.H);
         const int64_t waves = (C + rows_per_wave - 1) / rows_per_wave;

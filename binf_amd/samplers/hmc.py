@@ -190,11 +190,17 @@ class HMCSampler(object):
         spec = self._fused_spec(name, D)
         nrec = n // thin
         if spec is None or spec[0] != 'gauss':
-            out = []
+            out, flags, ebs, eas = [], [], [], []
             for i in range(n):
                 x = self.sample(p0=p0[i], u=u[i])
                 if record and (i + 1) % thin == 0:
                     out.append(x)
+                flags.append(self._last_move_accepted)
+                ebs.append(self.last_e_before)
+                eas.append(self.last_e_after)
+            self.accepted_history = torch.stack(flags)
+            if all(e is not None for e in ebs):
+                self.last_e_before, self.last_e_after = torch.stack(ebs), torch.stack(eas)
             return torch.stack(out) if (record and out) else None
 
         _, k, x0 = spec

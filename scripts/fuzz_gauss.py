@@ -1,0 +1,71 @@
+"""Randomised differential test of the fused Gaussian HMC kernels (all layouts:
+several chains per wave, one wave per chain, several waves per chain, split
+chains, irregular pairwise trees) against the C oracle, bit for bit.
+Development aid / soak test:  python scripts/fuzz_gauss.py [n_cases] [seed]"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from binf_amd.pdf import IsotropicGaussian
+from binf_amd.samplers.hmc import HMCSampler
+from oracle import c_oracle
+
+dev = torch.device('cuda:0')
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+rs = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+t0 = time.time()
+bad = 0
+for case in range(n_cases):
+    kind = rs.randint(5)
+    if kind == 0:
+        D = int(rs.randint(1, 130))
+    elif kind == 1:
+        D = int(rs.randint(130, 1100))
+    elif kind == 2:
+        D = int(rs.choice([768, 1024]))
+    elif kind == 3:
+        D = int(rs.randint(1100, 8193))
+    else:
+        D = int(8 * rs.randint(1, 1025))
+    C = int(rs.choice([1, 2, 3, 7, 8, 9, 31, 64, 65, 200, 1030]))
+    if D * C > 3e6:
+        C = max(1, int(3e6 // D))
+    L = int(rs.randint(1, 9))
+    n = int(rs.randint(1, 5))
+    thin = int(rs.randint(1, n + 1))
+    limit = int(rs.choice([0, 0, 2, 10]))
+    k, x0 = (1.0, 0.0) if rs.rand() < 0.5 else (float(rs.uniform(0.2, 3)), float(rs.normal()))
+    dt = float(rs.uniform(0.01, 0.6)) / np.sqrt(k)
+    q0 = rs.standard_normal((C, D)) / np.sqrt(k) + x0
+    p0 = rs.standard_normal((n, C, D))
+    u = rs.uniform(size=(n, C))
+    s = HMCSampler(IsotropicGaussian(k, x0), torch.from_numpy(q0).to(dev), dt, L,
+                   timestep_adaption_limit=limit, variable_name='x', record_energies=True)
+    rec = s.sample_n(n, thin=thin, p0=torch.from_numpy(p0).to(dev), u=torch.from_numpy(u).to(dev))
+    torch.cuda.synchronize()
+    acc = s.accepted_history.cpu().numpy()
+    eb, ea = s.last_e_before.cpu().numpy(), s.last_e_after.cpu().numpy()
+    q, dtc = q0, np.full(C, dt)
+    ok = True
+    for i in range(n):
+        adapt = (i + 1) < limit
+        w = c_oracle.hmc_sample_gauss(q, p0[i], u[i], dtc, L, k, x0, adapt=adapt, nthreads=8)
+        ok &= np.array_equal(acc[i], w['accepted'].astype(bool))
+        ok &= np.array_equal(eb[i], w['e_before']) and np.array_equal(ea[i], w['e_after'])
+        if (i + 1) % thin == 0:
+            ok &= np.array_equal(rec[(i + 1) // thin - 1].cpu().numpy(), w['q_out'])
+        q, dtc = w['q_out'], w['timestep_out']
+    ok &= np.array_equal(s.state.cpu().numpy(), q)
+    if limit:
+        ok &= np.array_equal(np.broadcast_to(s.timestep.cpu().numpy() if isinstance(s.timestep, torch.Tensor) else s.timestep, (C,)), dtc)
+    if not ok:
+        bad += 1
+        print('MISMATCH', dict(D=D, C=C, L=L, n=n, thin=thin, limit=limit, k=k, x0=x0, dt=dt), flush=True)
+    if case % 50 == 49:
+        print('%d cases, %d mismatches, %.0f s' % (case + 1, bad, time.time() - t0), flush=True)
+print('done: %d cases, %d mismatches' % (n_cases, bad))
+sys.exit(1 if bad else 0)

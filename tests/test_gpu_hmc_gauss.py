@@ -279,8 +279,10 @@ def test_c2_full_size_properties(device):
 # generic tier
 # --------------------------------------------------------------------------
 ROW_LENGTHS = [0, 1, 3, 7, 8, 9, 33, 127, 128, 129, 200, 258, 300, 768, 1000,
-               1023, 1024, 1025, 2049, 4096, 5000, 8192, 8193, 16384, 20000,
-               50000, 100003]
+               1023, 1024, 1025, 2049, 4096, 5000, 7688, 7689, 7700, 8191, 8192, 8193,
+               15892, 16383, 16384, 20000, 50000, 100003]
+# 7689..8191: the ragged lengths whose pairwise tree is 7 levels deep (65 leaves);
+# 15892 = 8192 + 7700: such a chunk after a full one
 
 
 @pytest.mark.parametrize('D', ROW_LENGTHS)

@@ -48,7 +48,7 @@ def synth(K, N, C, seed, xlim=1.0, tau=2.5):
 
 SHAPES = [(1, 1, 3), (17, 50, 5), (18, 33, 70), (34, 300, 9), (49, 200, 5), (50, 64, 3), (4, 20, 5), (4, 20, 70), (7, 37, 9), (8, 16, 64),
           (17, 100, 33), (33, 1000, 20), (33, 16384, 6), (36, 129, 3),
-          (48, 500, 4), (64, 8200, 2)]
+          (48, 500, 4), (64, 8200, 2), (5, 7700, 3), (3, 15892, 2)]
 
 
 @pytest.mark.parametrize('K,N,C', SHAPES)

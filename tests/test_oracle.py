@@ -8,7 +8,7 @@ from oracle import c_oracle
 from oracle import ref_numpy as R
 
 LENGTHS = list(range(0, 300)) + [511, 512, 768, 920, 1000, 1023, 1024, 2049,
-                                 4096, 5000, 16384, 100003]
+                                 4096, 5000, 7689, 7700, 8191, 15892, 16384, 100003]
 
 
 def test_pairwise_restatement_matches_np_sum_bitwise():
