@@ -20,7 +20,7 @@ rs = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 t0 = time.time()
 bad = 0
 for case in range(n_cases):
-    kind = rs.randint(5)
+    kind = rs.randint(6)
     if kind == 0:
         D = int(rs.randint(1, 130))
     elif kind == 1:
@@ -29,8 +29,10 @@ for case in range(n_cases):
         D = int(rs.choice([768, 1024]))
     elif kind == 3:
         D = int(rs.randint(1100, 8193))
-    else:
+    elif kind == 4:
         D = int(8 * rs.randint(1, 1025))
+    else:
+        D = int(rs.randint(7600, 40000))             # ragged 7-level trees, multi-chunk rows (generic tier)
     C = int(rs.choice([1, 2, 3, 7, 8, 9, 31, 64, 65, 200, 1030]))
     if D * C > 3e6:
         C = max(1, int(3e6 // D))
