@@ -117,6 +117,21 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit('bench.py needs a GPU (binf_amd has no CPU path)')
+    # a checkout without the built library: compile it (one rank per node), never fall back
+    lib_path = os.path.join(ROOT, 'binf_amd', 'csrc', 'libbinf_hip.so')
+    if not os.path.exists(lib_path):
+        if local_rank == 0:
+            import __graft_entry__
+            __graft_entry__.build()
+        else:
+            t_wait = time.time()
+            size = -1
+            while time.time() - t_wait < 900:   # present and no longer growing
+                time.sleep(3)
+                now = os.path.getsize(lib_path) if os.path.exists(lib_path) else -1
+                if now > 0 and now == size:
+                    break
+                size = now
     # BINF_BENCH_BACKEND=gloo: rehearsal of the multi-rank control flow on a box
     # with fewer GPUs than ranks (ranks then share devices); real runs use
     # nccl (= RCCL on ROCm), one rank per GPU.
