@@ -69,6 +69,8 @@ SIGNATURES = {
     'binf_poly_gauss_grad_f64': (_i32, [_vp, _vp, _vp, _f64, _vp, _vp, _vp,
                                         _i64, _i64, _i64, _i64, _vp]),
     'binf_gamma_precision_update_f64': (_i32, [_vp, _vp, _f64, _vp, _i64, _vp]),
+    'binf_pairdist_gauss_logp_f64': (_i32, [_vp, _vp, _vp, _vp, _f64, _vp, _vp, _i64,
+                                            _i64, _i64, _vp]),
     'binf_pairdist_forward_f64': (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i64,
                                          _vp]),
     'binf_pairdist_gauss_grad_f64': (_i32, [_vp, _vp, _f64, _vp, _vp, _i64,
@@ -472,6 +474,24 @@ def pairdist_forward(x, pair_i, pair_j):
         dptr(pair_j, torch.int32, P, 'pair_j'), dptr(out), C, D // 3, P,
         stream_handle(x.device))
     check(rc, 'binf_pairdist_forward_f64')
+    return out
+
+
+def pairdist_gauss_logp(x, pair_i, pair_j, ys, precision):
+    """Gaussian log-likelihood of the pair distances, fused (no [C x n_pairs]
+    intermediate)."""
+    C, D = _cd(x)
+    if D % 3:
+        raise ValueError('coordinates must be [n_chains, 3 * n_beads]')
+    P = pair_i.numel()
+    tau, tau_chain = _precision_args(precision, C, x.device)
+    out = torch.empty(C, dtype=torch.float64, device=x.device)
+    rc = lib().binf_pairdist_gauss_logp_f64(
+        dptr(x, numel=C * D, name='x'), dptr(pair_i, torch.int32, P, 'pair_i'),
+        dptr(pair_j, torch.int32, P, 'pair_j'), dptr(ys, numel=P, name='ys'), tau,
+        dptr(tau_chain, numel=C, name='precision'), dptr(out), C, D // 3, P,
+        stream_handle(x.device))
+    check(rc, 'binf_pairdist_gauss_logp_f64')
     return out
 
 

@@ -14,7 +14,7 @@
 // the chain's coordinates staged in LDS; the [3n x n(n-1)/2] Jacobian the
 // generic Likelihood path would need (200 MB per chain at n = 256) is never
 // formed.
-#include "common.hpp"
+#include "rowsum.hpp"
 
 namespace binf {
 
@@ -36,6 +36,46 @@ pairdist_forward_kernel(const double *x, const int32_t *I, const int32_t *J,
         out[c * n_pairs + p] = sqrt(s);
     }
 }
+
+// chi^2 of the restraints without the [C x n_pairs] distances ever reaching HBM:
+// element p of the row reduction is (d_p - y_p)^2 with d_p computed on the fly,
+// exactly as pairdist_forward_kernel + the error model's (mock - ys)**2 do.
+struct PairArgs {
+    const double *x;
+    const int32_t *I;
+    const int32_t *J;
+    const double *ys;
+    int64_t n_beads;
+};
+
+struct PairResid {
+    const double *xc;
+    const int32_t *I;
+    const int32_t *J;
+    const double *ys;
+    __device__ inline double operator()(int p) const
+    {
+        const int i = I[p], j = J[p];
+        const double a = xc[3 * i] - xc[3 * j];
+        const double b = xc[3 * i + 1] - xc[3 * j + 1];
+        const double e = xc[3 * i + 2] - xc[3 * j + 2];
+        const double s = (a * a + b * b) + e * e;
+        const double d = sqrt(s) - ys[p];
+        return d * d;
+    }
+};
+
+struct PairResidMake {
+    __device__ static inline PairResid make(const PairArgs &a, int64_t row)
+    {
+        PairResid f;
+        f.xc = a.x + row * 3 * a.n_beads;
+        f.I = a.I;
+        f.J = a.J;
+        f.ys = a.ys;
+        return f;
+    }
+};
 
 // Restraint weight of one pair: w = (d - y) / d = 1 - y / d with d = |x_i - x_j|.
 // IEEE sqrt + IEEE divide cost ~55 FP64 instructions per pair; instead
@@ -366,6 +406,31 @@ extern "C" int32_t binf_pairdist_forward_f64(const double *x, const int32_t *pai
         x, pair_i, pair_j, out, n_beads, n_pairs);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "pairdist_forward launch");
+    return 0;
+}
+
+extern "C" int32_t binf_pairdist_gauss_logp_f64(const double *x, const int32_t *pair_i,
+                                                const int32_t *pair_j, const double *ys,
+                                                double precision,
+                                                const double *precision_chain, double *out,
+                                                int64_t C, int64_t n_beads,
+                                                int64_t n_pairs, void *stream)
+{
+    if (C < 0 || n_beads < 0 || n_pairs < 0)
+        return fail(BINF_E_ARG, "pairdist_gauss_logp: negative size");
+    if (C == 0) return 0;
+    if (!out || (n_pairs > 0 && (!x || !pair_i || !pair_j || !ys)))
+        return fail(BINF_E_ARG, "pairdist_gauss_logp: null buffer");
+    PairArgs a;
+    a.x = x; a.I = pair_i; a.J = pair_j; a.ys = ys; a.n_beads = n_beads;
+    hipStream_t st = (hipStream_t)stream;
+    int32_t rc = row_reduce_launch<PairResidMake, PairArgs>(a, C, n_pairs, 1.0, out, st, true,
+                                                           "pairdist_gauss_logp");
+    if (rc) return rc;
+    gauss_logp_finish_kernel<<<dim3((unsigned)((C + 255) / 256)), 256, 0, st>>>(
+        out, precision, precision_chain, out, C, (double)n_pairs);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "pairdist_gauss_logp launch");
     return 0;
 }
 

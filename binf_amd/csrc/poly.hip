@@ -98,18 +98,6 @@ gauss_err_grad_kernel(const double *mock, const double *ys, double tau,
         out[c * N + n] = (mock[c * N + n] - ys[n]) * t;
 }
 
-// lp[c] = -0.5 * chi2[c] * tau_c + N * 0.5 * log(tau_c)     likelihood.py:54-57
-__global__ void gauss_logp_finish_kernel(const double *chi2, double tau,
-                                         const double *tau_chain, double *out,
-                                         int64_t C, double n_data)
-{
-    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
-    const double t = tau_chain ? tau_chain[c] : tau;
-    const double logZ = n_data * 0.5 * log(t);
-    out[c] = -0.5 * chi2[c] * t + logZ;
-}
-
 // tau[c] = g[c] / (-lp1[c] + prior_rate)                     samplers.py:34-51
 __global__ void gamma_update_kernel(const double *g, const double *lp1,
                                     double prior_rate, double *out, int64_t C)

@@ -151,4 +151,18 @@ static int32_t row_reduce_launch(const ARGS &args, int64_t C, int64_t D,
     return 0;
 }
 
+// Gaussian error model on top of a chi^2 row reduction (shared by the polynomial
+// and the pair-distance likelihoods)
+// lp[c] = -0.5 * chi2[c] * tau_c + N * 0.5 * log(tau_c)     likelihood.py:54-57
+static __global__ void gauss_logp_finish_kernel(const double *chi2, double tau,
+                                         const double *tau_chain, double *out,
+                                         int64_t C, double n_data)
+{
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const double t = tau_chain ? tau_chain[c] : tau;
+    const double logZ = n_data * 0.5 * log(t);
+    out[c] = -0.5 * chi2[c] * t + logZ;
+}
+
 }  // namespace binf

@@ -102,6 +102,23 @@ def make_distance_likelihood(target_distances, n_beads):
                       DistanceErrorModel(target_distances, n_beads))
 
 
+def native_log_prob(likelihood, fwm, em, fwm_vars, em_vars):
+    """Fused log-likelihood for the (DistanceForwardModel, DistanceErrorModel)
+    pair -- the same bits as forward model + error model, without the
+    ``[C x n_pairs]`` distances in HBM; None if the inputs are not device
+    tensors."""
+    fwm_vars, em_vars = dict(fwm_vars), dict(em_vars)
+    fwm._complete_variables(fwm_vars)
+    em._complete_variables(em_vars)
+    x = fwm_vars.get('coordinates')
+    if not (isinstance(x, torch.Tensor) and x.is_cuda) or 'precision' not in em_vars:
+        return None
+    x2 = x if x.dim() == 2 else x.reshape(1, -1)
+    I, J = fwm.pair_index(x.device)
+    return _native.pairdist_gauss_logp(x2.contiguous(), I, J, em.ys_device(x.device),
+                                       em_vars['precision'])
+
+
 def native_gradient(likelihood, fwm, em, fwm_vars, em_vars):
     """Fused all-pairs force for the (DistanceForwardModel, DistanceErrorModel)
     pair; None if the inputs are not device tensors."""

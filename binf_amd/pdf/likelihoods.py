@@ -98,6 +98,14 @@ class Likelihood(AbstractBinfPDF):
             out = native_poly.log_prob(self, pair, fwm_vars, em_vars)
             if out is not None:
                 return out
+        fs = getattr(self.forward_model, 'native_spec', lambda: None)()
+        es = getattr(self.error_model, 'native_spec', lambda: None)()
+        if fs is not None and es is not None and fs[0] == 'pairdist' and \
+                es[0] == 'gaussian_pairdist':
+            from binf_amd.example import distance
+            out = distance.native_log_prob(self, fs[1], es[1], fwm_vars, em_vars)
+            if out is not None:
+                return out
         mock_data = self.forward_model(**fwm_vars)
         return self.error_model.log_prob(mock_data=mock_data, **em_vars)
 

@@ -278,6 +278,16 @@ int32_t binf_pairdist_forward_f64(const double *x, const int32_t *pair_i,
                                   const int32_t *pair_j, double *out, int64_t C,
                                   int64_t n_beads, int64_t n_pairs, void *stream);
 
+/* Likelihood._evaluate_log_prob (binf/pdf/likelihoods.py:141-146) for the
+ * pair-distance forward model + Gaussian error model, fused: the same bits as
+ * binf_pairdist_forward_f64 followed by binf_gauss_err_logp_f64, without the
+ * [C x n_pairs] distances going through HBM. */
+int32_t binf_pairdist_gauss_logp_f64(const double *x, const int32_t *pair_i,
+                                     const int32_t *pair_j, const double *ys,
+                                     double precision, const double *precision_chain,
+                                     double *out, int64_t C, int64_t n_beads,
+                                     int64_t n_pairs, void *stream);
+
 /* Energy gradient of the Gaussian restraint likelihood,
  *   out[c, 3i+a] = precision_c * sum_{j != i} (d_ij - ymat[j][i]) (x_i - x_j)[a] / d_ij,
  * i.e. Likelihood._evaluate_gradient (binf/pdf/likelihoods.py:148-155) without

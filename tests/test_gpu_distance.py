@@ -168,3 +168,19 @@ def test_force_is_independent_of_the_batch_size(device):
     _native.pairdist_leapfrog(q1, p1, em.ymat_device(device), 2.0, (0.05, 0.0), True, 0.002, None, 4)
     _native.pairdist_leapfrog(q2, p2, em.ymat_device(device), 2.0, (0.05, 0.0), True, 0.002, None, 4)
     assert torch.equal(q1[:40], q2) and torch.equal(p1[:40], p2)
+
+
+@pytest.mark.parametrize('n,C', [(2, 3), (17, 5), (128, 4), (129, 3), (256, 6), (300, 2)])
+def test_fused_log_prob_is_forward_plus_error_model_bitwise(device, n, C):
+    """binf_pairdist_gauss_logp_f64 (distances never written to HBM) against
+    the two-kernel path it replaces, including n_pairs = 8128 / 8256 / 32640 /
+    44850 (one chunk, ragged second chunk, several chunks of the np.sum order)."""
+    ys, x = synth(n, C, 3 * n)
+    L = make_distance_likelihood(ys, n)
+    tx = dev_t(x, device)
+    taus = dev_t(np.random.RandomState(n).uniform(0.5, 3.0, size=C), device)
+    for prec in (1.0, 2.5, taus):
+        fused = L.log_prob(coordinates=tx, precision=prec)
+        mock = L.forward_model(coordinates=tx)
+        two = _native.gauss_err_logp(mock, L.error_model.ys_device(device), prec)
+        assert torch.equal(fused, two)
