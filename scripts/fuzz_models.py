@@ -4,7 +4,9 @@
   size (1-lane / 4-lane force variants);
 * MFMA polynomial gradient vs the numpy chain rule (1e-10);
 * fused small-data polynomial transition vs the per-step tier (E_before bit
-  for bit, state to 1e-10, same flags).
+  for bit, state to 1e-10, same flags);
+* Gibbs-within-HMC sweeps (fused transition + conjugate precision update)
+  through the class stack vs the single-chain numpy restatement.
   python scripts/fuzz_models.py [n_cases] [seed]"""
 import os
 import sys
@@ -22,7 +24,10 @@ from binf_amd.pdf import IsotropicGaussian
 from binf_amd.pdf.likelihoods import Likelihood
 from binf_amd.pdf.posteriors import Posterior
 from binf_amd.samplers.hmc import HMCSampler
+from binf_amd.example.samplers import make_hmc_sampler
+from binf_amd.samplers import BinfState
 from oracle import ref_distance as RD
+from oracle import ref_example as RE
 from oracle import ref_numpy as R
 
 dev = torch.device('cuda:0')
@@ -127,6 +132,41 @@ for case in range(n_cases):
             and np.allclose(qf, qg, rtol=1e-10, atol=1e-10 * np.abs(qg).max())
             and np.allclose(eaf, eag, rtol=1e-9, atol=0)):
         report('fused polynomial', K=K, N=N, C=Cs, lik=lik_name, prior='coefficients_prior' in priors)
+    # ---- Gibbs-within-HMC vs the single-chain numpy restatement ---------------
+    if case % 3 == 0:
+        K = int(rs.randint(1, 17))
+        N = int(rs.randint(2, 129))
+        Cg, S, L = int(rs.randint(1, 6)), int(rs.randint(1, 4)), int(rs.randint(1, 9))
+        xs = np.linspace(-1.5, 1.5, N)
+        ysp = R.polyval(xs, rs.standard_normal(K)) + 0.5 * rs.standard_normal(N)
+        post = Posterior({'points': Likelihood('points', ForwardModel(xs, POLYVAL), GaussianErrorModel(ysp))},
+                         {'precision_prior': GammaPrior(1.0, 0.2),
+                          'coefficients_prior': GaussianPrior(np.zeros(K), np.ones(K) * 5)})
+        c0 = 0.2 * rs.standard_normal((Cg, K))
+        tau0 = rs.uniform(0.5, 2.0, size=Cg)
+        p0, u = rs.standard_normal((S, Cg, K)), rs.uniform(size=(S, Cg))
+        gdraw = rs.gamma(R.gamma_shape(N, 1.0), size=(S, Cg))
+        dt = 0.02 / max(1.0, N / 20.0) / K
+        sweep = {'s': 0}
+        gips = make_hmc_sampler(post, dt, L, BinfState(dict(coefficients=t(c0), precision=t(tau0))),
+                                gamma=lambda sh, n_, d: t(gdraw[sweep['s']]))
+        hmc = gips.subsamplers['coefficients']
+        got = []
+        for si in range(S):
+            sweep['s'] = si
+            hmc.rng = type('Inject', (), {'normal': staticmethod(lambda shp, d, si=si: t(p0[si])),
+                                          'uniform': staticmethod(lambda n_, d, si=si: t(u[si]))})()
+            st = gips.sample()
+            got.append((st.variables['coefficients'].cpu().numpy().copy(),
+                        st.variables['precision'].cpu().numpy().copy(),
+                        hmc.last_move_accepted.cpu().numpy().copy()))
+        for c in range(Cg):
+            ref = RE.gibbs_hmc_chain(xs, ysp, c0[c], tau0[c], dt, L, p0[:, c], u[:, c], gdraw[:, c])
+            for si in range(S):
+                if not (bool(got[si][2][c]) == bool(ref['accepted'][si])
+                        and np.allclose(got[si][0][c], ref['coefficients'][si], rtol=1e-9, atol=1e-10)
+                        and abs(got[si][1][c] - ref['precision'][si]) <= 1e-9 * ref['precision'][si]):
+                    report('gibbs vs restatement', K=K, N=N, C=Cg, sweep=si, chain=c)
     if case % 20 == 19:
         print('%d cases, %d mismatches, %.0f s' % (case + 1, bad, time.time() - t0), flush=True)
 print('done: %d cases, %d mismatches' % (n_cases, bad))
