@@ -13,6 +13,7 @@ from binf_amd.example.distance import (DistanceErrorModel, DistanceForwardModel,
 from binf_amd.pdf import IsotropicGaussian
 from binf_amd.pdf.posteriors import Posterior
 from binf_amd.samplers.hmc import HMCSampler
+from conftest import golden_files, load_golden
 from oracle import ref_distance as RD
 from oracle import ref_numpy as R
 
@@ -184,3 +185,30 @@ def test_fused_log_prob_is_forward_plus_error_model_bitwise(device, n, C):
         mock = L.forward_model(coordinates=tx)
         two = _native.gauss_err_logp(mock, L.error_model.ys_device(device), prec)
         assert torch.equal(fused, two)
+
+
+@pytest.mark.parametrize('path', golden_files('dist_'))
+def test_distance_posterior_reproduces_golden_vectors(device, path):
+    """Committed fixtures (tests/golden/dist_*.npz): likelihood log-prob bit for
+    bit, force to 1e-10, consecutive HMC transitions with the recorded draws."""
+    g = load_golden(path)
+    n, L, dt = int(g['n_beads']), int(g['L']), float(g['timestep'])
+    tau, pk = float(g['precision']), float(g['prior_k'])
+    lik = make_distance_likelihood(g['ys'], n)
+    x0 = dev_t(g['q0'], device)
+    assert np.array_equal(lik.log_prob(coordinates=x0, precision=tau).cpu().numpy(),
+                          g['likelihood_log_prob'])
+    gr = lik.gradient(coordinates=x0, precision=tau).cpu().numpy()
+    assert np.abs(gr - g['likelihood_gradient']).max() <= 1e-10 * np.abs(g['likelihood_gradient']).max()
+    priors = {}
+    if pk != 0.0:
+        priors['coordinates_prior'] = IsotropicGaussian(pk, 0.0, name='coordinates_prior',
+                                                        variable_name='coordinates')
+    cond = Posterior({lik.name: lik}, priors).conditional_factory(precision=tau)
+    s = HMCSampler(cond, x0, dt, L, variable_name='coordinates')
+    for i in range(g['u'].shape[0]):
+        out = s.sample(p0=dev_t(g['p0'][i], device), u=dev_t(g['u'][i], device)).cpu().numpy()
+        assert np.array_equal(s.last_move_accepted.cpu().numpy(), g['accepted'][i].astype(bool))
+        assert np.abs(out - g['q_out'][i]).max() <= 1e-9 * np.abs(g['q_out'][i]).max()
+        assert np.allclose(s.last_e_before.cpu().numpy(), g['e_before'][i], rtol=1e-9, atol=0)
+        assert np.allclose(s.last_e_after.cpu().numpy(), g['e_after'][i], rtol=1e-8, atol=0)

@@ -19,6 +19,7 @@ from binf_amd.example.samplers import (GammaSampler, RWMCSampler,
                                        make_hmc_sampler, make_sampler)
 from binf_amd.samplers import BinfState
 from binf_amd.samplers.hmc import HMCSampler
+from conftest import golden_files, load_golden
 from oracle import ref_example as RE
 from oracle import ref_numpy as R
 
@@ -427,3 +428,39 @@ def test_example_script_counterpart_recovers_the_coefficients(device):
     mean = coeffs.reshape(-1, 4).mean(0).cpu().numpy()
     assert np.abs(mean - lsq).max() < 0.25
     assert 0.5 < float(prec.mean()) < 6.0
+
+
+@pytest.mark.parametrize('path', golden_files('poly_'))
+def test_gibbs_within_hmc_reproduces_golden_vectors(device, path):
+    """Committed fixtures (tests/golden/poly_*.npz: Gibbs sweeps of several
+    chains, draws recorded from the reference's np.random consumption order;
+    poly_c1_example is example_script.py's own data and start) through the
+    class stack: Posterior -> Gibbs -> fused HMC transition + conjugate update."""
+    g = load_golden(path)
+    K, L, dt = int(g['K']), int(g['L']), float(g['timestep'])
+    S, C = g['u'].shape
+    from binf_amd.pdf.likelihoods import Likelihood
+    from binf_amd.pdf.posteriors import Posterior
+    lik = Likelihood('points', ForwardModel(g['xs'], POLYVAL), GaussianErrorModel(g['ys']))
+    post = Posterior({lik.name: lik}, {'precision_prior': GammaPrior(1.0, 0.2),
+                                       'coefficients_prior': GaussianPrior(np.zeros(K), np.ones(K) * 5)})
+    start = BinfState(dict(coefficients=dev_t(g['coefficients0'], device),
+                           precision=dev_t(g['precision0'], device)))
+    sweep = {'s': 0}
+    gips = make_hmc_sampler(post, dt, L, start,
+                            gamma=lambda sh, n, d: dev_t(g['gamma'][sweep['s']], d))
+    hmc = gips.subsamplers['coefficients']
+    assert gips.subsamplers['precision']._calculate_shape() == float(g['gamma_shape'])
+    for s in range(S):
+        sweep['s'] = s
+        hmc.rng = type('Inject', (), {
+            'normal': staticmethod(lambda shp, d, s=s: dev_t(g['p0'][s], d)),
+            'uniform': staticmethod(lambda n, d, s=s: dev_t(g['u'][s], d))})()
+        state = gips.sample()
+        assert np.array_equal(hmc.last_move_accepted.cpu().numpy(), g['accepted'][s].astype(bool)), s
+        c = state.variables['coefficients'].cpu().numpy()
+        t = state.variables['precision'].cpu().numpy()
+        assert np.allclose(c, g['coefficients'][s], rtol=1e-9, atol=1e-10)
+        assert np.allclose(t, g['precision'][s], rtol=1e-9, atol=0)
+        assert np.allclose(hmc.last_e_before.cpu().numpy(), g['e_before'][s], rtol=1e-9, atol=0)
+        assert np.allclose(hmc.last_e_after.cpu().numpy(), g['e_after'][s], rtol=1e-8, atol=0)

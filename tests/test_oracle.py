@@ -126,3 +126,34 @@ def test_golden_rng_stream_order():
         for i in range(g['p0'].shape[0]):
             assert np.array_equal(np.random.normal(size=int(g['D'])), g['p0'][i, c])
             assert np.random.uniform() == g['u'][i, c]
+
+
+@pytest.mark.parametrize('name', ['poly_c1_example', 'poly_k7_n37', 'poly_k16_n128'])
+def test_polynomial_gibbs_golden_is_what_the_restatement_gives(name):
+    """The committed Gibbs-within-HMC fixtures (BASELINE C1 / C4 at CPU size)
+    are the restatement's outputs for the reference's own stream consumption."""
+    from oracle import gen_golden as G
+    g = load_golden(golden_files(name)[0])
+    spec = [s for s in G.POLY_SETS if s[0] == name][0]
+    r = G.run_poly_set(*spec[1:])
+    for k in ('xs', 'ys', 'p0', 'u', 'gamma', 'coefficients', 'precision', 'accepted',
+              'e_before', 'e_after'):
+        assert np.array_equal(r[k], g[k]), k
+    if name == 'poly_c1_example':
+        # example_script.py:17-26 with np.random.seed(0)
+        np.random.seed(0)
+        xs = np.linspace(-2, 2, 20)
+        ys = np.random.normal(loc=np.polynomial.polynomial.polyval(xs, [2.0, -4.0, 1.0, 1.5]),
+                              scale=1.0 / np.sqrt(2.5))
+        assert np.array_equal(g['xs'], xs) and np.array_equal(g['ys'], ys)
+        assert 0 < g['accepted'].mean() < 1
+
+
+@pytest.mark.parametrize('name', ['dist_n12', 'dist_n40'])
+def test_distance_golden_is_what_the_restatement_gives(name):
+    from oracle import gen_golden as G
+    g = load_golden(golden_files(name)[0])
+    spec = [s for s in G.DIST_SETS if s[0] == name][0]
+    r = G.run_dist_set(*spec[1:])
+    for k in r:
+        assert np.array_equal(r[k], g[k]), k
