@@ -80,6 +80,7 @@ POLY_SETS = [
     ('poly_c1_example', 4, 20, 4, 5, 50, 0.02, 300),
     ('poly_k7_n37',     7, 37, 3, 3, 10, 0.004, 310),
     ('poly_k16_n128',  16, 128, 2, 2, 4, 0.0005, 320),
+    ('poly_k33_n16384', 33, 16384, 2, 2, 5, 1e-6, 330),      # BASELINE C3's shape (per-step tier)
 ]
 
 # name, n_beads, C, ncalls, L, dt, precision, prior_k, seed  -- pair-distance model (C5, build-defined)

@@ -128,7 +128,8 @@ def test_golden_rng_stream_order():
             assert np.random.uniform() == g['u'][i, c]
 
 
-@pytest.mark.parametrize('name', ['poly_c1_example', 'poly_k7_n37', 'poly_k16_n128'])
+@pytest.mark.parametrize('name', ['poly_c1_example', 'poly_k7_n37', 'poly_k16_n128',
+                                  'poly_k33_n16384'])
 def test_polynomial_gibbs_golden_is_what_the_restatement_gives(name):
     """The committed Gibbs-within-HMC fixtures (BASELINE C1 / C4 at CPU size)
     are the restatement's outputs for the reference's own stream consumption."""
