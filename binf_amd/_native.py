@@ -53,6 +53,8 @@ SIGNATURES = {
                                       _i32, _vp]),
     'binf_leapfrog_drift_f64': (_i32, [_vp, _vp, _f64, _vp, _i64, _i64, _i32,
                                        _vp]),
+    'binf_leapfrog_kick_drift_f64': (_i32, [_vp, _vp, _vp, _f64, _vp, _i64, _i64,
+                                            _i32, _vp]),
     'binf_gauss_grad_f64': (_i32, [_vp, _vp, _f64, _f64, _i64, _i64, _vp]),
     'binf_accept_select_f64': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                       _i32, _f64, _f64, _i64, _i64, _vp]),
@@ -235,6 +237,17 @@ def leapfrog_kick(p, grad, timestep, dt_chain=None, half=False,
         float(timestep), dptr(dt_chain, numel=C, name='dt_chain'),
         int(bool(half)), C, D, int(mode), stream_handle(p.device))
     check(rc, 'binf_leapfrog_kick_f64')
+
+
+def leapfrog_kick_drift(q, p, grad, timestep, dt_chain=None, mode=MODE_EXACT):
+    """p -= dt * grad; q += p * dt  (kick then drift, one pass)."""
+    C, D = _cd(q)
+    rc = lib().binf_leapfrog_kick_drift_f64(
+        dptr(q, numel=C * D, name='q'), dptr(p, numel=C * D, name='p'),
+        dptr(grad, numel=C * D, name='grad'), float(timestep),
+        dptr(dt_chain, numel=C, name='dt_chain'), C, D, int(mode),
+        stream_handle(q.device))
+    check(rc, 'binf_leapfrog_kick_drift_f64')
 
 
 def leapfrog_drift(q, p, timestep, dt_chain=None, mode=MODE_EXACT):

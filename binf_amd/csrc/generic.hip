@@ -84,6 +84,26 @@ __global__ void __launch_bounds__(256) ew_kernel(const EwArgs a)
     }
 }
 
+// One interior leapfrog step after its gradient call, hmc.py:120 followed by the
+// next iteration's :119 (or the closing :122): p -= dt * grad; q += p * dt.
+// The same two roundings per element as kick then drift, one pass over memory.
+template <bool FMA>
+__global__ void __launch_bounds__(256)
+kick_drift_kernel(double *q, double *p, const double *g, double timestep,
+                  const double *dt_chain, int64_t D)
+{
+    const int64_t c = blockIdx.y;
+    const double dt = dt_chain ? dt_chain[c] : timestep;
+    double *qc = q + c * D, *pc = p + c * D;
+    const double *gc = g + c * D;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < D;
+         i += (int64_t)gridDim.x * 256) {
+        const double pn = FMA ? __builtin_fma(-dt, gc[i], pc[i]) : pc[i] - dt * gc[i];
+        pc[i] = pn;
+        qc[i] = FMA ? __builtin_fma(pn, dt, qc[i]) : qc[i] + pn * dt;
+    }
+}
+
 // ---------------------------------------------------------------------------
 // Metropolis accept, step-size adaption, select           hmc.py:151-164,188-191
 // ---------------------------------------------------------------------------
@@ -246,6 +266,35 @@ extern "C" int32_t binf_leapfrog_drift_f64(double *q, const double *p,
 {
     return ew_launch(EW_DRIFT, q, p, timestep, dt_chain, 0, 0.0, 0.0, C, D, mode,
                      stream, "leapfrog_drift");
+}
+
+extern "C" int32_t binf_leapfrog_kick_drift_f64(double *q, double *p, const double *grad,
+                                                double timestep, const double *dt_chain,
+                                                int64_t C, int64_t D, int32_t mode,
+                                                void *stream)
+{
+    if (C < 0 || D < 0) return fail(BINF_E_ARG, "leapfrog_kick_drift: negative size");
+    if (mode != BINF_MODE_EXACT && mode != BINF_MODE_FMA)
+        return fail(BINF_E_ARG, "leapfrog_kick_drift: unknown mode %d", mode);
+    if (C == 0 || D == 0) return 0;
+    if (!q || !p || !grad) return fail(BINF_E_ARG, "leapfrog_kick_drift: null buffer");
+    hipStream_t st = (hipStream_t)stream;
+    int64_t bx = (D + 255) / 256;
+    if (bx > 64) bx = 64;
+    for (int64_t c0 = 0; c0 < C; c0 += 65535) {            // gridDim.y limit
+        const int64_t cn = (C - c0 < 65535) ? C - c0 : 65535;
+        const dim3 grid((unsigned)bx, (unsigned)cn);
+        const double *dtc = dt_chain ? dt_chain + c0 : nullptr;
+        if (mode == BINF_MODE_FMA)
+            kick_drift_kernel<true><<<grid, 256, 0, st>>>(q + c0 * D, p + c0 * D, grad + c0 * D,
+                                                         timestep, dtc, D);
+        else
+            kick_drift_kernel<false><<<grid, 256, 0, st>>>(q + c0 * D, p + c0 * D, grad + c0 * D,
+                                                          timestep, dtc, D);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "leapfrog_kick_drift");
+    return 0;
 }
 
 extern "C" int32_t binf_gauss_grad_f64(const double *x, double *out, double k,

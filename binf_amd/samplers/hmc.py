@@ -321,11 +321,13 @@ class HMCSampler(object):
             _native.pairdist_leapfrog(q2, p2, em.ymat_device(q2.device), precision,
                                       prior, prior_first, dt, dtc, nsteps, mode)
             return q, p
+        # half kick, drift, (nsteps - 1) x [gradient, kick + next drift], half kick:
+        # the reference's sequence (hmc.py:116-123) with every interior kick
+        # and the drift that follows it in one pass over memory
         _native.leapfrog_kick(p2, grad(q2), dt, dtc, half=True, mode=mode)
-        for _ in range(nsteps - 1):
-            _native.leapfrog_drift(q2, p2, dt, dtc, mode=mode)
-            _native.leapfrog_kick(p2, grad(q2), dt, dtc, mode=mode)
         _native.leapfrog_drift(q2, p2, dt, dtc, mode=mode)
+        for _ in range(nsteps - 1):
+            _native.leapfrog_kick_drift(q2, p2, grad(q2), dt, dtc, mode=mode)
         _native.leapfrog_kick(p2, grad(q2), dt, dtc, half=True, mode=mode)
         return q, p
 

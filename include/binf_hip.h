@@ -149,6 +149,14 @@ int32_t binf_leapfrog_drift_f64(double *q, const double *p, double timestep,
                                 const double *dt_chain, int64_t C, int64_t D,
                                 int32_t mode, void *stream);
 
+/* p[c,:] -= dt * grad[c,:];  q[c,:] += p[c,:] * dt    hmc.py:120 then :119 / :122
+ * (one interior leapfrog step after its gradient call; the same roundings as
+ * binf_leapfrog_kick_f64 followed by binf_leapfrog_drift_f64, one pass). */
+int32_t binf_leapfrog_kick_drift_f64(double *q, double *p, const double *grad,
+                                     double timestep, const double *dt_chain,
+                                     int64_t C, int64_t D, int32_t mode,
+                                     void *stream);
+
 /* out = k * (x - x0): energy gradient of TestHO, binf/pdf/__init__.py:187-191 */
 int32_t binf_gauss_grad_f64(const double *x, double *out, double k, double x0,
                             int64_t C, int64_t D, void *stream);
