@@ -1,0 +1,157 @@
+"""Memory-safety checks without a GPU sanitizer (not available on this pool):
+every buffer handed to a kernel is a window inside a larger allocation whose
+surroundings are NaN (doubles) / 0xAB (bytes).  An out-of-bounds WRITE shows up
+as a changed guard zone; an out-of-bounds READ that reaches the arithmetic
+turns results into NaN or makes them differ from the same call on plain
+tensors.  Shapes are ragged on purpose (partial waves, partial tiles, tails)."""
+import numpy as np
+import pytest
+import torch
+
+from binf_amd import _native
+
+pytestmark = pytest.mark.gpu
+PAD = 1024
+
+
+class Guarded(object):
+    def __init__(self, device):
+        self.device = device
+        self.zones = []
+
+    def __call__(self, a, dtype=torch.float64):
+        a = np.ascontiguousarray(a)
+        n = a.size
+        if dtype == torch.float64:
+            buf = torch.full((n + 2 * PAD,), float('nan'), dtype=dtype, device=self.device)
+        else:
+            buf = torch.full((n + 2 * PAD,), 0xAB if dtype == torch.uint8 else -0x5555, dtype=dtype,
+                             device=self.device)
+        win = buf[PAD:PAD + n]
+        win.copy_(torch.from_numpy(a.reshape(-1)).to(self.device).to(dtype))
+        self.zones.append((buf, n, dtype))
+        return win.view(a.shape)
+
+    def check(self):
+        torch.cuda.synchronize()
+        for buf, n, dtype in self.zones:
+            for z in (buf[:PAD], buf[PAD + n:]):
+                if dtype == torch.float64:
+                    assert bool(torch.isnan(z).all()), 'guard zone overwritten'
+                else:
+                    ref = 0xAB if dtype == torch.uint8 else -0x5555
+                    assert bool((z == ref).all()), 'guard zone overwritten'
+
+
+def plain(a, device, dtype=torch.float64):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(device).to(dtype)
+
+
+@pytest.mark.parametrize('D,C,n', [(1, 1, 1), (7, 3, 2), (33, 9, 3), (129, 5, 2), (258, 3, 2),
+                                   (768, 5, 3), (1000, 3, 2), (1024, 1, 3), (1024, 1031, 2),
+                                   (1024, 2049, 1), (1025, 3, 2), (3000, 2, 2), (8192, 1, 1),
+                                   (7700, 2, 1)])
+def test_gaussian_hmc_kernels_stay_inside_their_buffers(device, D, C, n):
+    rs = np.random.RandomState(D + C)
+    q0, p0, u = rs.standard_normal((C, D)), rs.standard_normal((n, C, D)), rs.uniform(size=(n, C))
+    outs = []
+    for make in (Guarded(device), None):
+        t = make if make is not None else (lambda a, dtype=torch.float64: plain(a, device, dtype))
+        tq, tp, tu = t(q0), t(p0), t(u)
+        qo, smp = t(np.zeros((C, D))), t(np.zeros((n, C, D)))
+        acc = t(np.zeros((n, C), dtype=np.uint8), torch.uint8)
+        nacc = t(np.zeros(C, dtype=np.int64), torch.int64)
+        eb, ea = t(np.zeros((n, C))), t(np.zeros((n, C)))
+        dtc = t(np.full(C, 0.2))
+        if D <= 8192 and _native.pairwise_tree_height(D) <= 6:
+            _native.hmc_sample_n_gauss(tq, tp, tu, qo, smp, acc, nacc, eb, ea, 0.2, dtc, 5, n, 1,
+                                       2.5, 0.3, n, 1.05, 0.95, _native.MODE_EXACT)
+        else:                                   # generic-tier kernels
+            g = t(np.zeros((C, D)))
+            _native.lib()
+            qo.copy_(tq)
+            for i in range(n):
+                rc = _native.lib().binf_gauss_grad_f64(qo.data_ptr(), g.data_ptr(), 2.5, 0.3, C, D,
+                                                       _native.stream_handle(device))
+                assert rc == 0
+                _native.leapfrog_kick(tp[i], g, 0.2, dtc, half=True)
+                _native.leapfrog_kick_drift(qo, tp[i], g, 0.2, dtc)
+                eb[i].copy_(_native.row_sum(qo, _native.ROW_SUMSQ_SHIFT, shift=0.3, scale=-1.25))
+                ea[i].copy_(_native.row_sum(tp[i], _native.ROW_SUMSQ, scale=0.5))
+                _native.accept_select(qo, tq, eb[i], ea[i], tu[i], qo, acc[i], nacc, dtc, True, 1.05, 0.95)
+            smp.copy_(tp)
+        if make is not None:
+            make.check()
+        outs.append([x.clone().cpu() for x in (qo, smp, acc, nacc, eb, ea, dtc)])
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+        assert not torch.isnan(a.double()).any()
+
+
+@pytest.mark.parametrize('K,N,C', [(1, 1, 1), (4, 20, 70), (17, 100, 33), (33, 1000, 20), (33, 4099, 130),
+                                   (34, 257, 65), (50, 64, 3), (64, 8200, 2), (5, 7700, 3)])
+def test_polynomial_kernels_stay_inside_their_buffers(device, K, N, C):
+    rs = np.random.RandomState(K + N)
+    xs, ys = np.linspace(-1, 1, N), rs.standard_normal(N)
+    th, tau = 0.3 * rs.standard_normal((C, K)), rs.uniform(0.5, 2, size=C)
+    A = np.vstack([xs ** i for i in range(K)])
+    outs = []
+    for make in (Guarded(device), None):
+        t = make if make is not None else (lambda a, dtype=torch.float64: plain(a, device, dtype))
+        tth, txs, tys, ttau, tA = t(th), t(xs), t(ys), t(tau), t(A)
+        r = [_native.poly_forward(tth, txs), _native.poly_gauss_logp(tth, txs, tys, ttau),
+             _native.poly_gauss_grad(tth, tA, tys, ttau)]
+        if make is not None:
+            make.check()
+        outs.append([x.clone().cpu() for x in r])
+    for a, b in zip(*outs):
+        assert torch.equal(a, b) and not torch.isnan(a).any()
+
+
+@pytest.mark.parametrize('K,N,C', [(1, 1, 1), (4, 20, 70), (9, 100, 65), (16, 128, 3)])
+def test_fused_polynomial_transition_stays_inside_its_buffers(device, K, N, C):
+    rs = np.random.RandomState(K * N)
+    xs, ys = np.linspace(-1, 1, N), rs.standard_normal(N)
+    q0, p0, u = 0.2 * rs.standard_normal((C, K)), rs.standard_normal((C, K)), rs.uniform(size=C)
+    tau, lp = rs.uniform(0.5, 2, size=C), rs.standard_normal(C)
+    outs = []
+    for make in (Guarded(device), None):
+        t = make if make is not None else (lambda a, dtype=torch.float64: plain(a, device, dtype))
+        qo = t(np.zeros((C, K)))
+        acc = t(np.zeros(C, dtype=np.uint8), torch.uint8)
+        nacc = t(np.zeros(C, dtype=np.int64), torch.int64)
+        eb, ea, dtc = t(np.zeros(C)), t(np.zeros(C)), t(np.full(C, 1e-3))
+        _native.hmc_sample_poly(t(q0), t(p0), t(u), qo, acc, nacc, eb, ea, t(xs), t(ys), t(tau),
+                                t(np.zeros(K)), t(np.full(K, 5.0)), True, t(lp), t(lp), 1e-3, dtc,
+                                4, True, 1.05, 0.95)
+        if make is not None:
+            make.check()
+        outs.append([x.clone().cpu() for x in (qo, acc, nacc, eb, ea, dtc)])
+    for a, b in zip(*outs):
+        assert torch.equal(a, b) and not torch.isnan(a.double()).any()
+
+
+@pytest.mark.parametrize('n,C', [(2, 1), (3, 5), (17, 9), (100, 3), (256, 2), (257, 2), (513, 2), (1030, 1)])
+def test_distance_kernels_stay_inside_their_buffers(device, n, C):
+    rs = np.random.RandomState(n)
+    x = rs.standard_normal((C, 3 * n)) * 2
+    I, J = np.triu_indices(n, 1)
+    ys = np.abs(rs.standard_normal(I.size)) + 0.5
+    ym = np.zeros((n, n)); ym[I, J] = ys; ym[J, I] = ys
+    tau, p = rs.uniform(0.5, 2, size=C), rs.standard_normal((C, 3 * n))
+    outs = []
+    for make in (Guarded(device), None):
+        t = make if make is not None else (lambda a, dtype=torch.float64: plain(a, device, dtype))
+        tx, tI, tJ = t(x), t(I.astype(np.int32), torch.int32), t(J.astype(np.int32), torch.int32)
+        tys, tym, ttau = t(ys), t(ym), t(tau)
+        r = [_native.pairdist_forward(tx, tI, tJ), _native.pairdist_gauss_logp(tx, tI, tJ, tys, ttau),
+             _native.pairdist_gauss_grad(tx, tym, ttau)]
+        if n <= 1024:
+            q2, p2 = t(x), t(p)
+            _native.pairdist_leapfrog(q2, p2, tym, ttau, (0.05, 0.1), True, 0.002, None, 3)
+            r += [q2, p2]
+        if make is not None:
+            make.check()
+        outs.append([z.clone().cpu() for z in r])
+    for a, b in zip(*outs):
+        assert torch.equal(a, b) and not torch.isnan(a).any()
