@@ -155,3 +155,24 @@ def test_distance_kernels_stay_inside_their_buffers(device, n, C):
         outs.append([z.clone().cpu() for z in r])
     for a, b in zip(*outs):
         assert torch.equal(a, b) and not torch.isnan(a).any()
+
+
+@pytest.mark.parametrize('n', [1, 2, 3, 7, 8, 9, 63, 64, 65, 511, 513, 1001, 4097, 100003])
+@pytest.mark.parametrize('kind', ['uniform', 'normal', 'normal_zig', 'gamma'])
+def test_rng_kernels_stay_inside_their_buffers(device, kind, n):
+    """The generators store pairs / blocks of draws; odd and tiny lengths must
+    not spill, and the window start here is only 8-byte aligned relative to
+    the 16-byte stores' natural alignment when PAD is odd-sized (it is not:
+    a second window at an odd element offset covers that)."""
+    for shift in (0, 1):
+        g = Guarded(device)
+        buf = g(np.zeros(n + shift))
+        out = buf[shift:]                       # 8-byte aligned, possibly not 16-byte aligned
+        _native.rng_fill(kind, out, 123, 4 * n, shape=10.0)
+        g.check()
+        assert bool(torch.isfinite(out).all())
+        if shift:
+            assert float(buf[0]) == 0.0         # the element before the window
+        ref = torch.empty(n, dtype=torch.float64, device=device)
+        _native.rng_fill(kind, ref, 123, 4 * n, shape=10.0)
+        assert torch.equal(out, ref)
