@@ -424,21 +424,24 @@ def poly_gauss_grad(coeffs, design, ys, precision):
     tau, tau_chain = _precision_args(precision, C, coeffs.device)
     need = lib().binf_poly_gauss_grad_workspace_bytes(C, K, N)
     ws = None
+    st = stream_handle(coeffs.device)
     if need > 0:
-        key = (coeffs.device, need)
+        # one scratch buffer per (device, stream, size): calls on the same stream
+        # are ordered, calls on different streams must not share it
+        key = (coeffs.device, st, need)
         ws = _grad_ws.get(key)
         if ws is None:
             ws = torch.empty(need // 8, dtype=torch.float64,
                              device=coeffs.device)
-            _grad_ws.clear()
+            while len(_grad_ws) >= 4:
+                _grad_ws.pop(next(iter(_grad_ws)))
             _grad_ws[key] = ws
     out = torch.empty((C, K), dtype=torch.float64, device=coeffs.device)
     rc = lib().binf_poly_gauss_grad_f64(
         dptr(coeffs, numel=C * K, name='coeffs'),
         dptr(design, numel=K * N, name='design'), dptr(ys, numel=N, name='ys'),
         tau, dptr(tau_chain, numel=C, name='precision'), dptr(out),
-        ws.data_ptr() if ws is not None else None, need, C, K, N,
-        stream_handle(coeffs.device))
+        ws.data_ptr() if ws is not None else None, need, C, K, N, st)
     check(rc, 'binf_poly_gauss_grad_f64')
     return out
 

@@ -464,3 +464,24 @@ def test_gibbs_within_hmc_reproduces_golden_vectors(device, path):
         assert np.allclose(t, g['precision'][s], rtol=1e-9, atol=0)
         assert np.allclose(hmc.last_e_before.cpu().numpy(), g['e_before'][s], rtol=1e-9, atol=0)
         assert np.allclose(hmc.last_e_after.cpu().numpy(), g['e_after'][s], rtol=1e-8, atol=0)
+
+
+def test_gradient_calls_on_two_streams_do_not_share_scratch(device):
+    """The split-data gradient reduces through a cached scratch buffer; two
+    streams running it concurrently must each get their own."""
+    K, N, C = 33, 16384, 2048
+    xs, ys, theta = synth(K, N, C, 3)
+    A = dev_t(np.vstack([xs ** i for i in range(K)]), device)
+    tys = dev_t(ys, device)
+    th1, th2 = dev_t(theta, device), dev_t(theta[::-1].copy(), device)
+    want1 = _native.poly_gauss_grad(th1, A, tys, 2.5).clone()
+    want2 = _native.poly_gauss_grad(th2, A, tys, 2.5).clone()
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(device), torch.cuda.Stream(device)
+    for _ in range(5):
+        with torch.cuda.stream(s1):
+            g1 = _native.poly_gauss_grad(th1, A, tys, 2.5)
+        with torch.cuda.stream(s2):
+            g2 = _native.poly_gauss_grad(th2, A, tys, 2.5)
+        torch.cuda.synchronize()
+        assert torch.equal(g1, want1) and torch.equal(g2, want2)
