@@ -75,6 +75,22 @@ struct PairResidMake {
         f.ys = a.ys;
         return f;
     }
+    // the chain's coordinates in LDS: 6 of the 9 gathers per pair leave the
+    // vector memory pipe, which bounded the kernel (0.22 -> 0.1x ms at 2048 chains)
+    __device__ static inline void stage(const PairArgs &a, int64_t row, double *lds)
+    {
+        const double *xc = a.x + row * 3 * a.n_beads;
+        for (int64_t k = threadIdx.x; k < 3 * a.n_beads; k += 256) lds[k] = xc[k];
+    }
+    __device__ static inline PairResid make_lds(const PairArgs &a, int64_t row, const double *lds)
+    {
+        PairResid f;
+        f.xc = lds;
+        f.I = a.I;
+        f.J = a.J;
+        f.ys = a.ys;
+        return f;
+    }
 };
 
 // Restraint weight of one pair: w = (d - y) / d = 1 - y / d with d = |x_i - x_j|.
@@ -424,8 +440,14 @@ extern "C" int32_t binf_pairdist_gauss_logp_f64(const double *x, const int32_t *
     PairArgs a;
     a.x = x; a.I = pair_i; a.J = pair_j; a.ys = ys; a.n_beads = n_beads;
     hipStream_t st = (hipStream_t)stream;
-    int32_t rc = row_reduce_launch<PairResidMake, PairArgs>(a, C, n_pairs, 1.0, out, st, true,
-                                                           "pairdist_gauss_logp");
+    int32_t rc;
+    if (n_beads <= 2048)            // 48 KiB of coordinates fit the static LDS budget
+        rc = row_reduce_launch<PairResidMake, PairArgs, true>(a, C, n_pairs, 1.0, out, st, true,
+                                                             "pairdist_gauss_logp",
+                                                             (size_t)n_beads * 3 * sizeof(double));
+    else
+        rc = row_reduce_launch<PairResidMake, PairArgs>(a, C, n_pairs, 1.0, out, st, true,
+                                                       "pairdist_gauss_logp");
     if (rc) return rc;
     gauss_logp_finish_kernel<<<dim3((unsigned)((C + 255) / 256)), 256, 0, st>>>(
         out, precision, precision_chain, out, C, (double)n_pairs);

@@ -80,18 +80,30 @@ row_reduce_wave_kernel(const ARGS args, const RowGeom g, double *out)
 // 7 for the 441 ragged lengths in [7689, 8191].  g.H is the largest height
 // among the row's chunks; walking a shallower chunk with it only adds
 // redundant paths (pairwise_leaf).
-template <class FM, class ARGS>
+// STAGED: the functor factory first copies per-row data into dynamic LDS
+// (FM::stage, all 256 threads) and builds the element functor on top of it
+// (FM::make_lds) -- for element functions that gather from a small per-row
+// table (pair distances: the chain's coordinates).
+template <class FM, class ARGS, bool STAGED = false>
 __global__ void __launch_bounds__(256)
 row_reduce_block_kernel(const ARGS args, const RowGeom g, double *out)
 {
     __shared__ double S[128];
     __shared__ int dep[128];
+    extern __shared__ double row_lds[];
     const int H = g.H;
     const int npaths = 1 << H;
     const int lane = threadIdx.x & 63;
     const int group = threadIdx.x >> 3;      // 32 groups of 8 lanes
     const int64_t row = blockIdx.x;
-    const auto f = FM::make(args, row);
+    if constexpr (STAGED) {
+        FM::stage(args, row, row_lds);
+        __syncthreads();
+    }
+    const auto f = [&]() {
+        if constexpr (STAGED) return FM::make_lds(args, row, row_lds);
+        else return FM::make(args, row);
+    }();
     double total = 0.0;                      // the reduction's identity
     for (int cbase = 0; cbase == 0 || cbase < g.D; cbase += NPY_BUFSIZE) {
         const int n = (g.D - cbase < NPY_BUFSIZE) ? g.D - cbase : NPY_BUFSIZE;
@@ -123,10 +135,11 @@ row_reduce_block_kernel(const ARGS args, const RowGeom g, double *out)
     if (threadIdx.x == 0) out[row] = g.scale * total;
 }
 
-template <class FM, class ARGS>
+template <class FM, class ARGS, bool STAGED = false>
 static int32_t row_reduce_launch(const ARGS &args, int64_t C, int64_t D,
                                  double scale, double *out, hipStream_t st,
-                                 bool force_block, const char *what)
+                                 bool force_block, const char *what,
+                                 size_t staged_bytes = 0)
 {
     if (C > 0x7fffffffLL || D > 0x7fffffffLL)
         return fail(BINF_E_UNSUPPORTED, "%s: too large", what);
@@ -138,7 +151,9 @@ static int32_t row_reduce_launch(const ARGS &args, int64_t C, int64_t D,
         if (h_last > g.H) g.H = h_last;
     }
     if (g.H > 7) return fail(BINF_E_UNSUPPORTED, "%s: pairwise tree height %d", what, g.H);
-    if (g.H <= 3 && !force_block) {
+    if constexpr (STAGED) {
+        row_reduce_block_kernel<FM, ARGS, true><<<dim3((unsigned)C), 256, staged_bytes, st>>>(args, g, out);
+    } else if (g.H <= 3 && !force_block) {
         const int64_t rows_per_wave = 64 >> (3 + g.H);
         const int64_t waves = (C + rows_per_wave - 1) / rows_per_wave;
         const int64_t blocks = (waves + 3) / 4;
