@@ -78,3 +78,46 @@ def gibbs_hmc_chain(xses, ys, coeffs0, precision0, timestep, nsteps, p0, u, g):
     return dict(coefficients=np.array(out_c), precision=np.array(out_t),
                 accepted=np.array(out_a), e_before=np.array(out_eb),
                 e_after=np.array(out_ea), gamma_shape=shape)
+
+
+def example_script_chain(seed, sweeps, stepsize=0.1, n_data_points=20):
+    """The reference's example_script.py as it stands (one chain, its own
+    wiring: random-walk Metropolis on the coefficients + conjugate Gamma for the
+    precision inside Gibbs), consuming ONE global legacy stream from
+    ``np.random.seed(seed)`` on -- the data first (example_script.py:17-23), then
+    per sweep, alphabetically (gibbs.py:141):
+
+      'coefficients'  RWMCSampler.sample   binf/example/samplers.py:78-92
+                      uniform(-step, step, size=K), then random()
+      'precision'     GammaSampler.sample  binf/example/samplers.py:43-51
+                      gamma(shape)
+
+    Returns the data and the state after every sweep."""
+    np.random.seed(seed)
+    real_coeffs = np.array([2.0, -4.0, 1.0, 1.5])
+    xses = np.linspace(-2, 2, n_data_points)
+    ys = np.random.normal(loc=R.polyval(xses, real_coeffs), scale=1.0 / np.sqrt(2.5))
+    coeffs = np.ones(4)
+    tau = 1.0
+    K = len(coeffs)
+    n_moves = n_acc = 0
+    out_c, out_t, out_a = [], [], []
+    for _ in range(sweeps):
+        pdf = conditional_pdf(xses, ys, tau, K)
+        E_old = -pdf.log_prob(coefficients=coeffs)                       # :80
+        change = np.random.uniform(low=-stepsize, high=stepsize, size=K)  # :81-82
+        proposal = coeffs + change                                       # :83
+        E_new = -pdf.log_prob(coefficients=proposal)                     # :84
+        accepted = np.random.random() < np.exp(-(E_new - E_old))         # :86
+        if accepted:
+            coeffs = proposal
+            n_acc += 1
+        n_moves += 1
+        shape = R.gamma_shape(n_data_points, PRIOR_SHAPE)
+        rate = R.gamma_rate(xses, ys, coeffs, PRIOR_RATE_IN_CONDITIONALS)
+        tau = np.random.gamma(shape) / rate                              # :47-49
+        out_c.append(coeffs.copy())
+        out_t.append(tau)
+        out_a.append(bool(accepted))
+    return dict(xs=xses, ys=ys, coefficients=np.array(out_c), precision=np.array(out_t),
+                accepted=np.array(out_a), acceptance_rate=n_acc / float(n_moves))

@@ -485,3 +485,31 @@ def test_gradient_calls_on_two_streams_do_not_share_scratch(device):
             g2 = _native.poly_gauss_grad(th2, A, tys, 2.5)
         torch.cuda.synchronize()
         assert torch.equal(g1, want1) and torch.equal(g2, want2)
+
+
+@pytest.mark.parametrize('seed', [0, 1, 7])
+def test_example_script_itself_one_chain_same_stream(device, seed):
+    """example_script.py as the reference ships it -- ONE chain, RWMC + Gamma
+    inside Gibbs (make_sampler), every draw from the global legacy np.random
+    stream that also generated the data -- against its numpy restatement: the
+    chain-batched samplers with C = 1 consume the stream in the same order, and
+    every state of the chain must match bit for bit."""
+    sweeps = 300
+    ref = RE.example_script_chain(seed, sweeps)
+    np.random.seed(seed)
+    xs = np.linspace(-2, 2, 20)
+    ys = np.random.normal(loc=R.polyval(xs, np.array([2.0, -4.0, 1.0, 1.5])),
+                          scale=1.0 / np.sqrt(2.5))
+    assert np.array_equal(ys, ref['ys'])
+    start = BinfState(dict(coefficients=dev_t(np.ones((1, 4)), device),
+                           precision=dev_t(np.ones(1), device)))
+    gips = make_sampler(make_posterior(xs, ys, POLYVAL), 0.1, start)
+    for s in range(sweeps):
+        st = gips.sample()
+        c = st.variables['coefficients'].cpu().numpy()[0]
+        t = float(st.variables['precision'].cpu().numpy()[0])
+        assert np.array_equal(c, ref['coefficients'][s]), s
+        assert t == ref['precision'][s], s
+    rate = gips.last_draw_stats['coefficients'].acceptance_rate
+    assert abs(float(rate) - ref['acceptance_rate']) < 1e-12
+    assert 0.05 < ref['acceptance_rate'] < 0.95
