@@ -167,7 +167,16 @@ def dptr(t, dtype=torch.float64, numel=None, name='tensor'):
     return t.data_ptr()
 
 
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+
+
 def stream_handle(device=None):
+    """hipStream_t of torch's current stream on ``device`` (as an integer)."""
+    if _raw_stream is not None:
+        # the raw handle without building a torch.cuda.Stream object (~4 us less per launch)
+        idx = device.index if isinstance(device, torch.device) and device.index is not None \
+            else torch.cuda.current_device()
+        return _raw_stream(idx)
     return torch.cuda.current_stream(device).cuda_stream
 
 
