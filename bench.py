@@ -3,25 +3,38 @@
 Headline benchmark: chain*leapfrog-steps per second on BASELINE config C2
 (1024-d isotropic Gaussian, 4096 chains per GPU, 20 leapfrog steps, fp64).
 
-A "step" is one HMC transition (one HMCSampler.sample() worth of work) over the
-whole chain batch; by default 64 of them are issued per launch of the fused HIP
-trajectory kernel (HMCSampler.sample_n, --fuse), every state still recorded,
-through the C ABI.  Inputs (state, a pool of
-pre-generated momentum / uniform draws) are resident in HBM before the timed
-region.  Multi-GPU: chains are sharded (weak scaling, 4096 chains per GPU), no
-collective in the data path; the sample gather is timed separately.
+A "step" is ONE launch of the fused HIP trajectory kernel through the C ABI:
+HMCSampler.sample_n(F) = F (default 64) consecutive HMC transitions of every
+chain -- the reference's `for i in range(F): sampler.sample()` loop
+(example_script.py:33-34 around binf/samplers/hmc.py:136-164) -- with the state
+after EVERY transition written to a record buffer in HBM.  Inputs (start state,
+pre-generated momentum / uniform draws) and the record buffers are resident in
+HBM and allocated before the timed region; each timed launch reads draws that no
+earlier launch in the run has touched recently (>= 2 GiB of other traffic in
+between, the Infinity Cache is 256 MiB).
+
+Multi-GPU: chains are sharded (weak scaling, 4096 chains per GPU), no collective
+in the data path; the RCCL gather of one recorded draw is timed separately.
 
   python bench.py [--gpus N] [--steps K] [--warmup W]
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
-      --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+With --gpus N > 1 and no torch.distributed environment, bench.py starts the N
+ranks itself (python -m torch.distributed.run ... bench.py, as child processes,
+before this process touches the GPU) and relays rank 0's line.  It can equally be
+started by torch.distributed.run directly.
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import csv
 import glob
 import json
 import os
+import shutil
+import socket
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -33,38 +46,50 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0        # MI355X spec, MI355X_MICROARCH.md "HBM3E peak BW"
 HBM_COPY_GBS = 6290.0        # measured float4 copy ceiling, same table
+# FP64 vector peak without FMA contraction: 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz
+# = 39.3e12 lane-operations/s (half of the 78.6 TFLOP/s FMA figure)
+VALU_PEAK_LANEOPS = 39.3e12
+PERSIST_KERNEL = 'hmc_gauss_persist_kernel'
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=1024,
-                    help='timed transitions (HMCSampler.sample() calls worth of work)')
-    ap.add_argument('--warmup', type=int, default=128)
+    ap.add_argument('--steps', type=int, default=20,
+                    help='timed steps; one step = one sample_n(--fuse) launch')
+    ap.add_argument('--warmup', type=int, default=5, help='untimed steps')
     ap.add_argument('--chains', type=int, default=4096, help='chains per GPU')
     ap.add_argument('--dims', type=int, default=1024)
     ap.add_argument('--nsteps', type=int, default=20, help='leapfrog steps')
     ap.add_argument('--timestep', type=float, default=0.05)
     ap.add_argument('--mode', default='exact', choices=['exact', 'fma'])
-    ap.add_argument('--pool', type=int, default=16,
-                    help='momentum-draw buffers cycled through (pool*C*D*8 B; '
-                         '16 -> 512 MiB, larger than the 256 MiB Infinity Cache)')
     ap.add_argument('--fuse', type=int, default=64,
-                    help='transitions per launch: 1 = one HMCSampler.sample() '
-                         'per launch; n > 1 = HMCSampler.sample_n(n), the '
-                         'persistent kernel (same draws, bit-identical results, '
-                         'every transition\'s state still written to HBM)')
+                    help='transitions per step: n > 1 = HMCSampler.sample_n(n), '
+                         'one launch of the persistent kernel; 1 = one '
+                         'HMCSampler.sample() per step (bit-identical results)')
     ap.add_argument('--thin', type=int, default=1,
                     help='with --fuse > 1: record every thin-th state')
+    ap.add_argument('--draw-buffers', type=int, default=3,
+                    help='draw buffers [fuse, C, D] cycled through (>= 2)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-other-mode', action='store_true',
                     help='skip the short extra measurement in the other arithmetic mode')
+    ap.add_argument('--no-extra', action='store_true',
+                    help='skip the C3 / C5 / device-RNG sub-results')
+    ap.add_argument('--no-pmc', action='store_true',
+                    help='do not measure HBM traffic with rocprofv3 --pmc child '
+                         'runs; use the committed profile of this configuration')
+    ap.add_argument('--pmc-child', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--cpu-chains', type=int, default=64)
     ap.add_argument('--cpu-calls', type=int, default=2000,
                     help='sample() rounds of the CPU baseline (~10 s on the GPU box)')
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
 
+# ---------------------------------------------------------------------------
+# CPU baseline (the only place the oracle is used here: as the thing compared
+# against, never inside the measured path)
+# ---------------------------------------------------------------------------
 def cpu_baseline(D, L, dt, chains, calls):
     """The reference semantics (one chain per sampler, numpy fp64,
     hmc.py:136-164) via the numpy restatement, on ONE host core; plus the C
@@ -105,38 +130,201 @@ def cpu_baseline(D, L, dt, chains, calls):
     return out
 
 
+# ---------------------------------------------------------------------------
+# launching
+# ---------------------------------------------------------------------------
+def ensure_library():
+    """A checkout without the built library: compile it (hipcc needs no GPU and
+    this runs before any GPU call).  build() writes to a temporary name and
+    renames, so a rank that sees the file sees a complete one."""
+    lib_path = os.path.join(ROOT, 'binf_amd', 'csrc', 'libbinf_hip.so')
+    if os.path.exists(lib_path):
+        return
+    if int(os.environ.get('LOCAL_RANK', '0')) == 0:
+        import __graft_entry__
+        __graft_entry__.build()
+        return
+    t_wait = time.time()
+    while not os.path.exists(lib_path):
+        if time.time() - t_wait > 900:
+            sys.exit('bench.py: %s did not appear (local rank 0 builds it)' % lib_path)
+        time.sleep(1)
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch(args, argv):
+    """--gpus N > 1 without a torch.distributed environment: start the N ranks
+    as CHILD processes (this process has not touched the GPU and never will)."""
+    backend = os.environ.get('BINF_BENCH_BACKEND', 'nccl')
+    ndev = torch.cuda.device_count()       # does not initialise the GPU
+    if backend == 'nccl' and ndev < args.gpus:
+        sys.stderr.write('bench.py --gpus %d: only %d GPU(s) visible on this node '
+                         '(one rank per GPU; BINF_BENCH_BACKEND=gloo rehearses the '
+                         'control flow with ranks sharing devices)\n'
+                         % (args.gpus, ndev))
+        sys.exit(2)
+    ensure_library()
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
+           '--nproc-per-node', str(args.gpus), '--master-addr', '127.0.0.1',
+           '--master-port', str(free_port()), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', '1')
+    proc = subprocess.run(cmd, env=env)
+    sys.exit(proc.returncode)
+
+
+# ---------------------------------------------------------------------------
+# HBM traffic from the PMC counters, measured in THIS run: two child runs of the
+# same configuration under rocprofv3 (FETCH_SIZE and WRITE_SIZE in separate
+# passes), started before this process initialises the GPU.
+# ---------------------------------------------------------------------------
+def under_profiler():
+    if 'rocprof' in os.environ.get('LD_PRELOAD', ''):
+        return True
+    return any(k.startswith(('ROCPROF', 'ROCP_')) for k in os.environ)
+
+
+def pmc_traffic_live(args):
+    """-> (hbm bytes per launch, description) or (None, reason)."""
+    rocprof = shutil.which('rocprofv3') or '/opt/rocm/bin/rocprofv3'
+    if not os.path.exists(rocprof):
+        return None, 'rocprofv3 not found'
+    child = [sys.executable, os.path.abspath(__file__), '--pmc-child',
+             '--chains', str(args.chains), '--dims', str(args.dims),
+             '--nsteps', str(args.nsteps), '--timestep', repr(args.timestep),
+             '--mode', args.mode, '--fuse', str(args.fuse), '--thin', str(args.thin),
+             '--steps', '3', '--warmup', '1']
+    kb = {}
+    tmp = tempfile.mkdtemp(prefix='binf_pmc_', dir='/tmp')
+    env = dict(os.environ, TMPDIR='/tmp')
+    try:
+        for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
+            out = os.path.join(tmp, counter)
+            cmd = [rocprof, '--kernel-trace', '--pmc', counter, '--output-format', 'csv',
+                   '-d', out, '--'] + child
+            try:
+                r = subprocess.run(cmd, cwd='/tmp', env=env, stdout=subprocess.PIPE,
+                                   stderr=subprocess.PIPE, timeout=300)
+            except subprocess.TimeoutExpired:
+                return None, 'rocprofv3 --pmc %s child timed out' % counter
+            if r.returncode != 0:
+                return None, 'rocprofv3 --pmc %s child failed (rc %d)' % (counter, r.returncode)
+            vals = []
+            for f in glob.glob(os.path.join(out, '**', '*counter_collection.csv'), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if PERSIST_KERNEL in row.get('Kernel_Name', '') and \
+                            row.get('Counter_Name') == counter:
+                        vals.append(float(row['Counter_Value']))
+            if not vals:
+                return None, 'no %s rows for %s in the rocprofv3 output' % (counter, PERSIST_KERNEL)
+            kb[counter] = (sum(vals) / len(vals), len(vals))
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    # gfx950: FETCH_SIZE tallies reads at half size (MI355X_MICROARCH.md, HBM /
+    # rocprofv3 section; calibration in profiles/r01_h_pmc_calibration.json:
+    # 0.5000 / 1.0000 on a kernel of known traffic); both counters are in KiB
+    nbytes = (2.0 * kb['FETCH_SIZE'][0] + kb['WRITE_SIZE'][0]) * 1024.0
+    src = ('measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE '
+           '(separate child passes of this configuration, mean over %d / %d dispatches of %s; '
+           'FETCH_SIZE x2 (gfx950 correction), KiB -> B)'
+           % (kb['FETCH_SIZE'][1], kb['WRITE_SIZE'][1], PERSIST_KERNEL))
+    return nbytes, src
+
+
+def pmc_traffic_committed(C, D, L, F, thin, mode):
+    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_traffic.json')),
+                       reverse=True):
+        try:
+            pm = json.load(open(path))
+            c = pm['config']
+            if (c['chains'], c['dims'], c['nsteps'], c['fuse'], c['thin'], c['mode']) == \
+                    (C, D, L, F, thin, mode):
+                return pm['hbm_bytes_per_transition'] * F, \
+                    'profiles/%s (committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE summary of ' \
+                    'this configuration, separate passes, FETCH x2)' % os.path.basename(path)
+        except (OSError, ValueError, KeyError):
+            continue
+    return None, None
+
+
+# ---------------------------------------------------------------------------
+def dry_run(args, rank, world):
+    """BINF_BENCH_DRYRUN=1: the multi-rank control flow without a GPU (CPU test
+    suite): rendezvous, barrier, MAX over ranks, the sample gather -- no sampling."""
+    import torch.distributed as dist
+    from binf_amd.dist import gather_chains, shard_chains
+    if world > 1:
+        dist.init_process_group('gloo')
+        dist.barrier()
+    elapsed = 1.0 + rank
+    gathered = None
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax[0])
+        _, count = shard_chains(args.chains * world, rank, world)
+        state = torch.full((count, 4), float(rank), dtype=torch.float64)
+        gathered = gather_chains(state)
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps({'dry_run': True, 'n_gpus': world, 'steps': args.steps,
+                          'warmup': args.warmup, 'max_elapsed': elapsed,
+                          'gathered_rows': None if gathered is None else int(gathered.shape[0]),
+                          'value': None}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
-    args = parse()
+    argv = sys.argv[1:]
+    args = parse(argv)
+    in_dist = 'WORLD_SIZE' in os.environ and 'RANK' in os.environ
+    if args.gpus > 1 and not in_dist:
+        self_launch(args, argv)
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit('bench.py --gpus %d must be launched with torch.distributed'
-                     '.run --nproc-per-node %d' % (args.gpus, args.gpus))
-        args.gpus = world
+    args.gpus = world
+    if os.environ.get('BINF_BENCH_DRYRUN') == '1':
+        return dry_run(args, rank, world)
+    ensure_library()
+
+    C, D, L, dt = args.chains, args.dims, args.nsteps, args.timestep
+    K, W = max(1, args.steps), max(0, args.warmup)
+    F = max(1, args.fuse)
+    thin = min(max(1, args.thin), F)
+    NB = max(2, args.draw_buffers)
+
+    # HBM traffic of the dominant kernel by PMC, measured live in child runs --
+    # BEFORE this process initialises the GPU (rank 0 of a single-GPU run only)
+    live_traffic, live_src = None, 'not attempted'
+    if world == 1 and F > 1 and not args.pmc_child and not args.no_pmc:
+        if under_profiler():
+            live_src = 'this process itself runs under a profiler'
+        else:
+            t_p = time.perf_counter()
+            live_traffic, live_src = pmc_traffic_live(args)
+            if live_traffic is not None:
+                live_src += '; %.0f s' % (time.perf_counter() - t_p)
+
     if not torch.cuda.is_available():
         sys.exit('bench.py needs a GPU (binf_amd has no CPU path)')
-    # a checkout without the built library: compile it (one rank per node), never fall back
-    lib_path = os.path.join(ROOT, 'binf_amd', 'csrc', 'libbinf_hip.so')
-    if not os.path.exists(lib_path):
-        if local_rank == 0:
-            import __graft_entry__
-            __graft_entry__.build()
-        else:
-            t_wait = time.time()
-            size = -1
-            while time.time() - t_wait < 900:   # present and no longer growing
-                time.sleep(3)
-                now = os.path.getsize(lib_path) if os.path.exists(lib_path) else -1
-                if now > 0 and now == size:
-                    break
-                size = now
     # BINF_BENCH_BACKEND=gloo: rehearsal of the multi-rank control flow on a box
     # with fewer GPUs than ranks (ranks then share devices); real runs use
     # nccl (= RCCL on ROCm), one rank per GPU.
     backend = os.environ.get('BINF_BENCH_BACKEND', 'nccl')
     ndev = torch.cuda.device_count()
+    if backend == 'nccl' and world > ndev:
+        sys.exit('bench.py: %d ranks but only %d GPU(s) visible (one rank per GPU)'
+                 % (world, ndev))
     dev_index = local_rank if backend == 'nccl' else local_rank % max(1, ndev)
     torch.cuda.set_device(dev_index)
     dev = torch.device('cuda', dev_index)
@@ -151,62 +339,58 @@ def main():
     from binf_amd.pdf import IsotropicGaussian
     from binf_amd.samplers.hmc import HMCSampler
 
-    C, D, L, dt = args.chains, args.dims, args.nsteps, args.timestep
-    K, W, P = max(1, args.steps), max(0, args.warmup), max(1, args.pool)
-
     # synthetic inputs, resident in HBM before the timed region
     q0 = torch.from_numpy(
         np.random.RandomState(1234 + rank).standard_normal((C, D))).to(dev)
     gen = torch.Generator(device=dev)
     gen.manual_seed(1000 + rank)
-    p_pool = [torch.randn((C, D), dtype=torch.float64, device=dev, generator=gen)
-              for _ in range(P)]
-    u_pool = [torch.rand(C, dtype=torch.float64, device=dev, generator=gen)
-              for _ in range(P)]
+    p_bufs = [torch.randn((F, C, D), dtype=torch.float64, device=dev, generator=gen)
+              for _ in range(NB)]
+    u_bufs = [torch.rand((F, C), dtype=torch.float64, device=dev, generator=gen)
+              for _ in range(NB)]
+    nrec = F // thin
+    # record buffers (every thin-th state of a step), preallocated: two, used in turn
+    rec_bufs = [torch.empty((nrec, C, D), dtype=torch.float64, device=dev)
+                for _ in range(2)] if F > 1 else None
 
-    sampler = HMCSampler(IsotropicGaussian(1.0, 0.0), q0, dt, L,
-                         variable_name='x', mode=args.mode)
+    def make_sampler(mode):
+        return HMCSampler(IsotropicGaussian(1.0, 0.0), q0, dt, L,
+                          variable_name='x', mode=mode)
+
+    def run(sampler, first, nsteps):
+        """steps first .. first+nsteps-1 of the run (the draw buffer of a step
+        is first-use or last used >= NB-1 steps = >= 2 GiB of traffic ago)"""
+        for i in range(first, first + nsteps):
+            b = i % NB
+            if F > 1:
+                sampler.sample_n(F, thin=thin, p0=p_bufs[b], u=u_bufs[b],
+                                 record=True, out=rec_bufs[i % 2])
+            else:
+                sampler.sample(p0=p_bufs[b][0], u=u_bufs[b][0])
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    F = max(1, args.fuse)
-    if F > 1:
-        # one step is still ONE transition; they are issued F per launch (a
-        # step count that is not a multiple of F ends with one shorter launch)
-        nchunk = max(2, P // F)
-        p_chunks = [torch.randn((F, C, D), dtype=torch.float64, device=dev,
-                                generator=gen) for _ in range(nchunk)]
-        u_chunks = [torch.rand((F, C), dtype=torch.float64, device=dev,
-                               generator=gen) for _ in range(nchunk)]
-        del p_pool, u_pool
+    if args.pmc_child:
+        s = make_sampler(args.mode)
+        run(s, 0, W + K)
+        torch.cuda.synchronize()
+        return
 
-        def run(nsteps, sampler=sampler):
-            i = 0
-            while nsteps > 0:
-                n = min(F, nsteps)
-                sampler.sample_n(n, thin=min(args.thin, n), p0=p_chunks[i % nchunk][:n],
-                                 u=u_chunks[i % nchunk][:n], record=True)
-                nsteps -= n
-                i += 1
-    else:
-        def run(nsteps, sampler=sampler):
-            for i in range(nsteps):
-                sampler.sample(p0=p_pool[i % P], u=u_pool[i % P])
-
-    run(W)
+    sampler = make_sampler(args.mode)
+    run(sampler, 0, W)
     barrier()
     ev0 = torch.cuda.Event(enable_timing=True)
     ev1 = torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
-    ev0.record()
-    run(K)
+    ev0.record()                                # same stream as the launches
+    run(sampler, W, K)
     ev1.record()
     barrier()
     elapsed = time.perf_counter() - t0
-    dev_ms = ev0.elapsed_time(ev1)              # same stream as the launches
+    dev_ms = ev0.elapsed_time(ev1)
 
     acc_rate = float(sampler.acceptance_rate.mean())
     gather_ms = None
@@ -216,20 +400,21 @@ def main():
     other = None
     if world == 1 and not args.no_other_mode:
         om = 'fma' if args.mode == 'exact' else 'exact'
-        s2 = HMCSampler(IsotropicGaussian(1.0, 0.0), q0, dt, L, variable_name='x', mode=om)
-        K2 = min(K, 4 * F)
-        run(min(W, F), s2)
+        s2 = make_sampler(om)
+        K2 = min(K, 8)
+        run(s2, 0, 2)
         torch.cuda.synchronize()
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
         e0.record()
-        run(K2, s2)
+        run(s2, 2, K2)
         e1.record()
         torch.cuda.synchronize()
-        t2 = e0.elapsed_time(e1) * 1e-3 / K2
+        t2 = e0.elapsed_time(e1) * 1e-3 / (K2 * F)
         other = {'mode': om, 'value': C * L / t2, 'avg_transition_us': t2 * 1e6,
                  'roofline_frac': (24.0 * D + 25.0) * C / t2 / 1e9 / HBM_PEAK_GBS,
                  'steps': K2, 'note': 'device time (HIP events), not the headline value'}
+        del s2
     if dist is not None:
         tmax = torch.tensor([elapsed], dtype=torch.float64,
                             device=dev if backend == 'nccl' else 'cpu')
@@ -247,31 +432,62 @@ def main():
         gather_ms = (time.perf_counter() - t1) / 5 * 1e3
 
     if rank == 0:
-        steps_total = float(world) * C * L * K
+        transitions = K * F
+        steps_total = float(world) * C * L * transitions
         value = steps_total / elapsed
-        bytes_per_transition = (24.0 * D + 25.0) * C
-        n_launches = (K + F - 1) // F
-        launch_s = dev_ms * 1e-3 / n_launches             # per kernel launch
-        trans_s = dev_ms * 1e-3 / K                       # per transition
-        bytes_per_launch = bytes_per_transition * min(F, K)   # a full launch
-        # algorithmic bytes of the timed region / device time of the timed
-        # region (= bytes per launch / average launch duration)
-        achieved = bytes_per_transition * K / (dev_ms * 1e-3) / 1e9
-        # HBM traffic from the committed PMC summary of this exact configuration
-        traffic, traffic_src = None, None
-        for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_traffic.json')),
-                           reverse=True):
-            try:
-                pm = json.load(open(path))
-                c = pm['config']
-                if (c['chains'], c['dims'], c['nsteps'], c['fuse'], c['thin'], c['mode']) == \
-                        (C, D, L, F, args.thin if F > 1 else 1, args.mode):
-                    traffic = pm['hbm_bytes_per_transition'] * min(F, K)
-                    traffic_src = 'profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, ' \
-                                  'separate passes, FETCH x2)' % os.path.basename(path)
-                    break
-            except (OSError, ValueError, KeyError):
-                continue
+        launch_s = dev_ms * 1e-3 / K                      # per kernel launch (= step)
+        trans_s = launch_s / F
+        # compulsory bytes of ONE sample() per chain = q0 in +
+        # p0 in + q_out out + u, flags, energies = 24 D + 25; one launch = F of them
+        contract_bytes_launch = (24.0 * D + 25.0) * C * F
+        achieved = contract_bytes_launch / launch_s / 1e9
+        # what this launch shape really has to move: p0 in, every thin-th state
+        # out, u + flag per transition; q0 in and q_out out once per launch
+        moved_bytes_launch = ((8.0 * D * (1.0 + 1.0 / thin) + 9.0) * F + 16.0 * D) * C \
+            if F > 1 else contract_bytes_launch
+        if live_traffic is not None:
+            traffic, traffic_src = live_traffic, live_src
+        else:
+            traffic, traffic_src = pmc_traffic_committed(C, D, L, F, thin if F > 1 else 1,
+                                                         args.mode)
+            if traffic_src is not None:
+                traffic_src += ' [live PMC pass: %s]' % live_src
+        # FP64 lane-operations of one transition: per element 4 L + 2 for the
+        # integrator (hmc.py:116-123, gradient = identity for k=1, x0=0) + 6 for
+        # the three energy sums; nothing contractible in exact mode
+        laneops_launch = (4.0 * L + 2.0 + 6.0) * C * D * F
+        if args.mode == 'fma':
+            laneops_launch = (2.0 * L + 1.0 + 3.0) * C * D * F
+        roof = {'bound': 'hbm', 'achieved': achieved,
+                'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                'frac': achieved / HBM_PEAK_GBS,
+                'frac_of_measured_copy_ceiling': achieved / HBM_COPY_GBS,
+                'traffic': traffic, 'traffic_source': traffic_src,
+                'hbm_frac_measured': (traffic / launch_s / 1e9 / HBM_PEAK_GBS)
+                if traffic is not None else None,
+                'hbm_frac_moved': moved_bytes_launch / launch_s / 1e9 / HBM_PEAK_GBS,
+                'valu_frac': laneops_launch / launch_s / VALU_PEAK_LANEOPS,
+                'per': 'kernel launch = 1 step = %d transition(s), each one '
+                       'HMCSampler.sample() worth of work' % F,
+                'kernel': PERSIST_KERNEL,
+                'transitions_per_launch': F,
+                'launches_timed': K,
+                'states_recorded': 'every transition' if thin == 1
+                else 'every %d. transition' % thin,
+                'algorithmic_bytes_per_launch': contract_bytes_launch,
+                'algorithmic_contract_bytes': 'SURVEY.md 8(d): (24 D + 25) B per chain and '
+                                              'sample() x %d chains x %d transitions' % (C, F),
+                'moved_bytes_per_launch': moved_bytes_launch,
+                'fp64_lane_ops_per_launch': laneops_launch,
+                'valu_peak_lane_ops_per_s': VALU_PEAK_LANEOPS,
+                'avg_launch_us': launch_s * 1e6,
+                'avg_transition_us': trans_s * 1e6,
+                'note': 'frac follows the contract (algorithmic bytes of F sample() calls / '
+                        'launch time / 8 TB/s); the persistent kernel keeps q in registers, so '
+                        'the bytes it really moves are moved_bytes_per_launch (hbm_frac_moved) '
+                        'and the PMC-measured traffic (hbm_frac_measured); valu_frac = exact '
+                        'FP64 lane-operations / time / 39.3e12 (the kernel is FP64-VALU / '
+                        'power bound, DESIGN.md 4.1)'}
         res = {
             'metric': 'chain*leapfrog-steps/sec, 1024-d Gaussian',
             'value': value,
@@ -285,33 +501,32 @@ def main():
             'data': 'synthetic',
             'config': {'workload': 'C2: %d-d isotropic Gaussian (k=1, x0=0), '
                                    '%d chains/GPU, %d leapfrog steps, dt=%g, '
-                                   'fused HMC transition, mode=%s, %d '
-                                   'transition(s) per launch'
-                                   % (D, C, L, dt, args.mode, F),
+                                   'fused HMC transition, mode=%s; 1 step = 1 launch = %d '
+                                   'transition(s) (sample() calls), %s state recorded'
+                                   % (D, C, L, dt, args.mode, F,
+                                      'every' if thin == 1 else 'every %d.' % thin),
                        'chains_per_gpu': C, 'n_dims': D, 'leapfrog_steps': L,
+                       'transitions_per_step': F,
                        'parallelism': 'chains sharded x%d, no data-path '
                                       'collective' % world,
-                       'draw_pool_buffers': P},
+                       'draw_buffers': NB},
+            'timed_region_ms': elapsed * 1e3,
             'acceptance_rate': acc_rate,
-            'roofline': {'bound': 'hbm', 'achieved': achieved,
-                         'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS,
-                         'frac_of_measured_copy_ceiling': achieved / HBM_COPY_GBS,
-                         'traffic': traffic, 'traffic_source': traffic_src,
-                         'per': 'kernel launch = %d transition(s), each one '
-                                'HMCSampler.sample() worth of work' % F,
-                         'kernel': 'hmc_gauss_persist_kernel',
-                         'transitions_per_launch': F,
-                         'states_recorded': 'every transition' if F == 1
-                         else 'every %d. transition' % args.thin,
-                         'algorithmic_bytes_per_launch': bytes_per_launch,
-                         'avg_launch_us': launch_s * 1e6,
-                         'avg_transition_us': trans_s * 1e6},
+            'roofline': roof,
         }
         if gather_ms is not None:
             res['sample_gather_ms'] = gather_ms
         if other is not None:
             res['other_mode'] = other
+        if world == 1 and not args.no_extra:
+            # free the C2 buffers first (the sub-results allocate their own)
+            del p_bufs, u_bufs, rec_bufs, sampler
+            torch.cuda.empty_cache()
+            try:
+                from scripts import bench_extra
+                res['extra'] = bench_extra.run_all(dev)
+            except Exception as e:              # sub-results never break the headline
+                res['extra'] = {'error': '%s: %s' % (type(e).__name__, e)}
         if world == 1 and not args.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline(D, L, dt, args.cpu_chains,
                                                args.cpu_calls)

@@ -93,6 +93,9 @@ __global__ void __launch_bounds__(256) hmc_gauss_split_kernel(const GaussNArgs a
     chain_sums(v0, v1, v2);
     double Sq_state = fin[1];                        // meaningful on the last part only
     int64_t nacc = 0;
+    // the last part's reads of `hand` above must complete before part 0 writes
+    // it again in transition 0 (inside the loop the verdict barrier does this)
+    __syncthreads();
 
     for (int s = 0; s < a.n; ++s) {
         const double hdt = 0.5 * dt;

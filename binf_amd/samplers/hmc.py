@@ -159,7 +159,7 @@ class HMCSampler(object):
         return q_out
 
     # -- n transitions in one launch -------------------------------------------
-    def sample_n(self, n, thin=1, p0=None, u=None, record=True):
+    def sample_n(self, n, thin=1, p0=None, u=None, record=True, out=None):
         """``n`` consecutive ``sample()`` calls (the ``for i in range(n)`` loop
         of the reference's ``example_script.py:33-34``), returning the recorded
         states ``[n // thin, C, D]`` -- the state after transitions ``thin,
@@ -169,6 +169,9 @@ class HMCSampler(object):
         For PDFs with a fused kernel this is ONE launch of the persistent
         kernel (state kept in registers between transitions); otherwise it
         loops over ``sample()``.  ``p0`` is ``[n, C, D]``, ``u`` is ``[n, C]``.
+        ``out`` (``[n // thin, C, D]`` fp64, contiguous, same device) is a
+        caller-owned record buffer to fill instead of a fresh allocation
+        (a sample store slice; the C ABI never allocates).
         """
         name = self._variable_name
         if not isinstance(name, str):
@@ -189,19 +192,31 @@ class HMCSampler(object):
         u = u.reshape(n, C)
         spec = self._fused_spec(name, D)
         nrec = n // thin
+        if out is not None:
+            if not record or nrec < 1:
+                raise ValueError('sample_n: out= given but nothing is recorded')
+            if out.dtype != torch.float64 or out.device != dev or \
+                    not out.is_contiguous() or out.numel() != nrec * C * D:
+                raise ValueError('sample_n: out must be a contiguous fp64 [%d, %d, %d] '
+                                 'tensor on %s' % (nrec, C, D, dev))
         if spec is None or spec[0] != 'gauss':
-            out, flags, ebs, eas = [], [], [], []
+            rec, flags, ebs, eas = [], [], [], []
             for i in range(n):
                 x = self.sample(p0=p0[i], u=u[i])
                 if record and (i + 1) % thin == 0:
-                    out.append(x)
+                    rec.append(x)
                 flags.append(self._last_move_accepted)
                 ebs.append(self.last_e_before)
                 eas.append(self.last_e_after)
             self.accepted_history = torch.stack(flags)
             if all(e is not None for e in ebs):
                 self.last_e_before, self.last_e_after = torch.stack(ebs), torch.stack(eas)
-            return torch.stack(out) if (record and out) else None
+            if not (record and rec):
+                return None
+            if out is not None:
+                torch.stack(rec, out=out.view((nrec,) + tuple(rec[0].shape)))
+                return out
+            return torch.stack(rec)
 
         _, k, x0 = spec
         n_adapt = max(0, min(n, self.timestep_adaption_limit - 1 - self.counter))
@@ -211,8 +226,11 @@ class HMCSampler(object):
         if not isinstance(self.n_accepted, torch.Tensor):
             self.n_accepted = torch.zeros(C, dtype=torch.int64, device=dev)
         q_out = torch.empty_like(q0)
-        samples = torch.empty((nrec, C, D), dtype=torch.float64, device=dev) \
-            if (record and nrec > 0) else None
+        if out is not None:
+            samples = out.view(nrec, C, D)
+        else:
+            samples = torch.empty((nrec, C, D), dtype=torch.float64, device=dev) \
+                if (record and nrec > 0) else None
         accepted = torch.empty((n, C), dtype=torch.uint8, device=dev)
         eb = ea = None
         if self.record_energies:

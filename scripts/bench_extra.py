@@ -1,0 +1,137 @@
+"""Short sub-results carried under the `extra` key of bench.py's JSON line (so
+they are timed by the driver's run, not only by builder runs): BASELINE configs
+C3 (polynomial model, MFMA design-matrix gradient), C5 (pair-distance model,
+FP64 VALU) and the C2 shape with the draws generated on the device inside the
+timed region.  Not the headline; each takes a second or two.
+
+All timings are HIP events on torch's current stream (the stream the C-ABI
+launches go to)."""
+import numpy as np
+import torch
+
+# 78.6 TFLOP/s: fp64 matrix (MFMA) datasheet peak; 39.3e12: FP64 vector
+# lane-operations/s without FMA contraction (bench.py)
+MFMA_F64_PEAK_TFLOPS = 78.6
+VALU_PEAK_LANEOPS = 39.3e12
+
+
+def _timed(fn, n, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e-3 / n
+
+
+def c3_polynomial(dev, C=8192, K=33, N=16384, L=20):
+    """C3: K=33 coefficients, N=16384 data, 8192 chains (SURVEY 8(d):
+    xs = linspace(-1, 1), tau = 2.5)."""
+    from binf_amd import _native
+    from binf_amd.example.likelihood import POLYVAL, ForwardModel, make_likelihood
+    from binf_amd.example.priors import GammaPrior, GaussianPrior
+    from binf_amd.pdf.posteriors import Posterior
+    from binf_amd.samplers.hmc import HMCSampler
+    from binf_amd.samplers.rng import DeviceRNG
+    xs = np.linspace(-1, 1, N)
+    c_true = np.random.RandomState(7).standard_normal(K)
+    ys = POLYVAL(xs, c_true) + np.random.RandomState(9).standard_normal(N) / np.sqrt(2.5)
+    q0 = torch.from_numpy(np.random.RandomState(8).standard_normal((C, K))).to(dev)
+    fwm = ForwardModel(xs, POLYVAL)
+    A = fwm.design_matrix(K, dev)
+    tx = fwm.xs_device(dev)
+    ty = torch.from_numpy(ys).to(dev)
+    t_grad = _timed(lambda: _native.poly_gauss_grad(q0, A, ty, 2.5), 20)
+    t_logp = _timed(lambda: _native.poly_gauss_logp(q0, tx, ty, 2.5), 20)
+    flops = 4.0 * K * N * C                      # 4 K N per chain and gradient
+    lik = make_likelihood(xs, ys, POLYVAL)
+    post = Posterior({lik.name: lik},
+                     {'precision_prior': GammaPrior(1.0, 0.2),
+                      'coefficients_prior': GaussianPrior(np.zeros(K), np.ones(K) * 5)})
+    cond = post.conditional_factory(precision=2.5)
+    s = HMCSampler(cond, q0, 2e-4, L, variable_name='coefficients', rng=DeviceRNG(1, dev))
+    t_hmc = _timed(s.sample, 3, warm=1)
+    return {'workload': 'C3: polynomial K=%d, N=%d, %d chains, L=%d' % (K, N, C, L),
+            'grad_kernel_ms': t_grad * 1e3,
+            'grad_TFLOPs': flops / t_grad / 1e12,
+            'mfma_frac': flops / t_grad / 1e12 / MFMA_F64_PEAK_TFLOPS,
+            'logp_kernel_ms': t_logp * 1e3,
+            'hmc_sample_ms': t_hmc * 1e3,
+            'chain_leapfrog_steps_per_s': C * L / t_hmc,
+            'gradient_share_of_sample': (L + 1) * t_grad / t_hmc,
+            'acceptance': float(s.acceptance_rate.mean())}
+
+
+def c5_distance(dev, C=256, n=256, L=20):
+    """C5 per-GPU share: 3 x 256 coordinates, 256 chains (= 2048 / 8)."""
+    from binf_amd.example.distance import make_distance_likelihood
+    from binf_amd.pdf import IsotropicGaussian
+    from binf_amd.pdf.posteriors import Posterior
+    from binf_amd.samplers.hmc import HMCSampler
+    from binf_amd.samplers.rng import DeviceRNG
+    rs = np.random.RandomState(0)
+    truth = rs.standard_normal((n, 3)) * 2.0
+    I, J = np.triu_indices(n, 1)
+    d_true = np.sqrt(np.sum((truth[I] - truth[J]) ** 2, axis=1))
+    ys = np.abs(d_true + 0.05 * rs.standard_normal(n * (n - 1) // 2))
+    x = torch.from_numpy(truth.reshape(-1)[None, :] +
+                         0.1 * rs.standard_normal((C, 3 * n))).to(dev)
+    lik = make_distance_likelihood(ys, n)
+    prior = IsotropicGaussian(0.05, 0.0, name='coordinates_prior', variable_name='coordinates')
+    cond = Posterior({lik.name: lik}, {prior.name: prior}).conditional_factory(precision=4.0)
+    t_g = _timed(lambda: lik.gradient(coordinates=x, precision=4.0), 20)
+    s = HMCSampler(cond, x, 0.002, L, variable_name='coordinates', rng=DeviceRNG(0, dev))
+    t_h = _timed(s.sample, 5, warm=1)
+    pairs = float(C) * n * n                      # ordered pairs evaluated per force call
+    return {'workload': 'C5 share: %d beads x 3, %d chains, L=%d' % (n, C, L),
+            'force_kernel_ms': t_g * 1e3,
+            'pair_interactions_per_s': pairs / t_g,
+            # 36 VALU instructions per pair (PMC), ~20 of them FP64
+            'valu_frac_fp64': 20.0 * pairs / t_g / VALU_PEAK_LANEOPS,
+            'hmc_sample_ms': t_h * 1e3,
+            'chain_leapfrog_steps_per_s': C * L / t_h,
+            'acceptance': float(s.acceptance_rate.mean())}
+
+
+def c2_device_rng(dev, C=4096, D=1024, L=20, F=64):
+    """C2 with the momentum / uniform draws generated on the device INSIDE the
+    timed region (hmc.py:146,151 are part of sample())."""
+    from binf_amd.pdf import IsotropicGaussian
+    from binf_amd.samplers.hmc import HMCSampler
+    from binf_amd.samplers.rng import DeviceRNG
+    out = {'workload': 'C2 shape, sample_n(%d), draws generated on the device in the '
+                       'timed region' % F}
+    for mode in ('exact', 'fma'):
+        s = HMCSampler(IsotropicGaussian(), torch.zeros((C, D), dtype=torch.float64, device=dev),
+                       0.05, L, variable_name='x', rng=DeviceRNG(0, dev), mode=mode)
+        t = _timed(lambda: s.sample_n(F), 4, warm=1) / F
+        out['%s_us_per_transition' % mode] = t * 1e6
+        out['%s_chain_steps_per_s' % mode] = C * L / t
+        del s
+        torch.cuda.empty_cache()
+    return out
+
+
+def run_all(dev):
+    res = {}
+    for name, fn in (('C3', c3_polynomial), ('C5', c5_distance),
+                     ('C2_device_rng', c2_device_rng)):
+        try:
+            res[name] = fn(dev)
+        except Exception as e:                    # one failing sub-result does not hide the others
+            res[name] = {'error': '%s: %s' % (type(e).__name__, e)}
+        torch.cuda.empty_cache()
+    return res
+
+
+if __name__ == '__main__':
+    import json
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    print(json.dumps(run_all(torch.device('cuda:0'))))
