@@ -81,6 +81,14 @@ hmc_gauss_persist_kernel(const GaussNArgs a)
 
     double dt = a.dt_chain ? a.dt_chain[chain] : a.timestep;
     double uu = a.u[chain];
+    if (a.stagger > 0) {
+        // De-phase the waves that share a SIMD: a launch puts every wave in the
+        // same phase (all load, then all integrate, then all store), so the
+        // memory pipe idles while the FP64 pipe works and vice versa.  Wave slot
+        // s of its SIMD (HW_ID.WAVE_ID) starts s * stagger * 64 cycles late.
+        const int slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 3;
+        for (int i = 0; i < slot * a.stagger; ++i) __builtin_amdgcn_s_sleep(1);
+    }
     __builtin_amdgcn_sched_barrier(0);
 
     // q lives in registers for the whole launch; the momentum is needed one
@@ -88,8 +96,10 @@ hmc_gauss_persist_kernel(const GaussNArgs a)
     // (pa / pb): while group g runs its trajectory, group g+1's draw (or group
     // 0 of the next transition) is in flight.
     double q[TMAX], pa[GS], pb[GS];
+    // issue order = arrival order: the first group's state and momentum first,
+    // so its trajectory can start while the rest of the state is in flight
 #pragma unroll
-    for (int t = 0; t < TMAX; ++t) {
+    for (int t = 0; t < GS; ++t) {
         const bool m = REGULAR || (8 * t + j < n);
         q[t] = m ? a.q0[base + 8 * t] : 0.0;
     }
@@ -98,16 +108,18 @@ hmc_gauss_persist_kernel(const GaussNArgs a)
         const bool m = REGULAR || (8 * i + j < n);
         pa[i] = m ? a.p0[base + 8 * i] : 0.0;
     }
+#pragma unroll
+    for (int t = GS; t < TMAX; ++t) {
+        const bool m = REGULAR || (8 * t + j < n);
+        q[t] = m ? a.q0[base + 8 * t] : 0.0;
+    }
 
     const double c_lp = -0.5 * a.k;
     // np.sum((q - x0)**2) of the CURRENT state, carried across transitions
+    // (for the start state it is summed group by group inside the first
+    // transition, so that the first trajectories need not wait for all of q0)
     LaneSum s0 = {0.0, 0.0};
-#pragma unroll
-    for (int t = 0; t < TMAX; ++t) {
-        const double d = UNIT ? q[t] : q[t] - a.x0;
-        lane_sum_add<REGULAR>(s0, d * d, t, T);
-    }
-    double Sq_state = chain_sum_finish<REGULAR, LW>(s0, T, rem, lane, H, leafdepth, xch, wib);
+    double Sq_state = 0.0;
     int64_t nacc = 0;
 
     for (int s = 0; s < a.n; ++s) {
@@ -151,6 +163,14 @@ hmc_gauss_persist_kernel(const GaussNArgs a)
 #pragma unroll
             for (int i = 0; i < GS; ++i)
                 asm volatile("" : "+v"(cur[i]), "+v"(q[g * GS + i]));
+            if (s == 0) {
+#pragma unroll
+                for (int i = 0; i < GS; ++i) {
+                    const int t = g * GS + i;
+                    const double d = UNIT ? q[t] : q[t] - a.x0;
+                    lane_sum_add<REGULAR>(s0, d * d, t, T);
+                }
+            }
 #pragma unroll
             for (int i = 0; i < GS; ++i)                      // hmc.py:148
                 lane_sum_add<REGULAR>(spb, cur[i] * cur[i], g * GS + i, T);
@@ -192,6 +212,8 @@ hmc_gauss_persist_kernel(const GaussNArgs a)
 #pragma unroll
             for (int i = 0; i < GS; ++i) pa[i] = pb[i];
         }
+        if (s == 0)
+            Sq_state = chain_sum_finish<REGULAR, LW>(s0, T, rem, lane, H, leafdepth, xch, wib);
         const double Spb = chain_sum_finish<REGULAR, LW>(spb, T, rem, lane, H, leafdepth, xch, wib);
         const double Sqa = chain_sum_finish<REGULAR, LW>(sqa, T, rem, lane, H, leafdepth, xch, wib);
         const double Spa = chain_sum_finish<REGULAR, LW>(spa, T, rem, lane, H, leafdepth, xch, wib);
@@ -271,6 +293,18 @@ static hipError_t launch_n_wide(const GaussNArgs &a, bool regular, bool unit, bo
                    : launch_n_trl<16, false, LW>(a, unit, fma, grid, st);
 }
 
+// start stagger of the waves of a SIMD (units of ~64 cycles per wave slot)
+int gauss_stagger(int n)
+{
+    static int forced = -2;
+    if (forced == -2) {
+        const char *e = getenv("BINF_GAUSS_STAGGER");        // development aid
+        forced = e ? atoi(e) : -1;
+    }
+    if (forced >= 0) return forced;
+    return 0;
+}
+
 }  // namespace binf
 
 using namespace binf;
@@ -320,6 +354,7 @@ extern "C" int32_t binf_hmc_sample_n_gauss_f64(
     a.x0 = x0; a.uprate = uprate; a.downrate = downrate; a.C = C;
     a.D = (int32_t)D; a.nsteps = nsteps; a.H = H; a.n = n; a.thin = thin;
     a.n_adapt = n_adapt < n ? n_adapt : n;
+    a.stagger = gauss_stagger(n);
 
     int64_t blocks;
     if (LW == 0) {

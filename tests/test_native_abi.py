@@ -119,7 +119,7 @@ def test_product_package_never_touches_the_oracle():
         glob.glob(os.path.join(pkg, 'csrc', '*'))
     assert len(files) > 15
     for f in files:
-        if f.endswith('.so'):
+        if f.endswith('.so') or os.path.isdir(f):
             continue
         text = open(f, errors='replace').read()
         assert 'oracle' not in text, f
