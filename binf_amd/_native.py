@@ -43,6 +43,13 @@ SIGNATURES = {
                                            _vp, _vp, _f64, _vp, _i64, _i64,
                                            _i32, _i32, _i32, _f64, _f64, _i32,
                                            _f64, _f64, _i32, _vp]),
+    'binf_hmc_sample_n_gauss_rng_f64': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                               _f64, _vp, _i64, _i64, _i32, _i32,
+                                               _i32, _f64, _f64, _i32, _f64, _f64,
+                                               _i32, ctypes.c_uint64,
+                                               ctypes.c_uint64, _vp]),
+    'binf_hmc_gauss_rng_draws_f64': (_i32, [_vp, _vp, _i64, _i64, _i32,
+                                            ctypes.c_uint64, ctypes.c_uint64, _vp]),
     'binf_hmc_sample_poly_f64': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                         _vp, _vp, _f64, _vp, _vp, _vp, _i32,
                                         _vp, _vp, _f64, _vp, _i64, _i64, _i64,
@@ -486,6 +493,48 @@ def hmc_sample_n_gauss(q0, p0, u, q_out, samples, accepted, n_accepted,
         float(k), float(x0), int(n_adapt), float(uprate), float(downrate),
         int(mode), stream_handle(q0.device))
     check(rc, 'binf_hmc_sample_n_gauss_f64')
+
+
+def hmc_sample_n_gauss_rng(q0, q_out, samples, accepted, n_accepted, e_before,
+                           e_after, timestep, dt_chain, nsteps, n, thin, k, x0,
+                           n_adapt, uprate, downrate, mode, seed, offset):
+    """binf_hmc_sample_n_gauss_rng_f64 (draws generated in the kernel) on
+    torch's current stream."""
+    C, D = _cd(q0)
+    n = int(n)
+    thin = int(thin)
+    nrec = n // thin
+    rc = lib().binf_hmc_sample_n_gauss_rng_f64(
+        dptr(q0, numel=C * D, name='q0'),
+        dptr(q_out, numel=C * D, name='q_out'),
+        dptr(samples, numel=nrec * C * D, name='samples'),
+        dptr(accepted, torch.uint8, n * C, 'accepted'),
+        dptr(n_accepted, torch.int64, C, 'n_accepted'),
+        dptr(e_before, numel=n * C, name='e_before'),
+        dptr(e_after, numel=n * C, name='e_after'), float(timestep),
+        dptr(dt_chain, numel=C, name='dt_chain'), C, D, int(nsteps), n, thin,
+        float(k), float(x0), int(n_adapt), float(uprate), float(downrate),
+        int(mode), int(seed) & (2 ** 64 - 1), int(offset) & (2 ** 64 - 1),
+        stream_handle(q0.device))
+    check(rc, 'binf_hmc_sample_n_gauss_rng_f64')
+
+
+def hmc_gauss_rng_draws(n, C, D, seed, offset, device):
+    """(p0 [n, C, D], u [n, C]): the draws the fused-generator kernel consumes
+    for (seed, offset) at this batch shape."""
+    n, C, D = int(n), int(C), int(D)
+    p0 = torch.empty((n, C, D), dtype=torch.float64, device=device)
+    u = torch.empty((n, C), dtype=torch.float64, device=device)
+    rc = lib().binf_hmc_gauss_rng_draws_f64(
+        dptr(p0), dptr(u), C, D, n, int(seed) & (2 ** 64 - 1),
+        int(offset) & (2 ** 64 - 1), stream_handle(p0.device))
+    check(rc, 'binf_hmc_gauss_rng_draws_f64')
+    return p0, u
+
+
+def fused_rng_covers(D):
+    """Shapes binf_hmc_sample_n_gauss_rng_f64 accepts (one-wave chains)."""
+    return 1 <= D <= 1024 and pairwise_tree_height(D) <= 3
 
 
 def pairdist_forward(x, pair_i, pair_j):

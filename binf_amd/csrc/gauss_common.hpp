@@ -30,7 +30,47 @@ struct GaussNArgs {
     int32_t thin;            // record every thin-th state (>= 1)
     int32_t n_adapt;         // the first n_adapt transitions adapt the timestep
     int32_t stagger;         // start delay per SIMD wave slot, units of ~64 cycles (0 = none)
+    // draws generated in the kernel (hmc_gauss_rng.hip)
+    uint64_t rng_seed;
+    uint64_t rng_offset;
+    double *p_dump;          // [n x C x D], GAUSS_RNG_DUMP only
+    double *u_dump;          // [n x C],     GAUSS_RNG_DUMP only
 };
+
+// How a [C x D] batch maps onto waves (host side; shared by the launchers)
+struct GaussPlan {
+    int32_t H;        // height of numpy's pairwise tree for length D
+    int LW;           // log2(waves per chain)
+    int tneed;        // elements per lane
+    bool regular;     // all leaves equal, full depth, multiples of 8
+    int64_t blocks;   // workgroups of the one-wave-per-chain / wide kernels
+};
+
+inline GaussPlan gauss_plan(int64_t C, int64_t D)
+{
+    GaussPlan p;
+    p.H = pairwise_tree_height(D);
+    p.LW = p.H > 3 ? p.H - 3 : 0;
+    p.tneed = 1;
+    p.regular = true;
+    int32_t len0 = -1;
+    for (int g = 0; g < (1 << p.H); ++g) {
+        Leaf L = pairwise_leaf((int32_t)D, p.H, g);
+        int tn = (L.len + 7) / 8;
+        if (tn > p.tneed) p.tneed = tn;
+        if (len0 < 0) len0 = L.len;
+        if (L.len != len0 || L.depth != p.H || (L.len & 7)) p.regular = false;
+    }
+    if (p.LW == 0) {
+        const int64_t chains_per_wave = 64 >> (3 + p.H);
+        const int64_t waves = (C + chains_per_wave - 1) / chains_per_wave;
+        p.blocks = (waves + 3) / 4;
+    } else {
+        const int64_t chains_per_block = (p.LW == 3 ? 8 : 4) >> p.LW;
+        p.blocks = (C + chains_per_block - 1) / chains_per_block;
+    }
+    return p;
+}
 
 // hmc_gauss_split.hip: few chains of D in {768, 1024} spread over 2 / 4 waves each
 int gauss_split_factor(int64_t C, int32_t H, bool regular, int tneed);

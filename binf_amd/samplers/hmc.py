@@ -126,6 +126,9 @@ class HMCSampler(object):
         q0 = (state if state.dim() == 2 else state.reshape(1, -1)).contiguous()
         C, D = q0.shape
         dev = q0.device
+        if p0 is None and u is None and self._fused_rng(name, D):
+            # the draws are generated inside the sampling kernel
+            return self._sample_n_fused_rng(1)
         if p0 is None:
             p0 = self.rng.normal((C, D), dev)
             own_p = True
@@ -184,14 +187,16 @@ class HMCSampler(object):
         q0 = (state if state.dim() == 2 else state.reshape(1, -1)).contiguous()
         C, D = q0.shape
         dev = q0.device
-        if p0 is None:
-            p0 = self.rng.normal((n, C, D), dev)
-        if u is None:
-            u = self.rng.uniform(n * C, dev)
-        p0 = p0.reshape(n, C, D)
-        u = u.reshape(n, C)
-        spec = self._fused_spec(name, D)
         nrec = n // thin
+        fused_rng = p0 is None and u is None and self._fused_rng(name, D)
+        if not fused_rng:
+            if p0 is None:
+                p0 = self.rng.normal((n, C, D), dev)
+            if u is None:
+                u = self.rng.uniform(n * C, dev)
+            p0 = p0.reshape(n, C, D)
+            u = u.reshape(n, C)
+        spec = self._fused_spec(name, D)
         if out is not None:
             if not record or nrec < 1:
                 raise ValueError('sample_n: out= given but nothing is recorded')
@@ -236,12 +241,20 @@ class HMCSampler(object):
         if self.record_energies:
             eb = torch.empty((n, C), dtype=torch.float64, device=dev)
             ea = torch.empty((n, C), dtype=torch.float64, device=dev)
-        _native.hmc_sample_n_gauss(q0, p0.contiguous(), u.contiguous(), q_out,
-                                   samples, accepted, self.n_accepted, eb, ea,
-                                   self._timestep, self._dt_chain, self.nsteps,
-                                   n, thin, k, x0, n_adapt,
-                                   self.adaption_uprate,
-                                   self.adaption_downrate, _MODES[self.mode])
+        if fused_rng:
+            _native.hmc_sample_n_gauss_rng(q0, q_out, samples, accepted, self.n_accepted,
+                                           eb, ea, self._timestep, self._dt_chain,
+                                           self.nsteps, n, thin, k, x0, n_adapt,
+                                           self.adaption_uprate, self.adaption_downrate,
+                                           _MODES[self.mode], self.rng.seed,
+                                           self.rng.next_offset())
+        else:
+            _native.hmc_sample_n_gauss(q0, p0.contiguous(), u.contiguous(), q_out,
+                                       samples, accepted, self.n_accepted, eb, ea,
+                                       self._timestep, self._dt_chain, self.nsteps,
+                                       n, thin, k, x0, n_adapt,
+                                       self.adaption_uprate,
+                                       self.adaption_downrate, _MODES[self.mode])
         self.last_e_before, self.last_e_after = eb, ea
         self._last_move_accepted = accepted[-1].view(torch.bool)
         self.accepted_history = accepted.view(torch.bool)
@@ -252,6 +265,22 @@ class HMCSampler(object):
         return samples if state.dim() == 2 else samples.reshape((nrec,) + tuple(shape))
 
     # -- fused tier ----------------------------------------------------------
+    def _fused_rng(self, name, D):
+        """True if this sampler's draws can be generated inside the sampling
+        kernel: a device generator that allows it, a Gaussian with a fused
+        kernel, one-wave chains."""
+        if not getattr(self.rng, 'fused', False):
+            return False
+        spec = self._fused_spec(name, D)
+        return spec is not None and spec[0] == 'gauss' and _native.fused_rng_covers(D)
+
+    def _sample_n_fused_rng(self, n):
+        """sample() with in-kernel draws: one transition, the new state."""
+        self.sample_n(n, record=False)
+        if n == 1 and self.last_e_before is not None:
+            self.last_e_before, self.last_e_after = self.last_e_before[0], self.last_e_after[0]
+        return self.state
+
     def _fused_spec(self, name, D):
         """The PDF's fused-kernel descriptor if the library covers this shape,
         else None (generic per-step tier)."""

@@ -29,13 +29,24 @@ class DeviceRNG(object):
     (seed, call order), independent of launch geometry; NOT stream-compatible
     with numpy."""
 
-    def __init__(self, seed=0, device='cuda', normal='ziggurat'):
+    def __init__(self, seed=0, device='cuda', normal='ziggurat', fused=True):
         if normal not in ('ziggurat', 'box_muller'):
             raise ValueError("normal must be 'ziggurat' or 'box_muller'")
         self._normal_kind = 'normal_zig' if normal == 'ziggurat' else 'normal'
         self.seed = int(seed)
         self.offset = 0
         self.device = torch.device(device)
+        # fused: a sampler whose kernel can generate its own draws
+        # (HMCSampler on a Gaussian, one-wave chains) asks for a stream position
+        # with next_offset() instead of for buffers: the momentum never exists
+        # in HBM.  Off = always the stand-alone generator kernels.
+        self.fused = bool(fused)
+
+    def next_offset(self):
+        """Reserve one launch worth of the in-kernel generator's stream."""
+        o = self.offset
+        self.offset += 1
+        return o
 
     def _fill(self, kind, dims, device, advance, **kw):
         from binf_amd import _native

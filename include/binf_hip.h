@@ -119,6 +119,39 @@ int32_t binf_hmc_sample_n_gauss_f64(const double *q0, const double *p0,
                                     int32_t mode, void *stream);
 
 /* ------------------------------------------------------------------------
+ * The same n transitions with the random draws generated INSIDE the kernel:
+ * HMCSampler.sample() as the reference defines it, np.random.normal(size=
+ * q.shape) ... np.random.uniform() (binf/samplers/hmc.py:146,151), with no
+ * momentum buffer in HBM.  Per-lane xoshiro128++ streams seeded from the Philox
+ * block (lane's element set, offset) under `seed`, normals by a 512-layer
+ * ziggurat; deterministic in (seed, offset, C, D), independent of the launch
+ * geometry, NOT numpy's MT19937 stream (parity runs inject host draws through
+ * binf_hmc_sample_n_gauss_f64).  A caller advances `offset` by one per launch.
+ * Arguments as binf_hmc_sample_n_gauss_f64 without p0 / u.
+ * Supported: one-wave chains (pairwise tree height <= 3: any D <= 920 and the
+ * multiples of 8 up to 1024); otherwise BINF_E_UNSUPPORTED (use the stand-alone
+ * generators below + binf_hmc_sample_n_gauss_f64).
+ * ---------------------------------------------------------------------- */
+int32_t binf_hmc_sample_n_gauss_rng_f64(const double *q0, double *q_out,
+                                        double *samples, uint8_t *accepted,
+                                        int64_t *n_accepted, double *e_before,
+                                        double *e_after, double timestep,
+                                        double *dt_chain, int64_t C, int64_t D,
+                                        int32_t nsteps, int32_t n, int32_t thin,
+                                        double k, double x0, int32_t n_adapt,
+                                        double uprate, double downrate,
+                                        int32_t mode, uint64_t seed,
+                                        uint64_t offset, void *stream);
+
+/* The draws binf_hmc_sample_n_gauss_rng_f64 consumes for (seed, offset, C, D, n),
+ * written out instead of used: p0_out [n*C*D], u_out [n*C].  Feeding them to
+ * binf_hmc_sample_n_gauss_f64 reproduces the fused call bit for bit -- the
+ * handle by which the fused generator is tested and its stream inspected. */
+int32_t binf_hmc_gauss_rng_draws_f64(double *p0_out, double *u_out, int64_t C,
+                                     int64_t D, int32_t n, uint64_t seed,
+                                     uint64_t offset, void *stream);
+
+/* ------------------------------------------------------------------------
  * Generic per-step tier: the pieces of HMCSampler.sample() as separate
  * chain-batched launches, for posteriors whose gradient comes from other code
  * (any plug-in with log_prob / gradient, reference binf/samplers/hmc.py:114,143).

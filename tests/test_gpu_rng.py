@@ -119,3 +119,169 @@ def test_ziggurat_normals(device):
     a = rng.normal((8, 16), device)
     b = DeviceRNG(3, device, normal='box_muller').normal((8, 16), device)
     assert a.shape == b.shape and not torch.equal(a, b)
+
+
+# ---------------------------------------------------------------------------
+# the generator fused into the sampling kernel (csrc/xoshiro.hpp,
+# csrc/hmc_gauss_rng.hip): hmc.py:146,151 inside the launch
+# ---------------------------------------------------------------------------
+def _zig512_table():
+    import os
+    import re
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                        'binf_amd', 'csrc', 'zig_tables.hpp')
+    text = open(path).read()
+    body = re.search(r'ZIG512_X\[513\] = \{(.*?)\};', text, re.S).group(1)
+    return np.array([float.fromhex(t) for t in body.replace(',', ' ').split()])
+
+
+class _Xo128(object):
+    """xoshiro128++ (Blackman & Vigna), restated on the host."""
+    M = 0xffffffff
+
+    def __init__(self, stream, seed, offset):
+        r = _native.philox4x32_10([stream & self.M, stream >> 32, offset & self.M, offset >> 32],
+                                  [seed & self.M, (seed >> 32) ^ 0x58534f52])
+        self.s = [int(v) for v in r]
+        if not any(self.s):
+            self.s[0] = 1
+
+    @staticmethod
+    def _rotl(x, k):
+        return ((x << k) | (x >> (32 - k))) & 0xffffffff
+
+    def next(self):
+        s = self.s
+        r = (self._rotl((s[0] + s[3]) & self.M, 7) + s[0]) & self.M
+        t = (s[1] << 9) & self.M
+        s[2] ^= s[0]
+        s[3] ^= s[1]
+        s[1] ^= s[2]
+        s[0] ^= s[3]
+        s[2] ^= t
+        s[3] = self._rotl(s[3], 11)
+        return r
+
+    def uniform53(self):
+        a, b = self.next(), self.next()
+        return ((a >> 5) * 67108864.0 + (b >> 6)) / 9007199254740992.0
+
+
+def test_fused_generator_bits_match_a_host_restatement(device):
+    """D = 8: every lane owns ONE element, so its stream is: one ziggurat
+    candidate (two outputs), its resolution if it fails, then the uniform.  The
+    host restatement covers the fast path (98 % of the lanes) bit for bit."""
+    zx = _zig512_table()
+    assert zx.shape == (513,) and zx[512] == 0.0 and zx[1] == 3.852046150368391
+    C, D, seed, offset = 300, 8, 2 ** 40 + 12345, 7
+    p0, u = _native.hmc_gauss_rng_draws(1, C, D, seed, offset, device)
+    p0, u = p0.cpu().numpy()[0], u.cpu().numpy()[0]
+    checked = 0
+    for c in range(C):
+        for j in range(D):
+            g = _Xo128(c * 8 + j, seed, offset)           # stream = chain * 8 lanes + accumulator
+            hi, lo = g.next(), g.next()
+            layer = hi >> 23
+            bits = ((0x3ff00000 | (hi & 0xfffff)) << 32) | lo
+            d = np.frombuffer(np.uint64(bits).tobytes(), dtype=np.float64)[0]
+            x = (2.0 * d - 3.0) * zx[layer]
+            if abs(x) < zx[layer + 1]:
+                assert p0[c, j] == x, (c, j)
+                checked += 1
+                if j == 0:
+                    assert u[c] == g.uniform53(), c
+    assert checked > 0.97 * C * D
+
+
+FUSED_SHAPES = [(64, 1024, 20, 1.0, 0.0, 'exact'), (70, 768, 5, 2.5, 0.3, 'exact'),
+                (5, 33, 7, 1.0, 0.0, 'fma'), (9, 200, 3, 1.0, -0.2, 'exact'),
+                (4, 1000, 2, 1.0, 0.0, 'exact'), (3, 920, 2, 2.5, 0.3, 'fma'),
+                (130, 7, 4, 1.0, 0.0, 'exact'), (17, 1, 3, 1.0, 0.0, 'exact'),
+                (6, 258, 2, 1.0, 0.0, 'exact'), (2100, 1024, 2, 1.0, 0.0, 'exact')]
+
+
+@pytest.mark.parametrize('C,D,L,k,x0,mode', FUSED_SHAPES)
+def test_fused_generator_equals_sampling_from_its_own_dump(device, C, D, L, k, x0, mode):
+    """sample_n with the draws generated in the kernel == sample_n fed with the
+    dump of the same stream: states, flags, energies, adapted step sizes, all
+    bit for bit (regular and ragged trees, several chains per wave, adaption)."""
+    n, seed = 5, 99
+    q0 = torch.from_numpy(np.random.RandomState(D).standard_normal((C, D))).to(device)
+    dt = 0.9 / np.sqrt(k * max(D, 4))
+    kw = dict(timestep_adaption_limit=4, variable_name='x', mode=mode, record_energies=True)
+    a = HMCSampler(IsotropicGaussian(k, x0), q0, dt, L, rng=DeviceRNG(seed, device), **kw)
+    assert a._fused_rng('x', D)
+    rec_a = a.sample_n(n)                                    # offset 0
+    rec_a2 = a.sample_n(2, thin=2)                           # offset 1
+    p0, u = _native.hmc_gauss_rng_draws(n, C, D, seed, 0, device)
+    p1, u1 = _native.hmc_gauss_rng_draws(2, C, D, seed, 1, device)
+    b = HMCSampler(IsotropicGaussian(k, x0), q0, dt, L, **kw)
+    rec_b = b.sample_n(n, p0=p0, u=u)
+    e_b = (b.last_e_before.clone(), b.last_e_after.clone())
+    h_b = b.accepted_history.clone()
+    rec_b2 = b.sample_n(2, thin=2, p0=p1, u=u1)
+    assert torch.equal(rec_a, rec_b) and torch.equal(rec_a2, rec_b2)
+    assert torch.equal(a.state, b.state) and torch.equal(a.n_accepted, b.n_accepted)
+    assert torch.equal(a.timestep, b.timestep)
+    assert torch.equal(a.last_e_after, b.last_e_after)
+    # single sample() calls take the same route
+    a2 = HMCSampler(IsotropicGaussian(k, x0), q0, dt, L, rng=DeviceRNG(seed, device), **kw)
+    x = a2.sample()
+    assert torch.equal(x, rec_b[0]) and torch.equal(a2.last_move_accepted, h_b[0])
+    assert torch.equal(a2.last_e_before, e_b[0][0])
+    assert 0 < float(h_b.double().mean()) <= 1.0
+
+
+def test_fused_generator_stream_properties(device):
+    """The dump of the in-kernel stream at C2's shape: determinism, independence
+    of the batch size, distribution (moments, KS, tails beyond the base layer),
+    no correlation between the elements a lane draws in sequence, between
+    neighbouring lanes, between consecutive transitions."""
+    from scipy import stats
+    C, D, n = 4096, 1024, 2
+    p0, u = _native.hmc_gauss_rng_draws(n, C, D, 21, 5, device)
+    again, _ = _native.hmc_gauss_rng_draws(n, C, D, 21, 5, device)
+    assert torch.equal(p0, again)
+    small, us = _native.hmc_gauss_rng_draws(n, 10, D, 21, 5, device)
+    assert torch.equal(small, p0[:, :10]) and torch.equal(us, u[:, :10])
+    other, uo = _native.hmc_gauss_rng_draws(n, 10, D, 21, 6, device)
+    assert not torch.equal(other, small) and not torch.equal(uo, us)
+    other, _ = _native.hmc_gauss_rng_draws(n, 10, D, 22, 5, device)
+    assert not torch.equal(other, small)
+    z = p0.cpu().numpy()
+    uu = u.cpu().numpy().reshape(-1)
+    N = z.size
+    flat = z.reshape(-1)
+    assert abs(flat.mean()) < 2e-3 and abs(flat.var() - 1.0) < 3e-3
+    assert abs((flat ** 3).mean()) < 6e-3 and abs((flat ** 4).mean() - 3.0) < 2e-2
+    assert abs((flat ** 6).mean() - 15.0) < 0.3
+    sub = flat[::8][:1_000_000]
+    assert stats.kstest(sub, 'norm').statistic < 1.63 / np.sqrt(sub.size)
+    for t in (1.0, 2.0, 3.0, 3.852046150368391, 4.5):
+        want = 2 * stats.norm.sf(t)
+        got = (np.abs(flat) > t).mean()
+        assert abs(got - want) < 5 * np.sqrt(want / N) + 1e-7, (t, got, want)
+    assert np.abs(flat).max() < 7.0 and abs((flat > 0).mean() - 0.5) < 1e-3
+    lim = 5 / np.sqrt(N / 2)
+    assert abs(np.corrcoef(z[0, :, :-1].ravel(), z[0, :, 1:].ravel())[0, 1]) < lim   # neighbour lanes
+    assert abs(np.corrcoef(z[0, :, :-8].ravel(), z[0, :, 8:].ravel())[0, 1]) < lim   # same lane, next draw
+    assert abs(np.corrcoef(z[0].ravel(), z[1].ravel())[0, 1]) < lim                  # next transition
+    assert abs(np.corrcoef(z[0, :-1].ravel(), z[0, 1:].ravel())[0, 1]) < lim         # next chain
+    assert 0.0 <= uu.min() and uu.max() < 1.0
+    assert abs(uu.mean() - 0.5) < 5 / np.sqrt(12 * uu.size)
+    assert stats.kstest(uu, 'uniform').statistic < 1.63 / np.sqrt(uu.size)
+
+
+def test_fused_generator_limits_and_fallback(device):
+    z = torch.zeros((3, 2048), dtype=torch.float64, device=device)
+    with pytest.raises(NotImplementedError):
+        _native.hmc_gauss_rng_draws(1, 3, 2048, 0, 0, device)
+    # longer chains: DeviceRNG falls back to the stand-alone generator kernels
+    s = HMCSampler(IsotropicGaussian(), z, 0.02, 3, variable_name='x', rng=DeviceRNG(1, device))
+    assert not s._fused_rng('x', 2048)
+    assert s.sample_n(2).shape == (2, 3, 2048)
+    # ... and so does a generator that was told not to fuse
+    s = HMCSampler(IsotropicGaussian(), z[:, :64].contiguous(), 0.02, 3, variable_name='x',
+                   rng=DeviceRNG(1, device, fused=False))
+    assert not s._fused_rng('x', 64)
+    assert s.sample().shape == (3, 64)
