@@ -43,6 +43,11 @@ SIGNATURES = {
                                            _vp, _vp, _f64, _vp, _i64, _i64,
                                            _i32, _i32, _i32, _f64, _f64, _i32,
                                            _f64, _f64, _i32, _vp]),
+    'binf_hmc_sample_gauss_big_workspace_bytes': (_i64, [_i64, _i64]),
+    'binf_hmc_sample_gauss_big_f64': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                             _f64, _vp, _i64, _i64, _i32, _f64,
+                                             _f64, _i32, _f64, _f64, _i32, _vp,
+                                             _i64, _vp]),
     'binf_hmc_sample_n_gauss_rng_f64': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                                _f64, _vp, _i64, _i64, _i32, _i32,
                                                _i32, _f64, _f64, _i32, _f64, _f64,
@@ -187,6 +192,29 @@ def stream_handle(device=None):
     return torch.cuda.current_stream(device).cuda_stream
 
 
+def _launcher(fn):
+    """Every wrapper that enqueues a kernel: all tensor arguments must live on
+    ONE device, and the launch runs with that device current (the stream handle
+    passed to the C ABI belongs to it)."""
+    import functools
+
+    @functools.wraps(fn)
+    def guarded(*args, **kw):
+        dev = None
+        for a in list(args) + list(kw.values()):
+            if isinstance(a, torch.Tensor) and a.is_cuda:
+                if dev is None:
+                    dev = a.device
+                elif a.device != dev:
+                    raise ValueError('%s: tensors on different devices (%s and %s)'
+                                     % (fn.__name__, dev, a.device))
+        if dev is None or dev.index == torch.cuda.current_device():
+            return fn(*args, **kw)
+        with torch.cuda.device(dev):
+            return fn(*args, **kw)
+    return guarded
+
+
 def pairwise_tree_height(n):
     return lib().binf_pairwise_tree_height(int(n))
 
@@ -201,6 +229,7 @@ def pairwise_leaf(n, H, path):
     return off.value, ln.value, depth.value, canon.value
 
 
+@_launcher
 def hmc_sample_gauss(q0, p0, u, q_out, accepted, n_accepted, e_before, e_after, timestep,
                      dt_chain, nsteps, k, x0, adapt, uprate, downrate,
                      mode=MODE_EXACT):
@@ -232,6 +261,7 @@ def _cd(x):
     return x.shape
 
 
+@_launcher
 def row_sum(x, op=ROW_SUM, shift=0.0, scale=1.0, out=None):
     """scale * np.sum(f(x[c, :])) per chain, numpy pairwise order."""
     C, D = _cd(x)
@@ -245,6 +275,7 @@ def row_sum(x, op=ROW_SUM, shift=0.0, scale=1.0, out=None):
     return out
 
 
+@_launcher
 def leapfrog_kick(p, grad, timestep, dt_chain=None, half=False,
                   mode=MODE_EXACT):
     C, D = _cd(p)
@@ -255,6 +286,7 @@ def leapfrog_kick(p, grad, timestep, dt_chain=None, half=False,
     check(rc, 'binf_leapfrog_kick_f64')
 
 
+@_launcher
 def leapfrog_kick_drift(q, p, grad, timestep, dt_chain=None, mode=MODE_EXACT):
     """p -= dt * grad; q += p * dt  (kick then drift, one pass)."""
     C, D = _cd(q)
@@ -266,6 +298,7 @@ def leapfrog_kick_drift(q, p, grad, timestep, dt_chain=None, mode=MODE_EXACT):
     check(rc, 'binf_leapfrog_kick_drift_f64')
 
 
+@_launcher
 def leapfrog_drift(q, p, timestep, dt_chain=None, mode=MODE_EXACT):
     C, D = _cd(q)
     rc = lib().binf_leapfrog_drift_f64(
@@ -275,6 +308,7 @@ def leapfrog_drift(q, p, timestep, dt_chain=None, mode=MODE_EXACT):
     check(rc, 'binf_leapfrog_drift_f64')
 
 
+@_launcher
 def gauss_grad(x, k, x0, out=None):
     C, D = _cd(x)
     if out is None:
@@ -287,6 +321,7 @@ def gauss_grad(x, k, x0, out=None):
     return out
 
 
+@_launcher
 def accept_select(q_prop, q_old, e_before, e_after, u, q_out, accepted,
                   n_accepted=None, dt_chain=None, adapt=False, uprate=1.05, downrate=0.95):
     C, D = _cd(q_prop)
@@ -303,6 +338,7 @@ def accept_select(q_prop, q_old, e_before, e_after, u, q_out, accepted,
     check(rc, 'binf_accept_select_f64')
 
 
+@_launcher
 def clipped_exp(x):
     """exp(clip(x, -308, 709)) elementwise (csb.numeric.exp)."""
     require_device(x, 'x')
@@ -338,6 +374,7 @@ def _precision_args(precision, C, device):
     return float(precision), None
 
 
+@_launcher
 def row_sumsq_diff(x, y, scale=1.0, weights=None):
     C, D = _cd(x)
     out = torch.empty(C, dtype=torch.float64, device=x.device)
@@ -350,6 +387,7 @@ def row_sumsq_diff(x, y, scale=1.0, weights=None):
     return out
 
 
+@_launcher
 def poly_forward(coeffs, xs):
     C, K = _cd(coeffs)
     N = xs.numel()
@@ -361,6 +399,7 @@ def poly_forward(coeffs, xs):
     return out
 
 
+@_launcher
 def gauss_err_grad(mock, ys, precision):
     C, N = _cd(mock)
     tau, tau_chain = _precision_args(precision, C, mock.device)
@@ -374,6 +413,7 @@ def gauss_err_grad(mock, ys, precision):
     return out
 
 
+@_launcher
 def gauss_err_logp(mock, ys, precision):
     C, N = _cd(mock)
     tau, tau_chain = _precision_args(precision, C, mock.device)
@@ -387,6 +427,7 @@ def gauss_err_logp(mock, ys, precision):
     return out
 
 
+@_launcher
 def poly_gauss_logp(coeffs, xs, ys, precision):
     C, K = _cd(coeffs)
     N = xs.numel()
@@ -401,6 +442,7 @@ def poly_gauss_logp(coeffs, xs, ys, precision):
     return out
 
 
+@_launcher
 def hmc_sample_poly(q0, p0, u, q_out, accepted, n_accepted, e_before, e_after,
                     xs, ys, precision, prior_means, prior_vars, prior_first,
                     lp_pre, lp_post, timestep, dt_chain, nsteps, adapt, uprate,
@@ -431,6 +473,7 @@ def hmc_sample_poly(q0, p0, u, q_out, accepted, n_accepted, e_before, e_after,
 _grad_ws = {}
 
 
+@_launcher
 def poly_gauss_grad(coeffs, design, ys, precision):
     C, K = _cd(coeffs)
     N = ys.numel()
@@ -462,6 +505,7 @@ def poly_gauss_grad(coeffs, design, ys, precision):
     return out
 
 
+@_launcher
 def gamma_precision_update(g, lp_unit, prior_rate):
     C = g.numel()
     out = torch.empty(C, dtype=torch.float64, device=g.device)
@@ -472,6 +516,7 @@ def gamma_precision_update(g, lp_unit, prior_rate):
     return out
 
 
+@_launcher
 def hmc_sample_n_gauss(q0, p0, u, q_out, samples, accepted, n_accepted,
                        e_before, e_after, timestep, dt_chain, nsteps, n, thin,
                        k, x0, n_adapt, uprate, downrate, mode=MODE_EXACT):
@@ -495,6 +540,34 @@ def hmc_sample_n_gauss(q0, p0, u, q_out, samples, accepted, n_accepted,
     check(rc, 'binf_hmc_sample_n_gauss_f64')
 
 
+def gauss_persist_covers(D):
+    """Shapes the persistent kernel (binf_hmc_sample_[n_]gauss_f64) accepts."""
+    return 1 <= D <= 8192 and pairwise_tree_height(D) <= 6
+
+
+@_launcher
+def hmc_sample_gauss_big(q0, p0, u, q_out, accepted, n_accepted, e_before, e_after,
+                         timestep, dt_chain, nsteps, k, x0, adapt, uprate, downrate,
+                         mode=MODE_EXACT):
+    """binf_hmc_sample_gauss_big_f64 (chains of any length) on torch's current
+    stream; the chunk-sum scratch is allocated here (stream-ordered by torch's
+    caching allocator)."""
+    C, D = _cd(q0)
+    nbytes = lib().binf_hmc_sample_gauss_big_workspace_bytes(C, D)
+    ws = torch.empty(max(1, nbytes // 8), dtype=torch.float64, device=q0.device)
+    rc = lib().binf_hmc_sample_gauss_big_f64(
+        dptr(q0, numel=C * D, name='q0'), dptr(p0, numel=C * D, name='p0'),
+        dptr(u, numel=C, name='u'), dptr(q_out, numel=C * D, name='q_out'),
+        dptr(accepted, torch.uint8, C, 'accepted'),
+        dptr(n_accepted, torch.int64, C, 'n_accepted'),
+        dptr(e_before, numel=C, name='e_before'), dptr(e_after, numel=C, name='e_after'),
+        float(timestep), dptr(dt_chain, numel=C, name='dt_chain'), C, D, int(nsteps),
+        float(k), float(x0), int(bool(adapt)), float(uprate), float(downrate), int(mode),
+        dptr(ws), nbytes, stream_handle(q0.device))
+    check(rc, 'binf_hmc_sample_gauss_big_f64')
+
+
+@_launcher
 def hmc_sample_n_gauss_rng(q0, q_out, samples, accepted, n_accepted, e_before,
                            e_after, timestep, dt_chain, nsteps, n, thin, k, x0,
                            n_adapt, uprate, downrate, mode, seed, offset):
@@ -537,6 +610,7 @@ def fused_rng_covers(D):
     return 1 <= D <= 1024 and pairwise_tree_height(D) <= 3
 
 
+@_launcher
 def pairdist_forward(x, pair_i, pair_j):
     C, D = _cd(x)
     if D % 3:
@@ -551,6 +625,7 @@ def pairdist_forward(x, pair_i, pair_j):
     return out
 
 
+@_launcher
 def pairdist_gauss_logp(x, pair_i, pair_j, ys, precision):
     """Gaussian log-likelihood of the pair distances, fused (no [C x n_pairs]
     intermediate)."""
@@ -569,6 +644,7 @@ def pairdist_gauss_logp(x, pair_i, pair_j, ys, precision):
     return out
 
 
+@_launcher
 def pairdist_gauss_grad(x, ymat, precision):
     C, D = _cd(x)
     if D % 3:
@@ -592,6 +668,7 @@ def philox4x32_10(counter, key):
     return [int(x) for x in o]
 
 
+@_launcher
 def rng_fill(kind, out, seed, offset, shape=None):
     """Fill the contiguous f64 device tensor `out` with uniform / normal /
     gamma(shape) draws of the Philox stream (seed, offset)."""
@@ -613,11 +690,14 @@ def rng_fill(kind, out, seed, offset, shape=None):
     return out
 
 
+@_launcher
 def pairdist_leapfrog(q, p, ymat, precision, prior, prior_first, timestep,
                       dt_chain, nsteps, mode=MODE_EXACT):
     """In-place leapfrog of (q, p) for the restraint posterior; prior is None
     or (k, x0) of an isotropic Gaussian on the coordinates."""
     C, D = _cd(q)
+    if D % 3:
+        raise ValueError('coordinates must be [n_chains, 3 * n_beads]')
     n = D // 3
     tau, tau_chain = _precision_args(precision, C, q.device)
     k, x0 = prior if prior is not None else (0.0, 0.0)

@@ -1,0 +1,322 @@
+// Fused Gaussian HMC for chains of ANY length (D > 8192, or a length <= 8192 whose
+// pairwise tree is deeper than the persistent kernel handles): one
+// HMCSampler.sample() (binf/samplers/hmc.py:136-164,183-191) on the reference's
+// TestHO Gaussian (binf/pdf/__init__.py:181-191) in three launches instead of
+// ~3 L launches of the per-step tier, 24 D bytes per chain instead of 32 D per
+// leapfrog step.  Same arithmetic, same bits as the other tiers.  gfx950, wave64.
+//
+// np.sum of a long vector is a CHAIN of chunk sums: numpy's buffered reduction
+// feeds its pairwise loop 8192 elements at a time, r = r + pairwise(chunk).  So:
+//
+//  1. trajectory kernel -- one 256-thread workgroup per (chain, 8192-chunk).
+//     A group of 8 lanes owns one leaf of the chunk's pairwise tree (<= 128
+//     elements, lane j the elements off + 8 t + j -- numpy's j-th accumulator);
+//     the trajectory is elementwise, so q and p (16 + 16 doubles per lane) stay
+//     in registers for all L steps; the proposal goes straight to q_out.  The
+//     four sums the energies need (q0^2, p0^2, q_L^2, p_L^2) are formed per lane,
+//     per leaf (xor-shuffles 1, 2, 4 + tail elements), then up the chunk's tree
+//     through LDS -- bit-identical to pairwise(chunk) -- and written to a small
+//     workspace [C][chunks][4].
+//  2. finish kernel -- one thread per chain adds the chunk sums in order, forms
+//     E_before / E_after, runs the clipped-exp Metropolis test, adapts, counts.
+//  3. restore kernel -- flat 16-byte copy of q0 over q_out for REJECTED chains
+//     only (accepted chains cost one flag read per 2 KiB).
+#include "gauss_common.hpp"
+#include "rowsum.hpp"
+
+namespace binf {
+
+struct BigArgs {
+    const double *q0;
+    const double *p0;
+    double *q_out;
+    double *ws;              // [C][nchunks][4]: sum q0^2, p0^2, qL^2, pL^2 per chunk
+    const double *dt_chain;
+    double timestep;
+    double k;
+    double x0;
+    int64_t C;
+    int64_t D;
+    int32_t nchunks;
+    int32_t nsteps;
+    int32_t H;               // largest tree height among a row's chunks (<= 7)
+};
+
+// Leaf sum of per-lane register values: in-lane running sum r over t < T
+// (numpy's accumulator j), combined ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)), then
+// the leaf's tail elements in order.  All lanes of the wave call it.
+__device__ inline double leaf_finish(double r, double tail, int T, int rem, int lane)
+{
+    r = r + shfl_xor_f64(r, 1);
+    r = r + shfl_xor_f64(r, 2);
+    r = r + shfl_xor_f64(r, 4);
+    double res = (T > 0) ? r : -0.0;
+    const int leafbase = lane & ~7;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+        const double v = shfl_f64(tail, leafbase + i);
+        const double s = res + v;
+        res = (i < rem) ? s : res;
+    }
+    return res;
+}
+
+template <bool UNIT, bool FMA>
+__global__ void __launch_bounds__(256) hmc_gauss_big_traj_kernel(const BigArgs a)
+{
+    constexpr int TM = 16;                   // elements per lane (leaves are <= 128 long)
+    constexpr int GS = 8;
+    __shared__ double S[4][128];
+    __shared__ int dep[128];
+    const int H = a.H;
+    const int npaths = 1 << H;
+    const int lane = threadIdx.x & 63;
+    const int j = lane & 7;
+    const int group = threadIdx.x >> 3;      // 32 groups of 8 lanes
+    const int64_t c = blockIdx.x / a.nchunks;
+    const int chunk = (int)(blockIdx.x % a.nchunks);
+    const int64_t cbase = (int64_t)chunk * NPY_BUFSIZE;
+    const int n = (a.D - cbase < NPY_BUFSIZE) ? (int)(a.D - cbase) : NPY_BUFSIZE;
+    const double dt = a.dt_chain ? a.dt_chain[c] : a.timestep;
+    const double hdt = 0.5 * dt;
+    const double *q0 = a.q0 + c * a.D + cbase;
+    const double *p0 = a.p0 + c * a.D + cbase;
+    double *qo = a.q_out + c * a.D + cbase;
+
+    for (int base = 0; base < npaths; base += 32) {
+        const int path = base + group;
+        const bool act = path < npaths;
+        const Leaf L = pairwise_leaf(n, H, act ? path : 0);
+        // a leaf above depth H is reached by several paths: only the lowest one
+        // integrates it, the others copy its sums below
+        const bool work = act && L.canonical;
+        const int T = (L.len >= 8) ? (L.len >> 3) : 0;
+        const int rem = (L.len >= 8) ? (L.len & 7) : L.len;
+        // two halves of 8 elements per lane, one after the other: the running
+        // sums continue across them, and half the registers are live at a time
+        LaneSum sq0 = {0.0, 0.0}, sp0 = {0.0, 0.0}, sqL = {0.0, 0.0}, spL = {0.0, 0.0};
+#pragma unroll
+        for (int h = 0; h < TM / GS; ++h) {
+            double q[GS], p[GS];
+#pragma unroll
+            for (int i = 0; i < GS; ++i) {
+                const int t = h * GS + i;
+                const bool m = work && (8 * t + j < L.len);
+                q[i] = m ? q0[L.off + 8 * t + j] : 0.0;
+                p[i] = m ? p0[L.off + 8 * t + j] : 0.0;
+            }
+#pragma unroll
+            for (int i = 0; i < GS; ++i) {                     // hmc.py:143,148
+                const double d = UNIT ? q[i] : q[i] - a.x0;
+                lane_sum_add<false>(sq0, d * d, h * GS + i, T);
+                lane_sum_add<false>(sp0, p[i] * p[i], h * GS + i, T);
+            }
+#pragma unroll
+            for (int i = 0; i < GS; ++i)                       // hmc.py:116
+                p[i] = kick<FMA>(p[i], hdt, gauss_grad<UNIT>(q[i], a.k, a.x0));
+            for (int l = 0; l < a.nsteps - 1; ++l) {           // hmc.py:118-120
+#pragma unroll
+                for (int i = 0; i < GS; ++i) {
+                    q[i] = drift<FMA>(q[i], p[i], dt);
+                    p[i] = kick<FMA>(p[i], dt, gauss_grad<UNIT>(q[i], a.k, a.x0));
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < GS; ++i) {                     // hmc.py:122-123
+                q[i] = drift<FMA>(q[i], p[i], dt);
+                p[i] = kick<FMA>(p[i], hdt, gauss_grad<UNIT>(q[i], a.k, a.x0));
+            }
+#pragma unroll
+            for (int i = 0; i < GS; ++i) {                     // hmc.py:150
+                const int t = h * GS + i;
+                const double d = UNIT ? q[i] : q[i] - a.x0;
+                lane_sum_add<false>(sqL, d * d, t, T);
+                lane_sum_add<false>(spL, p[i] * p[i], t, T);
+                if (work && (8 * t + j < L.len)) qo[L.off + 8 * t + j] = q[i];
+            }
+            asm volatile("" : "+v"(sq0.r), "+v"(sp0.r), "+v"(sqL.r), "+v"(spL.r));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        const double r0 = leaf_finish(sq0.r, sq0.tail, T, rem, lane);
+        const double r1 = leaf_finish(sp0.r, sp0.tail, T, rem, lane);
+        const double r2 = leaf_finish(sqL.r, sqL.tail, T, rem, lane);
+        const double r3 = leaf_finish(spL.r, spL.tail, T, rem, lane);
+        if (act && j == 0) {
+            dep[path] = L.depth;
+            if (work) {
+                S[0][path] = r0; S[1][path] = r1; S[2][path] = r2; S[3][path] = r3;
+            }
+        }
+    }
+    __syncthreads();
+    // redundant paths take the sums of the leaf they coincide with
+    if ((int)threadIdx.x < npaths) {
+        const int pth = threadIdx.x;
+        const int canon = pth & ~((1 << (H - dep[pth])) - 1);
+        if (canon != pth) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) S[v][pth] = S[v][canon];
+        }
+    }
+    __syncthreads();
+    // up the chunk's tree: level l joins the two depth-(H-l) subtrees
+    for (int l = 0; l < H; ++l) {
+        double v[4] = {0.0, 0.0, 0.0, 0.0};
+        const int pth = threadIdx.x;
+        if (pth < npaths) {
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const double mine = S[w][pth];
+                v[w] = (dep[pth] >= H - l) ? mine + S[w][pth ^ (1 << l)] : mine;
+            }
+        }
+        __syncthreads();
+        if (pth < npaths) {
+#pragma unroll
+            for (int w = 0; w < 4; ++w) S[w][pth] = v[w];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x < 4)
+        a.ws[(c * a.nchunks + chunk) * 4 + threadIdx.x] = S[threadIdx.x][0];
+}
+
+struct BigFinishArgs {
+    const double *ws;
+    const double *u;
+    uint8_t *accepted;
+    int64_t *n_accepted;
+    double *e_before;
+    double *e_after;
+    double *dt_chain;
+    double k;
+    double uprate;
+    double downrate;
+    int64_t C;
+    int32_t nchunks;
+    int32_t adapt;
+};
+
+__global__ void __launch_bounds__(256) hmc_gauss_big_finish_kernel(const BigFinishArgs a)
+{
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= a.C) return;
+    double t[4] = {0.0, 0.0, 0.0, 0.0};      // the reduction's identity, then chunk after chunk
+    const double *w = a.ws + c * a.nchunks * 4;
+    for (int ch = 0; ch < a.nchunks; ++ch) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) t[v] = t[v] + w[ch * 4 + v];
+    }
+    const double c_lp = -0.5 * a.k;
+    const double Eb = -(c_lp * t[0]) + 0.5 * t[1];            // hmc.py:143,148
+    const double Ea = -(c_lp * t[2]) + 0.5 * t[3];            // hmc.py:150
+    double x = -(Ea - Eb);                                    // hmc.py:151
+    x = (x < -308.0) ? -308.0 : x;
+    x = (x > 709.0) ? 709.0 : x;
+    const bool acc = a.u[c] < exp_clipped_range(x);
+    a.accepted[c] = acc ? 1 : 0;
+    if (a.e_before) a.e_before[c] = Eb;
+    if (a.e_after) a.e_after[c] = Ea;
+    if (a.n_accepted && acc) a.n_accepted[c] += 1;
+    if (a.adapt) {                                            // hmc.py:188-191
+        const double dt = a.dt_chain[c];
+        a.dt_chain[c] = acc ? dt * a.uprate : dt * a.downrate;
+    }
+}
+
+// q_out[c, :] = q0[c, :] for rejected chains (hmc.py:164); VEC doubles per access
+template <int VEC>
+__global__ void __launch_bounds__(256)
+restore_rejected_kernel(double *q_out, const double *q0, const uint8_t *accepted, int64_t n,
+                        int64_t D)
+{
+    const bool small = n <= 0xffffffffLL;
+    for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * VEC; i < n;
+         i += (int64_t)gridDim.x * 256 * VEC) {
+        const int64_t c = small ? (int64_t)((uint32_t)i / (uint32_t)D) : i / D;
+        if (accepted[c]) continue;
+        if (VEC == 2) {
+            *reinterpret_cast<double2 *>(q_out + i) = *reinterpret_cast<const double2 *>(q0 + i);
+        } else {
+            q_out[i] = q0[i];
+        }
+    }
+}
+
+}  // namespace binf
+
+using namespace binf;
+
+static int32_t big_chunks(int64_t D) { return (int32_t)((D + NPY_BUFSIZE - 1) / NPY_BUFSIZE); }
+
+extern "C" int64_t binf_hmc_sample_gauss_big_workspace_bytes(int64_t C, int64_t D)
+{
+    if (C <= 0 || D <= 0) return 0;
+    return C * (int64_t)big_chunks(D) * 4 * (int64_t)sizeof(double);
+}
+
+extern "C" int32_t binf_hmc_sample_gauss_big_f64(
+    const double *q0, const double *p0, const double *u, double *q_out, uint8_t *accepted,
+    int64_t *n_accepted, double *e_before, double *e_after, double timestep, double *dt_chain,
+    int64_t C, int64_t D, int32_t nsteps, double k, double x0, int32_t adapt, double uprate,
+    double downrate, int32_t mode, void *workspace, int64_t workspace_bytes, void *stream)
+{
+    const char *what = "hmc_sample_gauss_big";
+    if (C < 0 || D < 1 || nsteps < 1) return fail(BINF_E_ARG, "%s: need C>=0, D>=1, nsteps>=1", what);
+    if (mode != BINF_MODE_EXACT && mode != BINF_MODE_FMA)
+        return fail(BINF_E_ARG, "%s: unknown mode %d", what, mode);
+    if (C == 0) return 0;
+    if (!q0 || !p0 || !u || !q_out || !accepted) return fail(BINF_E_ARG, "%s: null buffer", what);
+    if (adapt && !dt_chain) return fail(BINF_E_ARG, "%s: adaption needs dt_chain", what);
+    if (C > 0x7fffffffffffffffLL / D) return fail(BINF_E_ARG, "%s: C*D overflows", what);
+    const int64_t bytes = C * D * (int64_t)sizeof(double);
+    const char *qo = (const char *)q_out, *qi = (const char *)q0, *pi = (const char *)p0;
+    if ((qo < qi + bytes && qi < qo + bytes) || (qo < pi + bytes && pi < qo + bytes))
+        return fail(BINF_E_ALIAS, "%s: q_out must not overlap q0 or p0 (rejected chains are "
+                    "restored from q0)", what);
+    const int64_t need = binf_hmc_sample_gauss_big_workspace_bytes(C, D);
+    if (!workspace || workspace_bytes < need)
+        return fail(BINF_E_ARG, "%s: needs %lld bytes of workspace, got %lld", what,
+                    (long long)need, (long long)workspace_bytes);
+    BigArgs a;
+    a.q0 = q0; a.p0 = p0; a.q_out = q_out; a.ws = (double *)workspace; a.dt_chain = dt_chain;
+    a.timestep = timestep; a.k = k; a.x0 = x0; a.C = C; a.D = D; a.nchunks = big_chunks(D);
+    a.nsteps = nsteps;
+    a.H = pairwise_tree_height(D < NPY_BUFSIZE ? D : NPY_BUFSIZE);
+    if (D > NPY_BUFSIZE && D % NPY_BUFSIZE != 0) {
+        const int32_t h_last = pairwise_tree_height(D % NPY_BUFSIZE);
+        if (h_last > a.H) a.H = h_last;
+    }
+    if (a.H > 7) return fail(BINF_E_UNSUPPORTED, "%s: pairwise tree height %d", what, a.H);
+    const int64_t blocks = C * a.nchunks;
+    if (blocks > 0x7fffffffLL) return fail(BINF_E_UNSUPPORTED, "%s: too many (chain, chunk) pairs", what);
+    hipStream_t st = (hipStream_t)stream;
+    const bool unit = (k == 1.0 && x0 == 0.0), fma = (mode == BINF_MODE_FMA);
+    const dim3 grid((unsigned)blocks);
+    if (unit) {
+        if (fma) hmc_gauss_big_traj_kernel<true, true><<<grid, 256, 0, st>>>(a);
+        else     hmc_gauss_big_traj_kernel<true, false><<<grid, 256, 0, st>>>(a);
+    } else {
+        if (fma) hmc_gauss_big_traj_kernel<false, true><<<grid, 256, 0, st>>>(a);
+        else     hmc_gauss_big_traj_kernel<false, false><<<grid, 256, 0, st>>>(a);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "hmc_gauss_big_traj_kernel launch");
+    BigFinishArgs f;
+    f.ws = (const double *)workspace; f.u = u; f.accepted = accepted; f.n_accepted = n_accepted;
+    f.e_before = e_before; f.e_after = e_after; f.dt_chain = dt_chain; f.k = k;
+    f.uprate = uprate; f.downrate = downrate; f.C = C; f.nchunks = a.nchunks;
+    f.adapt = adapt ? 1 : 0;
+    hmc_gauss_big_finish_kernel<<<dim3((unsigned)((C + 255) / 256)), 256, 0, st>>>(f);
+    e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "hmc_gauss_big_finish_kernel launch");
+    const int64_t n = C * D;
+    const bool vec2 = (D % 2 == 0) && ((((uintptr_t)q_out | (uintptr_t)q0) & 15) == 0);
+    int64_t rb = (n + (vec2 ? 511 : 255)) / (vec2 ? 512 : 256);
+    if (rb > (1 << 20)) rb = 1 << 20;
+    if (vec2) restore_rejected_kernel<2><<<dim3((unsigned)rb), 256, 0, st>>>(q_out, q0, accepted, n, D);
+    else      restore_rejected_kernel<1><<<dim3((unsigned)rb), 256, 0, st>>>(q_out, q0, accepted, n, D);
+    e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "restore_rejected_kernel launch");
+    return 0;
+}

@@ -382,16 +382,19 @@ extern "C" int32_t binf_poly_forward_f64(const double *coeffs, const double *xs,
     if (rc) return rc;
     if (C == 0 || N == 0) return 0;
     if (!coeffs || !xs || !out) return fail(BINF_E_ARG, "poly_forward: null buffer");
-    if (C > 65535) return fail(BINF_E_UNSUPPORTED, "poly_forward: more than 65535 chains per call");
-    PolyArgs a;
-    a.theta = coeffs; a.xs = xs; a.ys = nullptr; a.K = (int32_t)K;
     int64_t bx = (N + 255) / 256;
     if (bx > 256) bx = 256;
-    dim3 grid((unsigned)bx, (unsigned)C);
     hipStream_t st = (hipStream_t)stream;
-#define CALL(KM) poly_forward_kernel<KM><<<grid, 256, 0, st>>>(a, out, C, N)
-    BINF_KMAX_DISPATCH(K, CALL);
+    for (int64_t c0 = 0; c0 < C; c0 += 65535) {            // gridDim.y limit
+        const int64_t cn = (C - c0 < 65535) ? C - c0 : 65535;
+        PolyArgs a;
+        a.theta = coeffs + c0 * K; a.xs = xs; a.ys = nullptr; a.K = (int32_t)K;
+        dim3 grid((unsigned)bx, (unsigned)cn);
+        double *o = out + c0 * N;
+#define CALL(KM) poly_forward_kernel<KM><<<grid, 256, 0, st>>>(a, o, cn, N)
+        BINF_KMAX_DISPATCH(K, CALL);
 #undef CALL
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "poly_forward launch");
     return 0;
@@ -406,11 +409,14 @@ extern "C" int32_t binf_gauss_err_grad_f64(const double *mock, const double *ys,
     if (C < 0 || N < 0) return fail(BINF_E_ARG, "gauss_err_grad: negative size");
     if (C == 0 || N == 0) return 0;
     if (!mock || !ys || !out) return fail(BINF_E_ARG, "gauss_err_grad: null buffer");
-    if (C > 65535) return fail(BINF_E_UNSUPPORTED, "gauss_err_grad: more than 65535 chains per call");
     int64_t bx = (N + 255) / 256;
     if (bx > 256) bx = 256;
-    gauss_err_grad_kernel<<<dim3((unsigned)bx, (unsigned)C), 256, 0, (hipStream_t)stream>>>(
-        mock, ys, precision, precision_chain, out, N);
+    for (int64_t c0 = 0; c0 < C; c0 += 65535) {            // gridDim.y limit
+        const int64_t cn = (C - c0 < 65535) ? C - c0 : 65535;
+        gauss_err_grad_kernel<<<dim3((unsigned)bx, (unsigned)cn), 256, 0, (hipStream_t)stream>>>(
+            mock + c0 * N, ys, precision, precision_chain ? precision_chain + c0 : nullptr,
+            out + c0 * N, N);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "gauss_err_grad launch");
     return 0;
@@ -477,9 +483,18 @@ extern "C" int32_t binf_poly_gauss_grad_f64(const double *coeffs, const double *
     if (C == 0) return 0;
     if (!coeffs || !out || ((!design || !ys) && N > 0))
         return fail(BINF_E_ARG, "poly_gauss_grad: null buffer");
-    int ns = grad_splits(C, N);
+    // The data range is summed in ns pieces (partial sums reduced in a fixed
+    // order); ns follows from (C, N) alone -- binf_poly_gauss_grad_workspace_bytes
+    // reports the scratch it needs -- so a call is deterministic, but the SAME
+    // chain evaluated in batches of different size may differ at rounding level
+    // (as the reference's BLAS contraction does between builds); a missing or
+    // short workspace is an error, never a silent change of summation order.
+    const int ns = grad_splits(C, N);
     const int64_t need = ns > 1 ? (int64_t)ns * C * K * (int64_t)sizeof(double) : 0;
-    if (need > 0 && (!workspace || workspace_bytes < need)) ns = 1;   // no workspace: single split
+    if (need > 0 && (!workspace || workspace_bytes < need))
+        return fail(BINF_E_ARG, "poly_gauss_grad: needs %lld bytes of workspace "
+                    "(binf_poly_gauss_grad_workspace_bytes), got %lld",
+                    (long long)need, (long long)workspace_bytes);
     const int ntiles = (int)((N + 15) / 16);
     GradArgs a;
     a.theta = coeffs; a.A = design; a.ys = ys; a.tau_chain = precision_chain;

@@ -60,7 +60,10 @@ class DistanceForwardModel(AbstractForwardModel):
         return copy
 
     def native_spec(self):
-        return ('pairdist', self)
+        from binf_amd.example.likelihood import _unchanged
+        if _unchanged(self, DistanceForwardModel, ('_evaluate', '_evaluate_jacobi_matrix')):
+            return ('pairdist', self)
+        return None
 
 
 class DistanceErrorModel(GaussianErrorModel):
@@ -93,7 +96,10 @@ class DistanceErrorModel(GaussianErrorModel):
         return copy
 
     def native_spec(self):
-        return ('gaussian_pairdist', self)
+        from binf_amd.example.likelihood import _unchanged
+        if _unchanged(self, GaussianErrorModel, ('_evaluate_log_prob', '_evaluate_gradient')):
+            return ('gaussian_pairdist', self)
+        return None
 
 
 def make_distance_likelihood(target_distances, n_beads):

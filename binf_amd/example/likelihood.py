@@ -18,6 +18,13 @@ def _as2d(x):
     return x if x.dim() == 2 else x.reshape(1, -1)
 
 
+def _unchanged(obj, base, names):
+    """True if ``obj``'s class still uses ``base``'s implementation of every
+    method in ``names`` -- a subclass that overrides one of them must be
+    evaluated as written, not through the fused kernels of the base model."""
+    return all(getattr(type(obj), n, None) is getattr(base, n) for n in names)
+
+
 class ForwardModel(AbstractForwardModel):
     """mock = polynomial(xses, coefficients); Jacobian rows are the powers of
     ``xses`` (reference ``:11-37``).
@@ -35,14 +42,27 @@ class ForwardModel(AbstractForwardModel):
 
     def __init__(self, xses, polynomial):
         super(ForwardModel, self).__init__('polynomial')
+        self._dev = {}
         self.xses = xses
         self.polynomial = polynomial
-        self._dev = {}
         self._register_variable('coefficients', differentiable=True)
         self.update_var_param_types(coefficients=ArrayParameter)
         self._set_original_variables()
 
     # -- device-resident model data -----------------------------------------
+    # The device copies are derived from ``xses`` when first needed and shared
+    # with clones; assigning a new ``xses`` drops THIS object's copies (the
+    # reference reads the attribute on every call).  Mutating the array in place
+    # after first use is not seen: model data are immutable once evaluated.
+    @property
+    def xses(self):
+        return self._xses
+
+    @xses.setter
+    def xses(self, value):
+        self._xses = value
+        self._dev = {}
+
     def _xs_host(self):
         x = self.xses
         return x.detach().cpu().numpy() if isinstance(x, torch.Tensor) \
@@ -88,7 +108,10 @@ class ForwardModel(AbstractForwardModel):
         return copy
 
     def native_spec(self):
-        return ('polynomial', self) if self.is_native else None
+        if self.is_native and _unchanged(self, ForwardModel,
+                                         ('_evaluate', '_evaluate_jacobi_matrix')):
+            return ('polynomial', self)
+        return None
 
 
 class GaussianErrorModel(AbstractErrorModel):
@@ -97,13 +120,25 @@ class GaussianErrorModel(AbstractErrorModel):
 
     def __init__(self, ys):
         super(GaussianErrorModel, self).__init__('error_model')
-        self.ys = ys
         self._dev = {}
+        self.ys = ys
         self._register_variable('mock_data')
         self._register_variable('precision')
         self.update_var_param_types(mock_data=ArrayParameter,
                                     precision=ScalarParameter)
         self._set_original_variables()
+
+    @property
+    def ys(self):
+        return self._ys
+
+    @ys.setter
+    def ys(self, value):
+        # new data: drop this object's device copies (clones keep theirs)
+        self._ys = value
+        self._dev = {}
+        if hasattr(self, '_ymat'):
+            self._ymat = {}
 
     def ys_device(self, device):
         if device not in self._dev:
@@ -131,7 +166,9 @@ class GaussianErrorModel(AbstractErrorModel):
         return copy
 
     def native_spec(self):
-        return ('gaussian', self)
+        if _unchanged(self, GaussianErrorModel, ('_evaluate_log_prob', '_evaluate_gradient')):
+            return ('gaussian', self)
+        return None
 
 
 def make_likelihood(xses, ys, polynomial):

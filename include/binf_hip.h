@@ -119,6 +119,31 @@ int32_t binf_hmc_sample_n_gauss_f64(const double *q0, const double *p0,
                                     int32_t mode, void *stream);
 
 /* ------------------------------------------------------------------------
+ * One transition for chains of ANY length -- what binf_hmc_sample_gauss_f64
+ * does not cover (D > 8192; lengths whose pairwise tree is deeper than 6).
+ * numpy sums long vectors 8192 elements at a time, so the trajectory runs per
+ * (chain, 8192-chunk) with the state in registers, the chunk sums are chained
+ * per chain, and rejected chains are restored from q0: three launches and
+ * 24 D bytes per chain instead of ~3 L launches and 32 D bytes per leapfrog
+ * step of the per-step tier; same bits.  Arguments as
+ * binf_hmc_sample_gauss_f64, plus
+ *   workspace  device scratch of binf_hmc_sample_gauss_big_workspace_bytes(C, D)
+ *              bytes (caller-owned; too small or NULL -> BINF_E_ARG)
+ * q_out must not overlap q0 or p0 (BINF_E_ALIAS).
+ * ---------------------------------------------------------------------- */
+int64_t binf_hmc_sample_gauss_big_workspace_bytes(int64_t C, int64_t D);
+int32_t binf_hmc_sample_gauss_big_f64(const double *q0, const double *p0,
+                                      const double *u, double *q_out,
+                                      uint8_t *accepted, int64_t *n_accepted,
+                                      double *e_before, double *e_after,
+                                      double timestep, double *dt_chain,
+                                      int64_t C, int64_t D, int32_t nsteps,
+                                      double k, double x0, int32_t adapt,
+                                      double uprate, double downrate,
+                                      int32_t mode, void *workspace,
+                                      int64_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------------
  * The same n transitions with the random draws generated INSIDE the kernel:
  * HMCSampler.sample() as the reference defines it, np.random.normal(size=
  * q.shape) ... np.random.uniform() (binf/samplers/hmc.py:146,151), with no
@@ -257,9 +282,14 @@ int32_t binf_poly_gauss_logp_f64(const double *coeffs, const double *xs,
  * pair: out[c,:] = J . ((mock_c - ys) * precision_c) with the Jacobian
  * J = design [K x N] (design[i][n] = xs[n]**i, likelihood.py:28-30), as two
  * chained f64 MFMA products per tile.  workspace: device scratch of
- * binf_poly_gauss_grad_workspace_bytes(C,K,N) bytes (caller-owned; if NULL or
- * too small the data range is not split and small chain counts under-fill
- * the chip).  Deterministic; held to the reference by tolerance (BLAS order). */
+ * binf_poly_gauss_grad_workspace_bytes(C,K,N) bytes (caller-owned; 0 bytes
+ * needed -> may be NULL; NULL or too small otherwise -> BINF_E_ARG, the
+ * summation order is never changed silently).  The data range is summed in a
+ * number of pieces that follows from (C, N), partial sums joined in a fixed
+ * order: a call is deterministic, but the same chain evaluated in batches of
+ * different size (one GPU vs a shard) can differ at rounding level -- inside
+ * the 1e-10 bar the contraction is held to (the reference's BLAS order is not
+ * reproducible either). */
 int64_t binf_poly_gauss_grad_workspace_bytes(int64_t C, int64_t K, int64_t N);
 int32_t binf_poly_gauss_grad_f64(const double *coeffs, const double *design,
                                  const double *ys, double precision,

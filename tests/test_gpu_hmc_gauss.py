@@ -548,3 +548,83 @@ def test_sample_n_generic_pdf_falls_back_to_a_loop(device):
     for i in range(n):
         want = c_oracle.hmc_sample_gauss(want, p0[i], u[i], 0.1, 3)['q_out']
     assert np.array_equal(rec[-1].cpu().numpy(), want)
+
+
+# --------------------------------------------------------------------------
+# chains of any length: the chunked fused path (csrc/hmc_gauss_big.hip)
+# --------------------------------------------------------------------------
+@pytest.mark.parametrize('D,C,L,k,x0,dt,adapt', [
+    (8193, 3, 2, 1.0, 0.0, 0.05, False),       # one full chunk + one element
+    (9000, 3, 2, 1.0, 0.0, 0.05, False),
+    (16384, 5, 3, 2.5, 0.3, 0.03, True),       # two full chunks
+    (20000, 3, 2, 1.0, 0.0, 0.02, False),
+    (7689, 4, 2, 1.0, 0.0, 0.05, True),        # <= 8192 but tree height 7
+    (8191, 2, 2, 2.5, -0.1, 0.04, False),
+    (8192 * 3 + 7, 2, 2, 1.0, 0.0, 0.02, False),   # a last chunk shorter than one accumulator row
+    (40000, 70, 1, 1.0, 0.0, 0.02, True)])
+def test_long_chains_fused_bitwise_vs_oracle(device, D, C, L, k, x0, dt, adapt):
+    """binf_hmc_sample_gauss_big_f64 through HMCSampler (what IsotropicGaussian
+    selects beyond the persistent kernel's reach) against the C restatement:
+    states, flags, energies and adapted step sizes bit for bit -- np.sum's
+    8192-element chunk rule included."""
+    assert not fused_covers(D)
+    rs = np.random.RandomState(D + L)
+    q0 = rs.standard_normal((C, D))
+    p0 = rs.standard_normal((2, C, D))
+    u = rs.uniform(size=(2, C))
+    if adapt:
+        u[0, ::2] = 0.999999           # make sure both branches of the adaption occur
+        p0[0, ::2] *= 3.0
+    s = HMCSampler(IsotropicGaussian(k, x0), dev_t(q0, device), dt, L, variable_name='x',
+                   timestep_adaption_limit=10 if adapt else 0, record_energies=True)
+    dts = np.full(C, dt)
+    q = q0
+    for i in range(2):
+        want = c_oracle.hmc_sample_gauss(q, p0[i], u[i], dts if adapt else dt, L, k, x0,
+                                         nthreads=4)
+        out = s.sample(p0=dev_t(p0[i], device), u=dev_t(u[i], device))
+        assert np.array_equal(out.cpu().numpy(), want['q_out']), i
+        assert np.array_equal(s.last_move_accepted.cpu().numpy(), want['accepted'].astype(bool))
+        assert np.array_equal(s.last_e_before.cpu().numpy(), want['e_before'])
+        assert np.array_equal(s.last_e_after.cpu().numpy(), want['e_after'])
+        if adapt:
+            dts = np.where(want['accepted'].astype(bool), dts * 1.05, dts * 0.95)
+            assert np.array_equal(s.timestep.cpu().numpy(), dts)
+        q = want['q_out']
+    if adapt:
+        acc = s.n_accepted.cpu().numpy()
+        assert 0 < acc.sum() < 2 * C
+
+
+def test_long_chains_sample_n_fma_and_errors(device):
+    D, C, L = 10000, 4, 3
+    rs = np.random.RandomState(1)
+    q0, p0, u = rs.standard_normal((C, D)), rs.standard_normal((3, C, D)), rs.uniform(size=(3, C))
+    # sample_n loops over the chunked kernel: same bits as single calls
+    a = HMCSampler(IsotropicGaussian(), dev_t(q0, device), 0.02, L, variable_name='x')
+    rec = a.sample_n(3, p0=dev_t(p0, device), u=dev_t(u, device))
+    b = HMCSampler(IsotropicGaussian(), dev_t(q0, device), 0.02, L, variable_name='x')
+    for i in range(3):
+        assert torch.equal(b.sample(p0=dev_t(p0[i], device), u=dev_t(u[i], device)), rec[i])
+    # FMA mode: within 1e-10, same flags
+    f = HMCSampler(IsotropicGaussian(), dev_t(q0, device), 0.02, L, variable_name='x', mode='fma')
+    x = f.sample(p0=dev_t(p0[0], device), u=dev_t(u[0], device))
+    assert torch.equal(f.last_move_accepted, a.accepted_history[0])
+    assert np.allclose(x.cpu().numpy(), rec[0].cpu().numpy(), rtol=1e-10, atol=1e-12)
+    # C ABI: aliasing and a short workspace are refused
+    tq, tp, tu = dev_t(q0, device), dev_t(p0[0], device), dev_t(u[0], device)
+    acc = torch.empty(C, dtype=torch.uint8, device=device)
+    lib = _native.lib()
+    need = lib.binf_hmc_sample_gauss_big_workspace_bytes(C, D)
+    assert need == C * 2 * 4 * 8
+    ws = torch.empty(need // 8, dtype=torch.float64, device=device)
+    st = _native.stream_handle(device)
+    args = lambda qo, wsb: (tq.data_ptr(), tp.data_ptr(), tu.data_ptr(), qo, acc.data_ptr(), None,
+                            None, None, 0.02, None, C, D, L, 1.0, 0.0, 0, 1.05, 0.95, 0,
+                            ws.data_ptr(), wsb, st)
+    assert lib.binf_hmc_sample_gauss_big_f64(*args(tq.data_ptr(), need)) == _native.E_ALIAS
+    out = torch.empty_like(tq)
+    assert lib.binf_hmc_sample_gauss_big_f64(*args(out.data_ptr(), need - 8)) == _native.E_ARG
+    assert lib.binf_hmc_sample_gauss_big_f64(*args(out.data_ptr(), need)) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(out, rec[0])

@@ -641,3 +641,88 @@ def test_example_script_itself_one_chain_same_stream(device, seed):
     rate = gips.last_draw_stats['coefficients'].acceptance_rate
     assert abs(float(rate) - ref['acceptance_rate']) < 1e-12
     assert 0.05 < ref['acceptance_rate'] < 0.95
+
+
+def test_gradient_summation_order_depends_on_the_batch_only_within_the_bar(device):
+    """The split of the data range follows (C, N): the same chain in batches of
+    different size may differ at rounding level (documented in the ABI header and
+    DESIGN.md section 6) -- pinned here: always inside 1e-10 of the
+    sum-of-magnitudes scale, bit-identical when the workspace size says the split
+    is the same, and a missing workspace is an error, not another order."""
+    K, N = 33, 16384
+    xs, ys, theta = synth(K, N, 4096, 5)
+    A = ForwardModel(xs, POLYVAL).design_matrix(K, device)
+    tys = dev_t(ys, device)
+    full = _native.poly_gauss_grad(dev_t(theta, device), A, tys, 2.5).cpu().numpy()
+    Jn = np.vstack([xs ** i for i in range(K)])
+    lib = _native.lib()
+    for Cs in (1, 64, 1000, 2048):
+        part = _native.poly_gauss_grad(dev_t(theta[:Cs], device), A, tys, 2.5).cpu().numpy()
+        for c in (0, Cs - 1):
+            B = np.abs(Jn).dot(np.abs((POLYVAL(xs, theta[c]) - ys) * 2.5))
+            assert np.all(np.abs(part[c] - full[c]) <= RTOL * B)
+    # same chains, same batch size, another position in the batch: same bits
+    a = _native.poly_gauss_grad(dev_t(theta[:2048], device), A, tys, 2.5)
+    b = _native.poly_gauss_grad(dev_t(theta[1024:3072], device), A, tys, 2.5)
+    assert torch.equal(a[1024:], b[:1024])
+    need = lib.binf_poly_gauss_grad_workspace_bytes(64, K, N)
+    assert need > 0
+    out = torch.empty((64, K), dtype=torch.float64, device=device)
+    th = dev_t(theta[:64], device)
+    rc = lib.binf_poly_gauss_grad_f64(th.data_ptr(), A.data_ptr(), tys.data_ptr(), 2.5, None,
+                                      out.data_ptr(), None, 0, 64, K, N,
+                                      _native.stream_handle(device))
+    assert rc == _native.E_ARG and 'workspace' in _native.last_error()
+
+
+def test_more_than_65535_chains_per_call(device):
+    """gridDim.y chunks: forward model and error-model gradient for a batch larger
+    than one grid dimension."""
+    K, N, C = 4, 20, 70000
+    xs, ys, _ = synth(K, N, 1, 3, xlim=2.0)
+    theta = np.random.RandomState(0).standard_normal((C, K))
+    mock = _native.poly_forward(dev_t(theta, device), dev_t(xs, device))
+    for c in (0, 65534, 65535, 65536, C - 1):
+        assert np.array_equal(mock[c].cpu().numpy(), POLYVAL(xs, theta[c]))
+    taus = np.random.RandomState(1).uniform(0.5, 2.0, size=C)
+    g = _native.gauss_err_grad(mock, dev_t(ys, device), dev_t(taus, device))
+    for c in (0, 65535, C - 1):
+        assert np.array_equal(g[c].cpu().numpy(), (POLYVAL(xs, theta[c]) - ys) * taus[c])
+
+
+def test_subclassed_models_are_evaluated_as_written_and_new_data_is_seen(device):
+    """A subclass that overrides an evaluation method must not be routed to the
+    fused kernels of its base class; reassigning the model data drops the cached
+    device copies."""
+    class Shifted(ForwardModel):
+        def _evaluate(self, coefficients):
+            return ForwardModel._evaluate(self, coefficients) + 1.0
+
+    class Scaled(GaussianErrorModel):
+        def _evaluate_gradient(self, mock_data, precision):
+            return 2.0 * GaussianErrorModel._evaluate_gradient(self, mock_data, precision)
+
+    xs, ys, theta = synth(4, 20, 5, 1, xlim=2.0)
+    assert ForwardModel(xs, POLYVAL).native_spec() is not None
+    assert Shifted(xs, POLYVAL).native_spec() is None
+    assert GaussianErrorModel(ys).native_spec() is not None
+    assert Scaled(ys).native_spec() is None
+    from binf_amd.pdf.likelihoods import Likelihood
+    tc = dev_t(theta, device)
+    plain = Likelihood('points', ForwardModel(xs, POLYVAL), GaussianErrorModel(ys))
+    shifted = Likelihood('points', Shifted(xs, POLYVAL), GaussianErrorModel(ys))
+    lp0 = plain.log_prob(coefficients=tc, precision=1.0).cpu().numpy()
+    lp1 = shifted.log_prob(coefficients=tc, precision=1.0).cpu().numpy()
+    for c in range(5):
+        mock = POLYVAL(xs, theta[c])
+        assert lp0[c] == -0.5 * np.sum((mock - ys) ** 2) * 1.0
+        assert abs(lp1[c] - (-0.5 * np.sum((mock + 1.0 - ys) ** 2))) <= 1e-12 * abs(lp1[c])
+    # new data on the same model object
+    em = plain.error_model
+    em.ys = ys + 1.0
+    lp2 = plain.log_prob(coefficients=tc, precision=1.0).cpu().numpy()
+    assert lp2[0] == -0.5 * np.sum((POLYVAL(xs, theta[0]) - (ys + 1.0)) ** 2) * 1.0
+    fm = plain.forward_model
+    fm.xses = xs * 0.5
+    lp3 = plain.log_prob(coefficients=tc, precision=1.0).cpu().numpy()
+    assert lp3[0] == -0.5 * np.sum((POLYVAL(xs * 0.5, theta[0]) - (ys + 1.0)) ** 2) * 1.0
