@@ -39,17 +39,21 @@ struct BigArgs {
     int64_t D;
     int32_t nchunks;
     int32_t nsteps;
-    int32_t H;               // largest tree height among a row's chunks (<= 7)
+    int32_t H;               // tree height of the chunks this launch covers (<= 7)
+    int32_t chunk0;          // first chunk of this launch
+    int32_t chunks_here;     // chunks per chain in this launch
 };
 
 // Leaf sum of per-lane register values: in-lane running sum r over t < T
 // (numpy's accumulator j), combined ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)), then
 // the leaf's tail elements in order.  All lanes of the wave call it.
+template <bool REG>
 __device__ inline double leaf_finish(double r, double tail, int T, int rem, int lane)
 {
     r = r + shfl_xor_f64(r, 1);
     r = r + shfl_xor_f64(r, 2);
     r = r + shfl_xor_f64(r, 4);
+    if (REG) return r;                       // 128 elements: no tail
     double res = (T > 0) ? r : -0.0;
     const int leafbase = lane & ~7;
 #pragma unroll
@@ -61,11 +65,12 @@ __device__ inline double leaf_finish(double r, double tail, int T, int rem, int 
     return res;
 }
 
-template <bool UNIT, bool FMA>
+// REG: full 8192-element chunks -- 64 leaves of 128 elements, tree height 6, no
+// ragged leaves, no masks; !REG: the last, shorter chunk of a chain (any length).
+template <bool UNIT, bool FMA, bool REG>
 __global__ void __launch_bounds__(256) hmc_gauss_big_traj_kernel(const BigArgs a)
 {
-    constexpr int TM = 16;                   // elements per lane (leaves are <= 128 long)
-    constexpr int GS = 8;
+    constexpr int GS = 8;                    // a lane's 16 elements, in two halves
     __shared__ double S[4][128];
     __shared__ int dep[128];
     const int H = a.H;
@@ -73,84 +78,117 @@ __global__ void __launch_bounds__(256) hmc_gauss_big_traj_kernel(const BigArgs a
     const int lane = threadIdx.x & 63;
     const int j = lane & 7;
     const int group = threadIdx.x >> 3;      // 32 groups of 8 lanes
-    const int64_t c = blockIdx.x / a.nchunks;
-    const int chunk = (int)(blockIdx.x % a.nchunks);
+    const int64_t c = blockIdx.x / a.chunks_here;
+    const int chunk = a.chunk0 + (int)(blockIdx.x % a.chunks_here);
     const int64_t cbase = (int64_t)chunk * NPY_BUFSIZE;
-    const int n = (a.D - cbase < NPY_BUFSIZE) ? (int)(a.D - cbase) : NPY_BUFSIZE;
+    const int n = REG ? NPY_BUFSIZE
+                      : ((a.D - cbase < NPY_BUFSIZE) ? (int)(a.D - cbase) : NPY_BUFSIZE);
     const double dt = a.dt_chain ? a.dt_chain[c] : a.timestep;
     const double hdt = 0.5 * dt;
     const double *q0 = a.q0 + c * a.D + cbase;
     const double *p0 = a.p0 + c * a.D + cbase;
     double *qo = a.q_out + c * a.D + cbase;
 
-    for (int base = 0; base < npaths; base += 32) {
+    // A lane integrates its leaf in two halves of GS = 8 elements.  The halves of
+    // consecutive leaves form one stream of work items through a two-deep
+    // register ring (A = first halves, B = second halves): while one half runs
+    // its L steps, the loads of the next are in flight.
+    struct Item {
+        Leaf L;
+        bool act, work;
+    };
+    auto item_of = [&](int base) {
+        Item it;
         const int path = base + group;
-        const bool act = path < npaths;
-        const Leaf L = pairwise_leaf(n, H, act ? path : 0);
+        it.act = path < npaths;
+        if (REG) {
+            it.L.off = path * PW_BLOCK; it.L.len = PW_BLOCK; it.L.depth = 6; it.L.canonical = 1;
+            it.work = true;
+            return it;
+        }
+        it.L = pairwise_leaf(n, H, it.act ? path : 0);
         // a leaf above depth H is reached by several paths: only the lowest one
         // integrates it, the others copy its sums below
-        const bool work = act && L.canonical;
-        const int T = (L.len >= 8) ? (L.len >> 3) : 0;
-        const int rem = (L.len >= 8) ? (L.len & 7) : L.len;
-        // two halves of 8 elements per lane, one after the other: the running
-        // sums continue across them, and half the registers are live at a time
-        LaneSum sq0 = {0.0, 0.0}, sp0 = {0.0, 0.0}, sqL = {0.0, 0.0}, spL = {0.0, 0.0};
+        it.work = it.act && it.L.canonical;
+        return it;
+    };
+    auto load_half = [&](double(&q)[GS], double(&p)[GS], const Item &it, int h) {
 #pragma unroll
-        for (int h = 0; h < TM / GS; ++h) {
-            double q[GS], p[GS];
+        for (int i = 0; i < GS; ++i) {
+            const int e = 8 * (h * GS + i) + j;
+            const bool m = REG || (it.work && (e < it.L.len));
+            q[i] = m ? q0[it.L.off + e] : 0.0;
+            p[i] = m ? p0[it.L.off + e] : 0.0;
+        }
+    };
+    LaneSum sq0, sp0, sqL, spL;
+    auto run_half = [&](double(&q)[GS], double(&p)[GS], const Item &it, int h, int T) {
+#pragma unroll
+        for (int i = 0; i < GS; ++i) {                         // hmc.py:143,148
+            const double d = UNIT ? q[i] : q[i] - a.x0;
+            lane_sum_add<REG>(sq0, d * d, h * GS + i, T);
+            lane_sum_add<REG>(sp0, p[i] * p[i], h * GS + i, T);
+        }
+#pragma unroll
+        for (int i = 0; i < GS; ++i)                           // hmc.py:116
+            p[i] = kick<FMA>(p[i], hdt, gauss_grad<UNIT>(q[i], a.k, a.x0));
+        for (int l = 0; l < a.nsteps - 1; ++l) {               // hmc.py:118-120
 #pragma unroll
             for (int i = 0; i < GS; ++i) {
-                const int t = h * GS + i;
-                const bool m = work && (8 * t + j < L.len);
-                q[i] = m ? q0[L.off + 8 * t + j] : 0.0;
-                p[i] = m ? p0[L.off + 8 * t + j] : 0.0;
-            }
-#pragma unroll
-            for (int i = 0; i < GS; ++i) {                     // hmc.py:143,148
-                const double d = UNIT ? q[i] : q[i] - a.x0;
-                lane_sum_add<false>(sq0, d * d, h * GS + i, T);
-                lane_sum_add<false>(sp0, p[i] * p[i], h * GS + i, T);
-            }
-#pragma unroll
-            for (int i = 0; i < GS; ++i)                       // hmc.py:116
-                p[i] = kick<FMA>(p[i], hdt, gauss_grad<UNIT>(q[i], a.k, a.x0));
-            for (int l = 0; l < a.nsteps - 1; ++l) {           // hmc.py:118-120
-#pragma unroll
-                for (int i = 0; i < GS; ++i) {
-                    q[i] = drift<FMA>(q[i], p[i], dt);
-                    p[i] = kick<FMA>(p[i], dt, gauss_grad<UNIT>(q[i], a.k, a.x0));
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < GS; ++i) {                     // hmc.py:122-123
                 q[i] = drift<FMA>(q[i], p[i], dt);
-                p[i] = kick<FMA>(p[i], hdt, gauss_grad<UNIT>(q[i], a.k, a.x0));
+                p[i] = kick<FMA>(p[i], dt, gauss_grad<UNIT>(q[i], a.k, a.x0));
             }
-#pragma unroll
-            for (int i = 0; i < GS; ++i) {                     // hmc.py:150
-                const int t = h * GS + i;
-                const double d = UNIT ? q[i] : q[i] - a.x0;
-                lane_sum_add<false>(sqL, d * d, t, T);
-                lane_sum_add<false>(spL, p[i] * p[i], t, T);
-                if (work && (8 * t + j < L.len)) qo[L.off + 8 * t + j] = q[i];
-            }
-            asm volatile("" : "+v"(sq0.r), "+v"(sp0.r), "+v"(sqL.r), "+v"(spL.r));
-            __builtin_amdgcn_sched_barrier(0);
         }
-        const double r0 = leaf_finish(sq0.r, sq0.tail, T, rem, lane);
-        const double r1 = leaf_finish(sp0.r, sp0.tail, T, rem, lane);
-        const double r2 = leaf_finish(sqL.r, sqL.tail, T, rem, lane);
-        const double r3 = leaf_finish(spL.r, spL.tail, T, rem, lane);
-        if (act && j == 0) {
-            dep[path] = L.depth;
-            if (work) {
+#pragma unroll
+        for (int i = 0; i < GS; ++i) {                         // hmc.py:122-123
+            q[i] = drift<FMA>(q[i], p[i], dt);
+            p[i] = kick<FMA>(p[i], hdt, gauss_grad<UNIT>(q[i], a.k, a.x0));
+        }
+#pragma unroll
+        for (int i = 0; i < GS; ++i) {                         // hmc.py:150
+            const int t = h * GS + i;
+            const double d = UNIT ? q[i] : q[i] - a.x0;
+            lane_sum_add<REG>(sqL, d * d, t, T);
+            lane_sum_add<REG>(spL, p[i] * p[i], t, T);
+            if (REG || (it.work && (8 * t + j < it.L.len))) qo[it.L.off + 8 * t + j] = q[i];
+        }
+        asm volatile("" : "+v"(sq0.r), "+v"(sp0.r), "+v"(sqL.r), "+v"(spL.r));
+    };
+
+    double qa[GS], pa[GS], qb[GS], pb[GS];
+    Item cur = item_of(0);
+    load_half(qa, pa, cur, 0);
+    for (int base = 0; base < npaths; base += 32) {
+        const int T = (cur.L.len >= 8) ? (cur.L.len >> 3) : 0;
+        const int rem = (cur.L.len >= 8) ? (cur.L.len & 7) : cur.L.len;
+        sq0 = {0.0, 0.0}; sp0 = {0.0, 0.0}; sqL = {0.0, 0.0}; spL = {0.0, 0.0};
+        load_half(qb, pb, cur, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        run_half(qa, pa, cur, 0, T);
+        __builtin_amdgcn_sched_barrier(0);
+        // next leaf's first half (unconditional: past the end it re-reads this
+        // leaf and is ignored -- a load under a branch would be waited for at once)
+        const Item nxt = item_of(base + 32 < npaths ? base + 32 : base);
+        load_half(qa, pa, nxt, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        run_half(qb, pb, cur, 1, T);
+        __builtin_amdgcn_sched_barrier(0);
+        const double r0 = leaf_finish<REG>(sq0.r, sq0.tail, T, rem, lane);
+        const double r1 = leaf_finish<REG>(sp0.r, sp0.tail, T, rem, lane);
+        const double r2 = leaf_finish<REG>(sqL.r, sqL.tail, T, rem, lane);
+        const double r3 = leaf_finish<REG>(spL.r, spL.tail, T, rem, lane);
+        if (cur.act && j == 0) {
+            const int path = base + group;
+            dep[path] = cur.L.depth;
+            if (cur.work) {
                 S[0][path] = r0; S[1][path] = r1; S[2][path] = r2; S[3][path] = r3;
             }
         }
+        cur = nxt;
     }
     __syncthreads();
     // redundant paths take the sums of the leaf they coincide with
-    if ((int)threadIdx.x < npaths) {
+    if (!REG && (int)threadIdx.x < npaths) {
         const int pth = threadIdx.x;
         const int canon = pth & ~((1 << (H - dep[pth])) - 1);
         if (canon != pth) {
@@ -224,21 +262,27 @@ __global__ void __launch_bounds__(256) hmc_gauss_big_finish_kernel(const BigFini
     }
 }
 
-// q_out[c, :] = q0[c, :] for rejected chains (hmc.py:164); VEC doubles per access
+// q_out[c, :] = q0[c, :] for rejected chains (hmc.py:164).  A workgroup serves
+// one 4096-element segment of one chain: accepted chains cost one flag read per
+// workgroup and no traffic.  VEC doubles per access.
+constexpr int RESTORE_SEG = 4096;
+
 template <int VEC>
 __global__ void __launch_bounds__(256)
-restore_rejected_kernel(double *q_out, const double *q0, const uint8_t *accepted, int64_t n,
-                        int64_t D)
+restore_rejected_kernel(double *q_out, const double *q0, const uint8_t *accepted, int64_t D,
+                        int32_t segs)
 {
-    const bool small = n <= 0xffffffffLL;
-    for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * VEC; i < n;
-         i += (int64_t)gridDim.x * 256 * VEC) {
-        const int64_t c = small ? (int64_t)((uint32_t)i / (uint32_t)D) : i / D;
-        if (accepted[c]) continue;
+    const int64_t c = blockIdx.x / segs;
+    if (accepted[c]) return;
+    const int64_t lo = (int64_t)(blockIdx.x % segs) * RESTORE_SEG;
+    const int64_t hi = (lo + RESTORE_SEG < D) ? lo + RESTORE_SEG : D;
+    const double *src = q0 + c * D;
+    double *dst = q_out + c * D;
+    for (int64_t i = lo + (int64_t)threadIdx.x * VEC; i < hi; i += 256 * VEC) {
         if (VEC == 2) {
-            *reinterpret_cast<double2 *>(q_out + i) = *reinterpret_cast<const double2 *>(q0 + i);
+            *reinterpret_cast<double2 *>(dst + i) = *reinterpret_cast<const double2 *>(src + i);
         } else {
-            q_out[i] = q0[i];
+            dst[i] = src[i];
         }
     }
 }
@@ -282,26 +326,41 @@ extern "C" int32_t binf_hmc_sample_gauss_big_f64(
     a.q0 = q0; a.p0 = p0; a.q_out = q_out; a.ws = (double *)workspace; a.dt_chain = dt_chain;
     a.timestep = timestep; a.k = k; a.x0 = x0; a.C = C; a.D = D; a.nchunks = big_chunks(D);
     a.nsteps = nsteps;
-    a.H = pairwise_tree_height(D < NPY_BUFSIZE ? D : NPY_BUFSIZE);
-    if (D > NPY_BUFSIZE && D % NPY_BUFSIZE != 0) {
-        const int32_t h_last = pairwise_tree_height(D % NPY_BUFSIZE);
-        if (h_last > a.H) a.H = h_last;
-    }
-    if (a.H > 7) return fail(BINF_E_UNSUPPORTED, "%s: pairwise tree height %d", what, a.H);
-    const int64_t blocks = C * a.nchunks;
-    if (blocks > 0x7fffffffLL) return fail(BINF_E_UNSUPPORTED, "%s: too many (chain, chunk) pairs", what);
+    const int32_t nfull = (int32_t)(D / NPY_BUFSIZE);
+    const int32_t ntail = (D % NPY_BUFSIZE) ? 1 : 0;
+    if (C * (int64_t)(nfull > 0 ? nfull : 1) > 0x7fffffffLL)
+        return fail(BINF_E_UNSUPPORTED, "%s: too many (chain, chunk) pairs", what);
     hipStream_t st = (hipStream_t)stream;
     const bool unit = (k == 1.0 && x0 == 0.0), fma = (mode == BINF_MODE_FMA);
-    const dim3 grid((unsigned)blocks);
-    if (unit) {
-        if (fma) hmc_gauss_big_traj_kernel<true, true><<<grid, 256, 0, st>>>(a);
-        else     hmc_gauss_big_traj_kernel<true, false><<<grid, 256, 0, st>>>(a);
-    } else {
-        if (fma) hmc_gauss_big_traj_kernel<false, true><<<grid, 256, 0, st>>>(a);
-        else     hmc_gauss_big_traj_kernel<false, false><<<grid, 256, 0, st>>>(a);
+    hipError_t e;
+    if (nfull > 0) {
+        a.H = 6; a.chunk0 = 0; a.chunks_here = nfull;
+        const dim3 grid((unsigned)(C * nfull));
+        if (unit) {
+            if (fma) hmc_gauss_big_traj_kernel<true, true, true><<<grid, 256, 0, st>>>(a);
+            else     hmc_gauss_big_traj_kernel<true, false, true><<<grid, 256, 0, st>>>(a);
+        } else {
+            if (fma) hmc_gauss_big_traj_kernel<false, true, true><<<grid, 256, 0, st>>>(a);
+            else     hmc_gauss_big_traj_kernel<false, false, true><<<grid, 256, 0, st>>>(a);
+        }
+        e = hipGetLastError();
+        if (e != hipSuccess) return hip_fail(e, "hmc_gauss_big_traj_kernel launch");
     }
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return hip_fail(e, "hmc_gauss_big_traj_kernel launch");
+    if (ntail) {
+        a.H = pairwise_tree_height(D % NPY_BUFSIZE);
+        if (a.H > 7) return fail(BINF_E_UNSUPPORTED, "%s: pairwise tree height %d", what, a.H);
+        a.chunk0 = nfull; a.chunks_here = 1;
+        const dim3 grid((unsigned)C);
+        if (unit) {
+            if (fma) hmc_gauss_big_traj_kernel<true, true, false><<<grid, 256, 0, st>>>(a);
+            else     hmc_gauss_big_traj_kernel<true, false, false><<<grid, 256, 0, st>>>(a);
+        } else {
+            if (fma) hmc_gauss_big_traj_kernel<false, true, false><<<grid, 256, 0, st>>>(a);
+            else     hmc_gauss_big_traj_kernel<false, false, false><<<grid, 256, 0, st>>>(a);
+        }
+        e = hipGetLastError();
+        if (e != hipSuccess) return hip_fail(e, "hmc_gauss_big_traj_kernel (tail chunk) launch");
+    }
     BigFinishArgs f;
     f.ws = (const double *)workspace; f.u = u; f.accepted = accepted; f.n_accepted = n_accepted;
     f.e_before = e_before; f.e_after = e_after; f.dt_chain = dt_chain; f.k = k;
@@ -310,12 +369,12 @@ extern "C" int32_t binf_hmc_sample_gauss_big_f64(
     hmc_gauss_big_finish_kernel<<<dim3((unsigned)((C + 255) / 256)), 256, 0, st>>>(f);
     e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "hmc_gauss_big_finish_kernel launch");
-    const int64_t n = C * D;
     const bool vec2 = (D % 2 == 0) && ((((uintptr_t)q_out | (uintptr_t)q0) & 15) == 0);
-    int64_t rb = (n + (vec2 ? 511 : 255)) / (vec2 ? 512 : 256);
-    if (rb > (1 << 20)) rb = 1 << 20;
-    if (vec2) restore_rejected_kernel<2><<<dim3((unsigned)rb), 256, 0, st>>>(q_out, q0, accepted, n, D);
-    else      restore_rejected_kernel<1><<<dim3((unsigned)rb), 256, 0, st>>>(q_out, q0, accepted, n, D);
+    const int32_t segs = (int32_t)((D + RESTORE_SEG - 1) / RESTORE_SEG);
+    if (C * segs > 0x7fffffffLL) return fail(BINF_E_UNSUPPORTED, "%s: too many segments", what);
+    const dim3 rgrid((unsigned)(C * segs));
+    if (vec2) restore_rejected_kernel<2><<<rgrid, 256, 0, st>>>(q_out, q0, accepted, D, segs);
+    else      restore_rejected_kernel<1><<<rgrid, 256, 0, st>>>(q_out, q0, accepted, D, segs);
     e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "restore_rejected_kernel launch");
     return 0;

@@ -176,3 +176,31 @@ def test_rng_kernels_stay_inside_their_buffers(device, kind, n):
         ref = torch.empty(n, dtype=torch.float64, device=device)
         _native.rng_fill(kind, ref, 123, 4 * n, shape=10.0)
         assert torch.equal(out, ref)
+
+
+@pytest.mark.parametrize('D,C', [(8193, 3), (7689, 2), (20000, 3), (16384 + 5, 2), (24576, 2)])
+def test_long_chain_kernels_stay_inside_their_buffers(device, D, C):
+    """binf_hmc_sample_gauss_big_f64: full chunks, a ragged last chunk, a last
+    chunk shorter than one accumulator row; guarded windows vs plain tensors."""
+    rs = np.random.RandomState(D)
+    q0, p0, u = rs.standard_normal((C, D)), rs.standard_normal((C, D)), rs.uniform(size=C)
+    u[0] = 0.999999
+    p0[0] *= 4.0                                    # a rejected chain: restored from q0
+    outs = []
+    for make in (Guarded(device), None):
+        t = make if make is not None else (lambda a, dtype=torch.float64: plain(a, device, dtype))
+        tq, tp, tu = t(q0), t(p0), t(u)
+        qo = t(np.zeros((C, D)))
+        acc = t(np.zeros(C, dtype=np.uint8), torch.uint8)
+        nacc = t(np.zeros(C, dtype=np.int64), torch.int64)
+        eb, ea = t(np.zeros(C)), t(np.zeros(C))
+        dtc = t(np.full(C, 0.05))
+        _native.hmc_sample_gauss_big(tq, tp, tu, qo, acc, nacc, eb, ea, 0.05, dtc, 3, 2.5, 0.3,
+                                     True, 1.05, 0.95, _native.MODE_EXACT)
+        if make is not None:
+            make.check()
+        outs.append([x.cpu().numpy().copy() for x in (qo, acc, nacc, eb, ea, dtc)])
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)
+    assert not np.isnan(outs[0][0]).any()
+    assert outs[0][1][0] == 0 and np.array_equal(outs[0][0][0], q0[0])
