@@ -10,8 +10,10 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from binf_amd import _native
 from binf_amd.pdf import IsotropicGaussian
 from binf_amd.samplers.hmc import HMCSampler
+from binf_amd.samplers.rng import DeviceRNG
 from oracle import c_oracle
 
 dev = torch.device('cuda:0')
@@ -64,6 +66,33 @@ for case in range(n_cases):
     ok &= np.array_equal(s.state.cpu().numpy(), q)
     if limit:
         ok &= np.array_equal(np.broadcast_to(s.timestep.cpu().numpy() if isinstance(s.timestep, torch.Tensor) else s.timestep, (C,)), dtc)
+    # the per-step tier (flat 16-byte kernels; odd D and per-chain dt take the other
+    # variants) on the same case, first transition
+    if rs.rand() < 0.3:
+        pdf = IsotropicGaussian(k, x0)
+        pdf.native_hmc_spec = lambda name: None
+        g = HMCSampler(pdf, torch.from_numpy(q0).to(dev), dt, L, timestep_adaption_limit=limit,
+                       variable_name='x')
+        xg = g.sample(p0=torch.from_numpy(p0[0]).to(dev), u=torch.from_numpy(u[0]).to(dev))
+        w = c_oracle.hmc_sample_gauss(q0, p0[0], u[0], np.full(C, dt), L, k, x0, adapt=1 < limit,
+                                      nthreads=8)
+        ok &= np.array_equal(xg.cpu().numpy(), w['q_out'])
+        ok &= np.array_equal(g.last_e_after.cpu().numpy(), w['e_after'])
+        ok &= np.array_equal(g.last_move_accepted.cpu().numpy(), w['accepted'].astype(bool))
+    # draws generated in the kernel == sampling from the dump of the same stream
+    if _native.fused_rng_covers(D) and rs.rand() < 0.4:
+        seed, mode = int(rs.randint(1 << 30)), ('exact' if rs.rand() < 0.7 else 'fma')
+        kw = dict(timestep_adaption_limit=limit, variable_name='x', mode=mode, record_energies=True)
+        a = HMCSampler(IsotropicGaussian(k, x0), torch.from_numpy(q0).to(dev), dt, L,
+                       rng=DeviceRNG(seed, dev), **kw)
+        ra = a.sample_n(n, thin=thin)
+        pd, ud = _native.hmc_gauss_rng_draws(n, C, D, seed, 0, dev)
+        b = HMCSampler(IsotropicGaussian(k, x0), torch.from_numpy(q0).to(dev), dt, L, **kw)
+        rb = b.sample_n(n, thin=thin, p0=pd, u=ud)
+        ok &= (ra is None and rb is None) or torch.equal(ra, rb)
+        ok &= torch.equal(a.state, b.state) and torch.equal(a.accepted_history, b.accepted_history)
+        ok &= torch.equal(a.last_e_after, b.last_e_after)
+        ok &= bool(torch.isfinite(pd).all()) and float(pd.abs().max()) < 9.0
     if not ok:
         bad += 1
         print('MISMATCH', dict(D=D, C=C, L=L, n=n, thin=thin, limit=limit, k=k, x0=x0, dt=dt), flush=True)
