@@ -18,18 +18,23 @@ enum { GAUSS_RNG_HBM = 0, GAUSS_RNG_FUSED = 1, GAUSS_RNG_DUMP = 2 };
 // wave (several chains per wave when G < 64).  LW > 0 (D > 1024): a chain spans
 // 2 / 4 / 8 whole waves of the workgroup; the leaf-tree levels above a wave are
 // joined through LDS (chain_sum_finish).
+// Waves per workgroup: 4 (8 for chains of 8 waves).  With the generator in the
+// kernel: 8, so that two workgroups per CU share the 160 KiB of LDS as 2 x (64 KiB
+// stash + the 8 KiB layer table) -- still 16 waves per CU, the whole C2 batch resident.
+constexpr int gauss_wpb(int LW, int RNG) { return (LW == 3 || RNG != GAUSS_RNG_HBM) ? 8 : 4; }
+
 template <int TMAX, bool REGULAR, bool UNIT, bool FMA, int LW, int RNG = GAUSS_RNG_HBM>
-__global__ void __launch_bounds__(LW == 3 ? 512 : 256)
+__global__ void __launch_bounds__(64 * gauss_wpb(LW, RNG))
 hmc_gauss_persist_kernel(const GaussNArgs a)
 {
     static_assert(RNG == GAUSS_RNG_HBM || LW == 0, "the fused generator covers one-wave chains");
-    constexpr int WPB = (LW == 3) ? 8 : 4;           // waves per workgroup
+    constexpr int WPB = gauss_wpb(LW, RNG);          // waves per workgroup
     constexpr int WPC = 1 << LW;                     // waves per chain
     __shared__ double xch[WPB];
     constexpr int GS = (TMAX % 8 == 0) ? 8 : ((TMAX % 4 == 0) ? 4 : TMAX);   // measured: 8 beats 4 and 16
     constexpr int NG = TMAX / GS;
     __shared__ double stash[RNG == GAUSS_RNG_DUMP ? 1 : WPB][RNG == GAUSS_RNG_DUMP ? 1 : TMAX][64];
-    __shared__ double zx[RNG == GAUSS_RNG_HBM ? 1 : ZIG512_C + 1];
+    __shared__ double zx[RNG == GAUSS_RNG_HBM ? 1 : XZIG_C + 1];
     if (RNG != GAUSS_RNG_HBM) {
         xzig_load_table(zx, threadIdx.x, WPB * 64);
         __syncthreads();

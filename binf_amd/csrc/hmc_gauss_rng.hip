@@ -3,7 +3,7 @@
 // q.shape), the trajectory, np.random.uniform() (binf/samplers/hmc.py:146-151)
 // -- n transitions per launch, with no momentum buffer in HBM at all.  Same
 // kernel template as hmc_gauss.hip (hmc_gauss_kernel.hpp, RNG = 1); the draws
-// come from per-lane xoshiro128++ streams + a 512-layer ziggurat (xoshiro.hpp).
+// come from per-lane xoshiro128++ streams + a 1024-layer ziggurat (xoshiro.hpp).
 //
 // binf_hmc_gauss_rng_draws_f64 runs the same template with RNG = 2: it writes
 // the draws the fused kernel WOULD consume for (seed, offset, C, D, n) and
@@ -20,13 +20,13 @@ template <int TMAX, bool REGULAR, int RNG>
 static hipError_t launch_rng_tr(const GaussNArgs &a, bool unit, bool fma, dim3 grid, hipStream_t st)
 {
     if (RNG == GAUSS_RNG_DUMP) {
-        hmc_gauss_persist_kernel<TMAX, REGULAR, true, false, 0, RNG><<<grid, 256, 0, st>>>(a);
+        hmc_gauss_persist_kernel<TMAX, REGULAR, true, false, 0, RNG><<<grid, 512, 0, st>>>(a);
     } else if (unit) {
-        if (fma) hmc_gauss_persist_kernel<TMAX, REGULAR, true, true, 0, RNG><<<grid, 256, 0, st>>>(a);
-        else     hmc_gauss_persist_kernel<TMAX, REGULAR, true, false, 0, RNG><<<grid, 256, 0, st>>>(a);
+        if (fma) hmc_gauss_persist_kernel<TMAX, REGULAR, true, true, 0, RNG><<<grid, 512, 0, st>>>(a);
+        else     hmc_gauss_persist_kernel<TMAX, REGULAR, true, false, 0, RNG><<<grid, 512, 0, st>>>(a);
     } else {
-        if (fma) hmc_gauss_persist_kernel<TMAX, REGULAR, false, true, 0, RNG><<<grid, 256, 0, st>>>(a);
-        else     hmc_gauss_persist_kernel<TMAX, REGULAR, false, false, 0, RNG><<<grid, 256, 0, st>>>(a);
+        if (fma) hmc_gauss_persist_kernel<TMAX, REGULAR, false, true, 0, RNG><<<grid, 512, 0, st>>>(a);
+        else     hmc_gauss_persist_kernel<TMAX, REGULAR, false, false, 0, RNG><<<grid, 512, 0, st>>>(a);
     }
     return hipGetLastError();
 }
@@ -35,7 +35,7 @@ template <int RNG>
 static hipError_t launch_rng(const GaussNArgs &a, const GaussPlan &p, bool unit, bool fma,
                              hipStream_t st)
 {
-    const dim3 grid((unsigned)p.blocks);
+    const dim3 grid((unsigned)((p.blocks + 1) / 2));   // 8 waves per workgroup (gauss_wpb)
     const int t = p.tneed;
 #define BINF_RNG_CASE(T)                                                            \
     return (p.regular && t == T) ? launch_rng_tr<T, true, RNG>(a, unit, fma, grid, st) \

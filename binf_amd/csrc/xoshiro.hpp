@@ -1,8 +1,8 @@
 // The random draws of HMCSampler.sample() -- np.random.normal(size=q.shape) and
 // np.random.uniform() (binf/samplers/hmc.py:146,151) -- generated INSIDE the
 // sampling kernel: one xoshiro128++ stream (Blackman & Vigna 2018) per lane,
-// normals by a 512-layer ziggurat (Marsaglia & Tsang 2000, Doornik's ZIGNOR
-// acceptance tests) whose layer table lives in 4 KiB of LDS.
+// normals by a 1024-layer ziggurat (Marsaglia & Tsang 2000, Doornik's ZIGNOR
+// acceptance tests) whose layer table lives in 8 KiB of LDS.
 //
 // Why not the Philox generator of rng.hip: Philox4x32-10 costs ~100 integer
 // instructions per two normals, four of them quarter-rate 32-bit multiplies per
@@ -18,6 +18,12 @@
 #include "zig_tables.hpp"
 
 namespace binf {
+
+// the ziggurat of the fused generator: 1024 layers, table = ZIG_X (8 KiB of LDS)
+constexpr int XZIG_C = ZIG_C;
+constexpr int XZIG_BITS = ZIG_BITS;
+constexpr double XZIG_TAIL_R = ZIG_TAIL_R;
+#define XZIG_TABLE ZIG_X
 
 struct Xo128 {
     uint32_t s0, s1, s2, s3;
@@ -58,14 +64,14 @@ __device__ inline double xo_uniform53(Xo128 &g)
     return ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) * (1.0 / 9007199254740992.0);
 }
 
-// One ziggurat candidate from two outputs: layer = top 9 bits of the first,
+// One ziggurat candidate from two outputs: layer = top 10 bits of the first,
 // u in [-1, 1) from the other 52 bits (built as a double in [1, 2), then
 // 2 d - 3 exactly).  x = u * X[layer]; the candidate is final iff |x| < X[layer+1]
 // (inside the part of the layer that lies wholly under the density).
 __device__ inline double xzig_candidate(Xo128 &g, const double *zx, int &layer, bool &ok)
 {
     const uint32_t hi = xo_next(g), lo = xo_next(g);
-    layer = (int)(hi >> (32 - ZIG512_BITS));
+    layer = (int)(hi >> (32 - XZIG_BITS));
     const double d = __hiloint2double((int)(0x3ff00000u | (hi & 0xfffffu)), (int)lo);
     const double u = __builtin_fma(2.0, d, -3.0);
     const double x = u * zx[layer];
@@ -77,11 +83,11 @@ __device__ inline double xzig_tail(Xo128 &g, bool neg)
 {
     double x = 0.0;
     for (int t = 0; t < 64; ++t) {
-        x = log(1.0 - xo_uniform53(g)) / ZIG512_TAIL_R;         // <= 0
+        x = log(1.0 - xo_uniform53(g)) / XZIG_TAIL_R;         // <= 0
         const double y = log(1.0 - xo_uniform53(g));
         if (-2.0 * y >= x * x) break;
     }
-    return neg ? x - ZIG512_TAIL_R : ZIG512_TAIL_R - x;
+    return neg ? x - XZIG_TAIL_R : XZIG_TAIL_R - x;
 }
 
 // Finish a candidate that failed the fast test: wedge test of its layer (or the
@@ -109,7 +115,7 @@ __device__ inline double xzig_resolve(double x, int layer, Xo128 &g, const doubl
 template <int N>
 __device__ inline void xzig_normals(double (&out)[N], unsigned want, Xo128 &g, const double *zx)
 {
-    static_assert(N <= 9, "9-bit layers are packed three to a register");
+    static_assert(N <= 9 && XZIG_BITS <= 10, "10-bit layers are packed three to a register");
     unsigned fail = 0;
     uint32_t lay[3] = {0u, 0u, 0u};
 #pragma unroll
@@ -120,7 +126,7 @@ __device__ inline void xzig_normals(double (&out)[N], unsigned want, Xo128 &g, c
             bool ok;
             out[i] = xzig_candidate(g, zx, layer, ok);
             if (!ok) fail |= 1u << i;
-            lay[i / 3] |= (uint32_t)layer << (9 * (i % 3));
+            lay[i / 3] |= (uint32_t)layer << (10 * (i % 3));
         }
     }
     while (fail) {
@@ -131,9 +137,9 @@ __device__ inline void xzig_normals(double (&out)[N], unsigned want, Xo128 &g, c
 #pragma unroll
         for (int e = 0; e < N; ++e) {
             x = (e == i) ? out[e] : x;
-            word = (e == i) ? (lay[e / 3] >> (9 * (e % 3))) : word;
+            word = (e == i) ? (lay[e / 3] >> (10 * (e % 3))) : word;
         }
-        const double v = xzig_resolve(x, (int)(word & 0x1ffu), g, zx);
+        const double v = xzig_resolve(x, (int)(word & 0x3ffu), g, zx);
 #pragma unroll
         for (int e = 0; e < N; ++e) out[e] = (e == i) ? v : out[e];
     }
@@ -142,7 +148,7 @@ __device__ inline void xzig_normals(double (&out)[N], unsigned want, Xo128 &g, c
 // LDS copy of the layer table (all threads of the block; a barrier follows)
 __device__ inline void xzig_load_table(double *zx, int tid, int nthreads)
 {
-    for (int k = tid; k <= ZIG512_C; k += nthreads) zx[k] = ZIG512_X[k];
+    for (int k = tid; k <= XZIG_C; k += nthreads) zx[k] = XZIG_TABLE[k];
 }
 
 }  // namespace binf

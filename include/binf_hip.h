@@ -148,7 +148,7 @@ int32_t binf_hmc_sample_gauss_big_f64(const double *q0, const double *p0,
  * HMCSampler.sample() as the reference defines it, np.random.normal(size=
  * q.shape) ... np.random.uniform() (binf/samplers/hmc.py:146,151), with no
  * momentum buffer in HBM.  Per-lane xoshiro128++ streams seeded from the Philox
- * block (lane's element set, offset) under `seed`, normals by a 512-layer
+ * block (lane's element set, offset) under `seed`, normals by a 1024-layer
  * ziggurat; deterministic in (seed, offset, C, D), independent of the launch
  * geometry, NOT numpy's MT19937 stream (parity runs inject host draws through
  * binf_hmc_sample_n_gauss_f64).  A caller advances `offset` by one per launch.

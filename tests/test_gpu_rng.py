@@ -125,13 +125,13 @@ def test_ziggurat_normals(device):
 # the generator fused into the sampling kernel (csrc/xoshiro.hpp,
 # csrc/hmc_gauss_rng.hip): hmc.py:146,151 inside the launch
 # ---------------------------------------------------------------------------
-def _zig512_table():
+def _zig_table():
     import os
     import re
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
                         'binf_amd', 'csrc', 'zig_tables.hpp')
     text = open(path).read()
-    body = re.search(r'ZIG512_X\[513\] = \{(.*?)\};', text, re.S).group(1)
+    body = re.search(r'ZIG_X\[1025\] = \{(.*?)\};', text, re.S).group(1)
     return np.array([float.fromhex(t) for t in body.replace(',', ' ').split()])
 
 
@@ -170,9 +170,9 @@ class _Xo128(object):
 def test_fused_generator_bits_match_a_host_restatement(device):
     """D = 8: every lane owns ONE element, so its stream is: one ziggurat
     candidate (two outputs), its resolution if it fails, then the uniform.  The
-    host restatement covers the fast path (98 % of the lanes) bit for bit."""
-    zx = _zig512_table()
-    assert zx.shape == (513,) and zx[512] == 0.0 and zx[1] == 3.852046150368391
+    host restatement covers the fast path (99.6 % of the lanes) bit for bit."""
+    zx = _zig_table()
+    assert zx.shape == (1025,) and zx[1024] == 0.0 and zx[1] == 4.038849846109505
     C, D, seed, offset = 300, 8, 2 ** 40 + 12345, 7
     p0, u = _native.hmc_gauss_rng_draws(1, C, D, seed, offset, device)
     p0, u = p0.cpu().numpy()[0], u.cpu().numpy()[0]
@@ -181,7 +181,7 @@ def test_fused_generator_bits_match_a_host_restatement(device):
         for j in range(D):
             g = _Xo128(c * 8 + j, seed, offset)           # stream = chain * 8 lanes + accumulator
             hi, lo = g.next(), g.next()
-            layer = hi >> 23
+            layer = hi >> 22
             bits = ((0x3ff00000 | (hi & 0xfffff)) << 32) | lo
             d = np.frombuffer(np.uint64(bits).tobytes(), dtype=np.float64)[0]
             x = (2.0 * d - 3.0) * zx[layer]
@@ -190,7 +190,7 @@ def test_fused_generator_bits_match_a_host_restatement(device):
                 checked += 1
                 if j == 0:
                     assert u[c] == g.uniform53(), c
-    assert checked > 0.97 * C * D
+    assert checked > 0.99 * C * D
 
 
 FUSED_SHAPES = [(64, 1024, 20, 1.0, 0.0, 'exact'), (70, 768, 5, 2.5, 0.3, 'exact'),
@@ -257,7 +257,7 @@ def test_fused_generator_stream_properties(device):
     assert abs((flat ** 6).mean() - 15.0) < 0.3
     sub = flat[::8][:1_000_000]
     assert stats.kstest(sub, 'norm').statistic < 1.63 / np.sqrt(sub.size)
-    for t in (1.0, 2.0, 3.0, 3.852046150368391, 4.5):
+    for t in (1.0, 2.0, 3.0, 4.038849846109505, 4.5):
         want = 2 * stats.norm.sf(t)
         got = (np.abs(flat) > t).mean()
         assert abs(got - want) < 5 * np.sqrt(want / N) + 1e-7, (t, got, want)
