@@ -212,7 +212,7 @@ def pmc_traffic_live(args):
                    '-d', out, '--'] + child
             try:
                 r = subprocess.run(cmd, cwd='/tmp', env=env, stdout=subprocess.PIPE,
-                                   stderr=subprocess.PIPE, timeout=300)
+                                   stderr=subprocess.PIPE, timeout=150)
             except subprocess.TimeoutExpired:
                 return None, 'rocprofv3 --pmc %s child timed out' % counter
             if r.returncode != 0:

@@ -91,8 +91,9 @@ def c5_distance(dev, C=256, n=256, L=20):
     return {'workload': 'C5 share: %d beads x 3, %d chains, L=%d' % (n, C, L),
             'force_kernel_ms': t_g * 1e3,
             'pair_interactions_per_s': pairs / t_g,
-            # 36 VALU instructions per pair (PMC), ~20 of them FP64
-            'valu_frac_fp64': 20.0 * pairs / t_g / VALU_PEAK_LANEOPS,
+            # 36 VALU instructions per ordered pair and lane (PMC) against
+            # the issue rate of the chip (one VALU instruction per lane and clock)
+            'valu_frac': 36.0 * pairs / t_g / VALU_PEAK_LANEOPS,
             'hmc_sample_ms': t_h * 1e3,
             'chain_leapfrog_steps_per_s': C * L / t_h,
             'acceptance': float(s.acceptance_rate.mean())}
@@ -117,10 +118,40 @@ def c2_device_rng(dev, C=4096, D=1024, L=20, F=64):
     return out
 
 
+def c2_strong_scaling_shares(dev, D=1024, L=20, F=64):
+    """SURVEY 8(e), secondary: 4096 chains in total over N GPUs leave 4096 / N per
+    GPU -- measured here on one GPU (chains spread over 2 / 4 waves below 2048,
+    csrc/hmc_gauss_split.hip); draws pre-generated in HBM as in the headline."""
+    from binf_amd.pdf import IsotropicGaussian
+    from binf_amd.samplers.hmc import HMCSampler
+    out = {'workload': 'C2 shape, 4096 chains / N per GPU, sample_n(%d), every state recorded' % F}
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(5)
+    for n_gpus in (2, 4, 8):
+        C = 4096 // n_gpus
+        s = HMCSampler(IsotropicGaussian(), torch.randn((C, D), dtype=torch.float64, device=dev,
+                                                         generator=gen), 0.05, L, variable_name='x')
+        p0 = [torch.randn((F, C, D), dtype=torch.float64, device=dev, generator=gen) for _ in range(2)]
+        u = [torch.rand((F, C), dtype=torch.float64, device=dev, generator=gen) for _ in range(2)]
+        rec = torch.empty((F, C, D), dtype=torch.float64, device=dev)
+        i = [0]
+
+        def step():
+            i[0] += 1
+            s.sample_n(F, p0=p0[i[0] % 2], u=u[i[0] % 2], out=rec)
+        t = _timed(step, 6, warm=2) / F
+        out['N=%d' % n_gpus] = {'chains_per_gpu': C, 'us_per_transition': t * 1e6,
+                                'chain_steps_per_s_per_gpu': C * L / t}
+        del s, p0, u, rec
+        torch.cuda.empty_cache()
+    return out
+
+
 def run_all(dev):
     res = {}
     for name, fn in (('C3', c3_polynomial), ('C5', c5_distance),
-                     ('C2_device_rng', c2_device_rng)):
+                     ('C2_device_rng', c2_device_rng),
+                     ('C2_strong_scaling_shares', c2_strong_scaling_shares)):
         try:
             res[name] = fn(dev)
         except Exception as e:                    # one failing sub-result does not hide the others
