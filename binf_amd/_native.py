@@ -606,8 +606,8 @@ def hmc_gauss_rng_draws(n, C, D, seed, offset, device):
 
 
 def fused_rng_covers(D):
-    """Shapes binf_hmc_sample_n_gauss_rng_f64 accepts (one-wave chains)."""
-    return 1 <= D <= 1024 and pairwise_tree_height(D) <= 3
+    """Shapes binf_hmc_sample_n_gauss_rng_f64 accepts (= the persistent kernel's)."""
+    return 1 <= D <= 8192 and pairwise_tree_height(D) <= 6
 
 
 @_launcher

@@ -27,10 +27,10 @@ template <int TMAX, bool REGULAR, bool UNIT, bool FMA, int LW, int RNG = GAUSS_R
 __global__ void __launch_bounds__(64 * gauss_wpb(LW, RNG))
 hmc_gauss_persist_kernel(const GaussNArgs a)
 {
-    static_assert(RNG == GAUSS_RNG_HBM || LW == 0, "the fused generator covers one-wave chains");
     constexpr int WPB = gauss_wpb(LW, RNG);          // waves per workgroup
     constexpr int WPC = 1 << LW;                     // waves per chain
     __shared__ double xch[WPB];
+    __shared__ double ubc[WPB];                      // the chain's acceptance draw, wave to wave
     constexpr int GS = (TMAX % 8 == 0) ? 8 : ((TMAX % 4 == 0) ? 4 : TMAX);   // measured: 8 beats 4 and 16
     constexpr int NG = TMAX / GS;
     __shared__ double stash[RNG == GAUSS_RNG_DUMP ? 1 : WPB][RNG == GAUSS_RNG_DUMP ? 1 : TMAX][64];
@@ -237,7 +237,15 @@ hmc_gauss_persist_kernel(const GaussNArgs a)
             // the acceptance draw, np.random.uniform (hmc.py:151): every lane
             // advances its stream, the chain uses the one of its first lane
             const double ud = xo_uniform53(gen);
-            uu = shfl_f64(ud, lane & ~((1 << lg) - 1));
+            if (LW == 0) {
+                uu = shfl_f64(ud, lane & ~((1 << lg) - 1));
+            } else {
+                // the first lane of the chain's first wave draws for all its waves
+                if (wchain == 0 && lane == 0) ubc[wib] = ud;
+                __syncthreads();
+                uu = ubc[wib & ~(WPC - 1)];
+                __syncthreads();
+            }
             if (RNG == GAUSS_RNG_DUMP) {
                 if (cvalid && writer) a.u_dump[(int64_t)s * a.C + chain] = uu;
                 continue;

@@ -10,31 +10,46 @@
 // integrates nothing, so that
 //     sample_n_rng(seed, offset)  ==  sample_n(p0 = draws, u = draws)   bit for bit
 // (tests/test_gpu_rng.py); the statistical quality of the stream is tested on the
-// dump.  One-wave chains only (tree height <= 3: any D <= 920 and the multiples of
-// 8 up to 1024); longer chains use the stand-alone generator kernels (rng.hip).
+// dump.  Same shapes as the persistent kernel (D <= 8192, tree height <= 6; chains
+// of 2 / 4 / 8 waves pass the acceptance draw from wave to wave through LDS);
+// longer chains use the stand-alone generator kernels (rng.hip).
 #include "hmc_gauss_kernel.hpp"
 
 namespace binf {
 
-template <int TMAX, bool REGULAR, int RNG>
+template <int TMAX, bool REGULAR, int RNG, int LW = 0>
 static hipError_t launch_rng_tr(const GaussNArgs &a, bool unit, bool fma, dim3 grid, hipStream_t st)
 {
     if (RNG == GAUSS_RNG_DUMP) {
-        hmc_gauss_persist_kernel<TMAX, REGULAR, true, false, 0, RNG><<<grid, 512, 0, st>>>(a);
+        hmc_gauss_persist_kernel<TMAX, REGULAR, true, false, LW, RNG><<<grid, 512, 0, st>>>(a);
     } else if (unit) {
-        if (fma) hmc_gauss_persist_kernel<TMAX, REGULAR, true, true, 0, RNG><<<grid, 512, 0, st>>>(a);
-        else     hmc_gauss_persist_kernel<TMAX, REGULAR, true, false, 0, RNG><<<grid, 512, 0, st>>>(a);
+        if (fma) hmc_gauss_persist_kernel<TMAX, REGULAR, true, true, LW, RNG><<<grid, 512, 0, st>>>(a);
+        else     hmc_gauss_persist_kernel<TMAX, REGULAR, true, false, LW, RNG><<<grid, 512, 0, st>>>(a);
     } else {
-        if (fma) hmc_gauss_persist_kernel<TMAX, REGULAR, false, true, 0, RNG><<<grid, 512, 0, st>>>(a);
-        else     hmc_gauss_persist_kernel<TMAX, REGULAR, false, false, 0, RNG><<<grid, 512, 0, st>>>(a);
+        if (fma) hmc_gauss_persist_kernel<TMAX, REGULAR, false, true, LW, RNG><<<grid, 512, 0, st>>>(a);
+        else     hmc_gauss_persist_kernel<TMAX, REGULAR, false, false, LW, RNG><<<grid, 512, 0, st>>>(a);
     }
     return hipGetLastError();
+}
+
+// chains of 2 / 4 / 8 waves: leaves of any length <= 128, so TMAX = 16
+template <int RNG, int LW>
+static hipError_t launch_rng_wide(const GaussNArgs &a, const GaussPlan &p, bool unit, bool fma,
+                                  hipStream_t st)
+{
+    const int64_t chains_per_block = 8 >> LW;        // 8 waves per workgroup (gauss_wpb)
+    const dim3 grid((unsigned)((a.C + chains_per_block - 1) / chains_per_block));
+    return (p.regular && p.tneed == 16) ? launch_rng_tr<16, true, RNG, LW>(a, unit, fma, grid, st)
+                                        : launch_rng_tr<16, false, RNG, LW>(a, unit, fma, grid, st);
 }
 
 template <int RNG>
 static hipError_t launch_rng(const GaussNArgs &a, const GaussPlan &p, bool unit, bool fma,
                              hipStream_t st)
 {
+    if (p.LW == 1) return launch_rng_wide<RNG, 1>(a, p, unit, fma, st);
+    if (p.LW == 2) return launch_rng_wide<RNG, 2>(a, p, unit, fma, st);
+    if (p.LW == 3) return launch_rng_wide<RNG, 3>(a, p, unit, fma, st);
     const dim3 grid((unsigned)((p.blocks + 1) / 2));   // 8 waves per workgroup (gauss_wpb)
     const int t = p.tneed;
 #define BINF_RNG_CASE(T)                                                            \
@@ -51,12 +66,12 @@ static hipError_t launch_rng(const GaussNArgs &a, const GaussPlan &p, bool unit,
 
 static int32_t rng_plan(const char *what, int64_t C, int64_t D, GaussPlan &p)
 {
-    if (D > 1024)
-        return fail(BINF_E_UNSUPPORTED, "%s: D=%lld: the fused generator covers one-wave chains (D <= 1024)",
+    if (D > 8192)
+        return fail(BINF_E_UNSUPPORTED, "%s: D=%lld > 8192 not covered by the persistent kernel",
                     what, (long long)D);
     p = gauss_plan(C, D);
-    if (p.LW != 0)
-        return fail(BINF_E_UNSUPPORTED, "%s: pairwise tree height %d > 3 for D=%lld", what, p.H,
+    if (p.H > 6)
+        return fail(BINF_E_UNSUPPORTED, "%s: pairwise tree height %d > 6 for D=%lld", what, p.H,
                     (long long)D);
     if (p.blocks > 0x7fffffffLL) return fail(BINF_E_UNSUPPORTED, "%s: too many chains", what);
     return 0;

@@ -153,9 +153,9 @@ int32_t binf_hmc_sample_gauss_big_f64(const double *q0, const double *p0,
  * geometry, NOT numpy's MT19937 stream (parity runs inject host draws through
  * binf_hmc_sample_n_gauss_f64).  A caller advances `offset` by one per launch.
  * Arguments as binf_hmc_sample_n_gauss_f64 without p0 / u.
- * Supported: one-wave chains (pairwise tree height <= 3: any D <= 920 and the
- * multiples of 8 up to 1024); otherwise BINF_E_UNSUPPORTED (use the stand-alone
- * generators below + binf_hmc_sample_n_gauss_f64).
+ * Supported: the shapes of binf_hmc_sample_n_gauss_f64 (D <= 8192, pairwise
+ * tree height <= 6); otherwise BINF_E_UNSUPPORTED (use the stand-alone
+ * generators below + binf_hmc_sample_gauss_big_f64).
  * ---------------------------------------------------------------------- */
 int32_t binf_hmc_sample_n_gauss_rng_f64(const double *q0, double *q_out,
                                         double *samples, uint8_t *accepted,

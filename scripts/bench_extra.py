@@ -105,16 +105,18 @@ def c2_device_rng(dev, C=4096, D=1024, L=20, F=64):
     from binf_amd.pdf import IsotropicGaussian
     from binf_amd.samplers.hmc import HMCSampler
     from binf_amd.samplers.rng import DeviceRNG
-    out = {'workload': 'C2 shape, sample_n(%d), draws generated on the device in the '
-                       'timed region' % F}
+    out = {'workload': 'C2 shape, sample_n(%d), every state recorded, draws generated inside '
+                       'the sampling kernel (in the timed region)' % F}
+    rec = torch.empty((F, C, D), dtype=torch.float64, device=dev)     # preallocated record buffer
     for mode in ('exact', 'fma'):
         s = HMCSampler(IsotropicGaussian(), torch.zeros((C, D), dtype=torch.float64, device=dev),
                        0.05, L, variable_name='x', rng=DeviceRNG(0, dev), mode=mode)
-        t = _timed(lambda: s.sample_n(F), 4, warm=1) / F
+        t = _timed(lambda: s.sample_n(F, out=rec), 12, warm=3) / F
         out['%s_us_per_transition' % mode] = t * 1e6
         out['%s_chain_steps_per_s' % mode] = C * L / t
         del s
-        torch.cuda.empty_cache()
+    del rec
+    torch.cuda.empty_cache()
     return out
 
 

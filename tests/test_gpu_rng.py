@@ -197,7 +197,11 @@ FUSED_SHAPES = [(64, 1024, 20, 1.0, 0.0, 'exact'), (70, 768, 5, 2.5, 0.3, 'exact
                 (5, 33, 7, 1.0, 0.0, 'fma'), (9, 200, 3, 1.0, -0.2, 'exact'),
                 (4, 1000, 2, 1.0, 0.0, 'exact'), (3, 920, 2, 2.5, 0.3, 'fma'),
                 (130, 7, 4, 1.0, 0.0, 'exact'), (17, 1, 3, 1.0, 0.0, 'exact'),
-                (6, 258, 2, 1.0, 0.0, 'exact'), (2100, 1024, 2, 1.0, 0.0, 'exact')]
+                (6, 258, 2, 1.0, 0.0, 'exact'), (2100, 1024, 2, 1.0, 0.0, 'exact'),
+                # chains of 2 / 4 / 8 waves (the acceptance draw crosses waves)
+                (5, 2048, 3, 1.0, 0.0, 'exact'), (3, 1023, 2, 2.5, 0.3, 'exact'),
+                (7, 3000, 2, 1.0, 0.0, 'fma'), (3, 4096, 2, 1.0, 0.0, 'exact'),
+                (9, 8192, 2, 1.0, 0.0, 'exact'), (2, 7000, 2, 2.5, -0.2, 'exact')]
 
 
 @pytest.mark.parametrize('C,D,L,k,x0,mode', FUSED_SHAPES)
@@ -273,13 +277,13 @@ def test_fused_generator_stream_properties(device):
 
 
 def test_fused_generator_limits_and_fallback(device):
-    z = torch.zeros((3, 2048), dtype=torch.float64, device=device)
+    z = torch.zeros((3, 9000), dtype=torch.float64, device=device)
     with pytest.raises(NotImplementedError):
-        _native.hmc_gauss_rng_draws(1, 3, 2048, 0, 0, device)
+        _native.hmc_gauss_rng_draws(1, 3, 9000, 0, 0, device)
     # longer chains: DeviceRNG falls back to the stand-alone generator kernels
     s = HMCSampler(IsotropicGaussian(), z, 0.02, 3, variable_name='x', rng=DeviceRNG(1, device))
-    assert not s._fused_rng('x', 2048)
-    assert s.sample_n(2).shape == (2, 3, 2048)
+    assert not s._fused_rng('x', 9000)
+    assert s.sample_n(2).shape == (2, 3, 9000)
     # ... and so does a generator that was told not to fuse
     s = HMCSampler(IsotropicGaussian(), z[:, :64].contiguous(), 0.02, 3, variable_name='x',
                    rng=DeviceRNG(1, device, fused=False))
