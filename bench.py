@@ -58,6 +58,11 @@ def parse(argv=None):
     ap.add_argument('--steps', type=int, default=20,
                     help='timed steps; one step = one sample_n(--fuse) launch')
     ap.add_argument('--warmup', type=int, default=5, help='untimed steps')
+    ap.add_argument('--settle-ms', type=float, default=300.0,
+                    help='untimed pre-run of the same workload before the warm-up steps: the '
+                         'chip needs ~50 ms of sustained load before its clock / power '
+                         'controller settles (the first ~20 launches of a cold run take up to '
+                         '1.5x the settled time; profiles/r02_settle_notes.md); 0 = none')
     ap.add_argument('--chains', type=int, default=4096, help='chains per GPU')
     ap.add_argument('--dims', type=int, default=1024)
     ap.add_argument('--nsteps', type=int, default=20, help='leapfrog steps')
@@ -380,17 +385,36 @@ def main():
         return
 
     sampler = make_sampler(args.mode)
-    run(sampler, 0, W)
+    # settle: the same launches, untimed, until the clock / power controller has
+    # converged (not part of the W warm-up steps; reported in the JSON line)
+    n_settle = 0
+    if args.settle_ms > 0:
+        t_s = time.perf_counter()
+        while (time.perf_counter() - t_s) * 1e3 < args.settle_ms:
+            run(sampler, n_settle, 4)
+            torch.cuda.synchronize()
+            n_settle += 4
+    run(sampler, n_settle, W)
     barrier()
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(K + 1)] if K <= 512 else None
     ev0 = torch.cuda.Event(enable_timing=True)
     ev1 = torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record()                                # same stream as the launches
-    run(sampler, W, K)
+    if evs is None:
+        run(sampler, n_settle + W, K)
+    else:                                       # one event per launch: the spread
+        evs[0].record()
+        for i in range(K):
+            run(sampler, n_settle + W + i, 1)
+            evs[i + 1].record()
     ev1.record()
     barrier()
     elapsed = time.perf_counter() - t0
     dev_ms = ev0.elapsed_time(ev1)
+    per_launch_us = None
+    if evs is not None:
+        per_launch_us = sorted(evs[i].elapsed_time(evs[i + 1]) * 1e3 for i in range(K))
 
     acc_rate = float(sampler.acceptance_rate.mean())
     gather_ms = None
@@ -402,12 +426,13 @@ def main():
         om = 'fma' if args.mode == 'exact' else 'exact'
         s2 = make_sampler(om)
         K2 = min(K, 8)
-        run(s2, 0, 2)
+        W2 = 40 if args.settle_ms > 0 else 2     # another arithmetic mix: settle again
+        run(s2, 0, W2)
         torch.cuda.synchronize()
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
         e0.record()
-        run(s2, 2, K2)
+        run(s2, W2, K2)
         e1.record()
         torch.cuda.synchronize()
         t2 = e0.elapsed_time(e1) * 1e-3 / (K2 * F)
@@ -482,6 +507,8 @@ def main():
                 'valu_peak_lane_ops_per_s': VALU_PEAK_LANEOPS,
                 'avg_launch_us': launch_s * 1e6,
                 'avg_transition_us': trans_s * 1e6,
+                'launch_us_min_median_max': None if per_launch_us is None else
+                [per_launch_us[0], per_launch_us[len(per_launch_us) // 2], per_launch_us[-1]],
                 'note': 'frac follows the contract (algorithmic bytes of F sample() calls / '
                         'launch time / 8 TB/s); the persistent kernel keeps q in registers, so '
                         'the bytes it really moves are moved_bytes_per_launch (hbm_frac_moved) '
@@ -511,6 +538,10 @@ def main():
                                       'collective' % world,
                        'draw_buffers': NB},
             'timed_region_ms': elapsed * 1e3,
+            'settle': {'ms': args.settle_ms, 'launches': n_settle,
+                       'what': 'untimed pre-run of the same launches before the %d warm-up steps '
+                               '(clock / power controller of the chip settles in ~50 ms of load; '
+                               '--settle-ms 0 to disable)' % W},
             'acceptance_rate': acc_rate,
             'roofline': roof,
         }

@@ -15,10 +15,17 @@ MFMA_F64_PEAK_TFLOPS = 78.6
 VALU_PEAK_LANEOPS = 39.3e12
 
 
-def _timed(fn, n, warm=2):
+def _timed(fn, n, warm=2, settle_s=0.0):
+    """settle_s: keep launching (untimed) for that long first -- the chip's clock /
+    power controller needs ~50 ms of sustained load to converge."""
+    import time
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
+    t_s = time.perf_counter()
+    while time.perf_counter() - t_s < settle_s:
+        fn()
+        torch.cuda.synchronize()
     e0 = torch.cuda.Event(enable_timing=True)
     e1 = torch.cuda.Event(enable_timing=True)
     e0.record()
@@ -46,7 +53,7 @@ def c3_polynomial(dev, C=8192, K=33, N=16384, L=20):
     A = fwm.design_matrix(K, dev)
     tx = fwm.xs_device(dev)
     ty = torch.from_numpy(ys).to(dev)
-    t_grad = _timed(lambda: _native.poly_gauss_grad(q0, A, ty, 2.5), 20)
+    t_grad = _timed(lambda: _native.poly_gauss_grad(q0, A, ty, 2.5), 20, settle_s=0.1)
     t_logp = _timed(lambda: _native.poly_gauss_logp(q0, tx, ty, 2.5), 20)
     flops = 4.0 * K * N * C                      # 4 K N per chain and gradient
     lik = make_likelihood(xs, ys, POLYVAL)
@@ -111,7 +118,7 @@ def c2_device_rng(dev, C=4096, D=1024, L=20, F=64):
     for mode in ('exact', 'fma'):
         s = HMCSampler(IsotropicGaussian(), torch.zeros((C, D), dtype=torch.float64, device=dev),
                        0.05, L, variable_name='x', rng=DeviceRNG(0, dev), mode=mode)
-        t = _timed(lambda: s.sample_n(F, out=rec), 12, warm=3) / F
+        t = _timed(lambda: s.sample_n(F, out=rec), 12, warm=3, settle_s=0.15) / F
         out['%s_us_per_transition' % mode] = t * 1e6
         out['%s_chain_steps_per_s' % mode] = C * L / t
         del s
@@ -141,7 +148,7 @@ def c2_strong_scaling_shares(dev, D=1024, L=20, F=64):
         def step():
             i[0] += 1
             s.sample_n(F, p0=p0[i[0] % 2], u=u[i[0] % 2], out=rec)
-        t = _timed(step, 6, warm=2) / F
+        t = _timed(step, 8, warm=2, settle_s=0.1) / F
         out['N=%d' % n_gpus] = {'chains_per_gpu': C, 'us_per_transition': t * 1e6,
                                 'chain_steps_per_s_per_gpu': C * L / t}
         del s, p0, u, rec
