@@ -19,7 +19,7 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 $R/bench.py --no-cpu-baseline --no-other-mode --no-extra --no-pmc > $O/bench_under_rocprof.json 2>/dev/null
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 $R/bench.py --pmc-child --steps 6 --warmup 2 > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 $R/bench.py --pmc-child --steps 6 --warmup 2 > /dev/null 2>&1
-rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES --output-format csv -d $O/pmc_valu -- python3 $R/bench.py --pmc-child --steps 6 --warmup 2 > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES --output-format csv -d $O/pmc_valu -- python3 $R/bench.py --pmc-child --steps 100 --warmup 20 > /dev/null 2>&1
 # fused generator (draws generated in the kernel): kernel stats + VALU counters
 cat > /tmp/e2e.py <<'PY'
 import os, sys, torch
@@ -31,7 +31,7 @@ dev = torch.device('cuda:0')
 s = HMCSampler(IsotropicGaussian(), torch.zeros((4096, 1024), dtype=torch.float64, device=dev), 0.05, 20,
                variable_name='x', rng=DeviceRNG(0, dev))
 buf = torch.empty((64, 4096, 1024), dtype=torch.float64, device=dev)
-for _ in range(8): s.sample_n(64, out=buf)
+for _ in range(120): s.sample_n(64, out=buf)
 torch.cuda.synchronize()
 PY
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_e2e -- python3 /tmp/e2e.py > /dev/null 2>&1

@@ -26,10 +26,12 @@ def counters(d, kernel):
 
 
 def durations(d, kernel):
+    """kernel durations in dispatch order (us)"""
     f = first(O + '/' + d + '/**/*kernel_trace.csv')
     if not f:
         return []
     rows = [r for r in csv.DictReader(open(f)) if kernel in r['Kernel_Name']]
+    rows.sort(key=lambda r: int(r['Start_Timestamp']))
     return [(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3 for r in rows]
 
 
@@ -41,6 +43,9 @@ wr, nwr = counters('pmc_write', 'persist')
 d = durations('prof', 'persist')
 out['persist_kernel'] = {
     'rocprof_kernel_mean_us': statistics.mean(d) if d else None, 'rocprof_kernel_n': len(d),
+    # the last 20 dispatches are bench.py's timed steps (settle and warm-up come before)
+    'rocprof_kernel_mean_us_timed_steps': statistics.mean(d[-20:]) if len(d) >= 20 else None,
+    'rocprof_first_20_dispatches_us': [round(x, 1) for x in d[:20]],
     'rocprof_kernel_min_us': min(d) if d else None, 'rocprof_kernel_max_us': max(d) if d else None,
     'bench_avg_launch_us': b['roofline']['avg_launch_us'],
     'bench_under_rocprof_avg_launch_us':
@@ -66,6 +71,7 @@ def valu(d, kernel, trace_dir=None):
     dur = durations(trace_dir or d, kernel)
     if not m or not dur:
         return None
+    # counters are averaged over all dispatches, so is the duration
     t = statistics.mean(dur) * 1e-6
     cyc = m['GRBM_GUI_ACTIVE'] / 8                     # summed over the 8 XCDs
     r = {'kernel_us': t * 1e6, 'shader_clock_GHz': cyc / t * 1e-9,
@@ -81,7 +87,9 @@ out['fused_generator_kernel_valu'] = valu('pmc_e2e', 'persist')
 de = durations('prof_e2e', 'persist')
 out['fused_generator_kernel'] = {'rocprof_kernel_mean_us': statistics.mean(de) if de else None,
                                  'n': len(de), 'transitions_per_launch': 64,
-                                 'us_per_transition': statistics.mean(de) / 64 if de else None}
+                                 'us_per_transition': statistics.mean(de) / 64 if de else None,
+                                 'us_per_transition_last_40': statistics.mean(de[-40:]) / 64
+                                 if len(de) >= 40 else None}
 m, _ = counters('pmc_poly', 'poly_grad_mfma')
 dp = durations('pmc_poly', 'poly_grad_mfma')
 if m and dp:
