@@ -13,43 +13,15 @@
 // dump.  Same shapes as the persistent kernel (D <= 8192, tree height <= 6; chains
 // of 2 / 4 / 8 waves pass the acceptance draw from wave to wave through LDS);
 // longer chains use the stand-alone generator kernels (rng.hip).
-#include "hmc_gauss_kernel.hpp"
+#include "hmc_gauss_rng_launch.hpp"
 
 namespace binf {
-
-template <int TMAX, bool REGULAR, int RNG, int LW = 0>
-static hipError_t launch_rng_tr(const GaussNArgs &a, bool unit, bool fma, dim3 grid, hipStream_t st)
-{
-    if (RNG == GAUSS_RNG_DUMP) {
-        hmc_gauss_persist_kernel<TMAX, REGULAR, true, false, LW, RNG><<<grid, 512, 0, st>>>(a);
-    } else if (unit) {
-        if (fma) hmc_gauss_persist_kernel<TMAX, REGULAR, true, true, LW, RNG><<<grid, 512, 0, st>>>(a);
-        else     hmc_gauss_persist_kernel<TMAX, REGULAR, true, false, LW, RNG><<<grid, 512, 0, st>>>(a);
-    } else {
-        if (fma) hmc_gauss_persist_kernel<TMAX, REGULAR, false, true, LW, RNG><<<grid, 512, 0, st>>>(a);
-        else     hmc_gauss_persist_kernel<TMAX, REGULAR, false, false, LW, RNG><<<grid, 512, 0, st>>>(a);
-    }
-    return hipGetLastError();
-}
-
-// chains of 2 / 4 / 8 waves: leaves of any length <= 128, so TMAX = 16
-template <int RNG, int LW>
-static hipError_t launch_rng_wide(const GaussNArgs &a, const GaussPlan &p, bool unit, bool fma,
-                                  hipStream_t st)
-{
-    const int64_t chains_per_block = 8 >> LW;        // 8 waves per workgroup (gauss_wpb)
-    const dim3 grid((unsigned)((a.C + chains_per_block - 1) / chains_per_block));
-    return (p.regular && p.tneed == 16) ? launch_rng_tr<16, true, RNG, LW>(a, unit, fma, grid, st)
-                                        : launch_rng_tr<16, false, RNG, LW>(a, unit, fma, grid, st);
-}
 
 template <int RNG>
 static hipError_t launch_rng(const GaussNArgs &a, const GaussPlan &p, bool unit, bool fma,
                              hipStream_t st)
 {
-    if (p.LW == 1) return launch_rng_wide<RNG, 1>(a, p, unit, fma, st);
-    if (p.LW == 2) return launch_rng_wide<RNG, 2>(a, p, unit, fma, st);
-    if (p.LW == 3) return launch_rng_wide<RNG, 3>(a, p, unit, fma, st);
+    if (p.LW > 0) return launch_gauss_rng_wide(a, p, RNG, unit, fma, st);   // hmc_gauss_rng_wide.hip
     const dim3 grid((unsigned)((p.blocks + 1) / 2));   // 8 waves per workgroup (gauss_wpb)
     const int t = p.tneed;
 #define BINF_RNG_CASE(T)                                                            \

@@ -359,7 +359,10 @@ using namespace binf;
         if ((K) <= 4) { CALL(4); }                                            \
         else if ((K) <= 8) { CALL(8); }                                       \
         else if ((K) <= 16) { CALL(16); }                                     \
+        else if ((K) <= 24) { CALL(24); }                                     \
+        else if ((K) <= 33) { CALL(33); }  /* degree 32: BASELINE C3 / C4 */  \
         else if ((K) <= 36) { CALL(36); }                                     \
+        else if ((K) <= 48) { CALL(48); }                                     \
         else { CALL(64); }                                                    \
     } while (0)
 

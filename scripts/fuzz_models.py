@@ -59,7 +59,11 @@ for case in range(n_cases):
     g = lik.gradient(coordinates=t(x), precision=t(tau)).cpu().numpy()
     for c in range(C):
         w = RD.gradient(x[c], ys, tau[c], n)
-        if np.abs(g[c] - w).max() > 1e-10 * np.abs(w).max():
+        # scale of the sum: tau * sum_j |x_i - x_j| (each pair's weight (d - y)/d is O(1) and is
+        # evaluated as 1 - y * rsqrt(d^2): absolute, not relative, accuracy when d ~ y)
+        xc = x[c].reshape(n, 3)
+        scale = tau[c] * np.abs(xc[:, None, :] - xc[None, :, :]).sum(axis=1).max()
+        if np.abs(g[c] - w).max() > 1e-10 * max(np.abs(w).max(), scale):
             report('pairdist force', n=n, C=C, c=c)
     # batch-size independence across the 1-lane / 4-lane switch (C < 1024, n <= 512)
     if n <= 300 and case % 4 == 0:
