@@ -43,6 +43,7 @@ SIGNATURES = {
                                            _vp, _vp, _f64, _vp, _i64, _i64,
                                            _i32, _i32, _i32, _f64, _f64, _i32,
                                            _f64, _f64, _i32, _vp]),
+    'binf_hmc_gauss_waves_per_chain': (_i32, [_i64, _i64]),
     'binf_hmc_sample_gauss_big_workspace_bytes': (_i64, [_i64, _i64]),
     'binf_hmc_sample_gauss_big_f64': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                              _f64, _vp, _i64, _i64, _i32, _f64,
@@ -538,6 +539,11 @@ def hmc_sample_n_gauss(q0, p0, u, q_out, samples, accepted, n_accepted,
         float(k), float(x0), int(n_adapt), float(uprate), float(downrate),
         int(mode), stream_handle(q0.device))
     check(rc, 'binf_hmc_sample_n_gauss_f64')
+
+
+def gauss_waves_per_chain(C, D):
+    """Waves the persistent kernel spreads a chain over for a [C x D] batch."""
+    return lib().binf_hmc_gauss_waves_per_chain(int(C), int(D))
 
 
 def gauss_persist_covers(D):

@@ -142,6 +142,20 @@ extern "C" int32_t binf_hmc_sample_n_gauss_f64(
     return 0;
 }
 
+// How many waves binf_hmc_sample_[n_]gauss_f64 spreads a chain over for a batch
+// of C chains of length D: 1 (one-wave chains; also for every shape the split
+// kernel does not serve), 2 or 4 (few chains of D = 768 / 1024), or 2 / 4 / 8 for
+// D > 1024.  Informational: lets a caller pick the draw source that suits the
+// launch shape (binf_amd/samplers/hmc.py).
+extern "C" int32_t binf_hmc_gauss_waves_per_chain(int64_t C, int64_t D)
+{
+    if (C < 1 || D < 1 || D > 8192) return 0;
+    const GaussPlan p = gauss_plan(C, D);
+    if (p.H > 6) return 0;
+    if (p.LW > 0) return 1 << p.LW;
+    return gauss_split_factor(C, p.H, p.regular, p.tneed);
+}
+
 // One transition per launch: HMCSampler.sample() for every chain.
 extern "C" int32_t binf_hmc_sample_gauss_f64(
     const double *q0, const double *p0, const double *u, double *q_out,

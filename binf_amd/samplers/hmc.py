@@ -126,7 +126,7 @@ class HMCSampler(object):
         q0 = (state if state.dim() == 2 else state.reshape(1, -1)).contiguous()
         C, D = q0.shape
         dev = q0.device
-        if p0 is None and u is None and self._fused_rng(name, D):
+        if p0 is None and u is None and self._fused_rng(name, D, C):
             # the draws are generated inside the sampling kernel
             return self._sample_n_fused_rng(1)
         if p0 is None:
@@ -188,7 +188,7 @@ class HMCSampler(object):
         C, D = q0.shape
         dev = q0.device
         nrec = n // thin
-        fused_rng = p0 is None and u is None and self._fused_rng(name, D)
+        fused_rng = p0 is None and u is None and self._fused_rng(name, D, C)
         if not fused_rng:
             if p0 is None:
                 p0 = self.rng.normal((n, C, D), dev)
@@ -265,14 +265,23 @@ class HMCSampler(object):
         return samples if state.dim() == 2 else samples.reshape((nrec,) + tuple(shape))
 
     # -- fused tier ----------------------------------------------------------
-    def _fused_rng(self, name, D):
-        """True if this sampler's draws can be generated inside the sampling
+    def _fused_rng(self, name, D, C=None):
+        """True if this sampler's draws are generated inside the sampling
         kernel: a device generator that allows it, a Gaussian with a fused
-        kernel, one-wave chains."""
+        kernel of that shape -- and a batch large enough for one wave per chain.
+        Up to 1024 chains of D = 768 / 1024 the library spreads a chain over 4
+        waves when the draws come from HBM (hmc_gauss_split.hip); that beats the
+        one-wave kernel with its own generator (512 chains: 4.0 vs 10.5 us per
+        transition, scripts/probe_small_batch_rng.py), so such batches take the
+        stand-alone generator kernels."""
         if not getattr(self.rng, 'fused', False):
             return False
         spec = self._fused_spec(name, D)
-        return spec is not None and spec[0] == 'gauss' and _native.fused_rng_covers(D)
+        if spec is None or spec[0] != 'gauss' or not _native.fused_rng_covers(D):
+            return False
+        if getattr(self.rng, 'fused', False) == 'always' or C is None:
+            return True
+        return D > 1024 or _native.gauss_waves_per_chain(C, D) < 4
 
     def _sample_n_fused_rng(self, n):
         """sample() with in-kernel draws: one transition, the new state."""

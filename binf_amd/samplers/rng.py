@@ -36,11 +36,14 @@ class DeviceRNG(object):
         self.seed = int(seed)
         self.offset = 0
         self.device = torch.device(device)
-        # fused: a sampler whose kernel can generate its own draws
-        # (HMCSampler on a Gaussian, one-wave chains) asks for a stream position
-        # with next_offset() instead of for buffers: the momentum never exists
-        # in HBM.  Off = always the stand-alone generator kernels.
-        self.fused = bool(fused)
+        # fused: a sampler whose kernel can generate its own draws (HMCSampler
+        # on a Gaussian, D <= 8192, more than 1024 chains) asks for a stream
+        # position with next_offset() instead of for buffers: the momentum
+        # never exists in HBM.  Which generator serves a sampler therefore
+        # depends on the batch shape; fused=False = always the stand-alone
+        # generator kernels (draws independent of the batch shape);
+        # fused='always' = the in-kernel generator whenever the shape is covered.
+        self.fused = fused if fused == 'always' else bool(fused)
 
     def next_offset(self):
         """Reserve one launch worth of the in-kernel generator's stream."""

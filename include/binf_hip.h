@@ -118,6 +118,11 @@ int32_t binf_hmc_sample_n_gauss_f64(const double *q0, const double *p0,
                                     double uprate, double downrate,
                                     int32_t mode, void *stream);
 
+/* Waves per chain binf_hmc_sample_[n_]gauss_f64 uses for a [C x D] batch: 1, or
+ * 2 / 4 for few chains of D = 768 / 1024 (a chain spread over several waves), or
+ * 2 / 4 / 8 for 1024 < D <= 8192; 0 if the shape is not covered.  Host function. */
+int32_t binf_hmc_gauss_waves_per_chain(int64_t C, int64_t D);
+
 /* ------------------------------------------------------------------------
  * One transition for chains of ANY length -- what binf_hmc_sample_gauss_f64
  * does not cover (D > 8192; lengths whose pairwise tree is deeper than 6).

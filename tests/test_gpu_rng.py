@@ -213,8 +213,8 @@ def test_fused_generator_equals_sampling_from_its_own_dump(device, C, D, L, k, x
     q0 = torch.from_numpy(np.random.RandomState(D).standard_normal((C, D))).to(device)
     dt = 0.9 / np.sqrt(k * max(D, 4))
     kw = dict(timestep_adaption_limit=4, variable_name='x', mode=mode, record_energies=True)
-    a = HMCSampler(IsotropicGaussian(k, x0), q0, dt, L, rng=DeviceRNG(seed, device), **kw)
-    assert a._fused_rng('x', D)
+    a = HMCSampler(IsotropicGaussian(k, x0), q0, dt, L, rng=DeviceRNG(seed, device, fused='always'), **kw)
+    assert a._fused_rng('x', D, C)
     rec_a = a.sample_n(n)                                    # offset 0
     rec_a2 = a.sample_n(2, thin=2)                           # offset 1
     p0, u = _native.hmc_gauss_rng_draws(n, C, D, seed, 0, device)
@@ -229,7 +229,7 @@ def test_fused_generator_equals_sampling_from_its_own_dump(device, C, D, L, k, x
     assert torch.equal(a.timestep, b.timestep)
     assert torch.equal(a.last_e_after, b.last_e_after)
     # single sample() calls take the same route
-    a2 = HMCSampler(IsotropicGaussian(k, x0), q0, dt, L, rng=DeviceRNG(seed, device), **kw)
+    a2 = HMCSampler(IsotropicGaussian(k, x0), q0, dt, L, rng=DeviceRNG(seed, device, fused='always'), **kw)
     x = a2.sample()
     assert torch.equal(x, rec_b[0]) and torch.equal(a2.last_move_accepted, h_b[0])
     assert torch.equal(a2.last_e_before, e_b[0][0])
@@ -284,6 +284,16 @@ def test_fused_generator_limits_and_fallback(device):
     s = HMCSampler(IsotropicGaussian(), z, 0.02, 3, variable_name='x', rng=DeviceRNG(1, device))
     assert not s._fused_rng('x', 9000)
     assert s.sample_n(2).shape == (2, 3, 9000)
+    # few chains of D = 1024: a chain is spread over 4 waves with draws from HBM, which beats
+    # the one-wave kernel with its own generator -> stand-alone generator kernels
+    for C, want in ((64, False), (1024, False), (1025, True), (2100, True), (5000, True)):
+        s = HMCSampler(IsotropicGaussian(), torch.zeros((C, 1024), dtype=torch.float64, device=device),
+                       0.02, 3, variable_name='x', rng=DeviceRNG(1, device))
+        assert s._fused_rng('x', 1024, C) is want, C
+    assert _native.gauss_waves_per_chain(512, 1024) == 4
+    assert _native.gauss_waves_per_chain(2048, 1024) == 2
+    assert _native.gauss_waves_per_chain(4096, 1024) == 1
+    assert _native.gauss_waves_per_chain(10, 4096) == 4 and _native.gauss_waves_per_chain(10, 9000) == 0
     # ... and so does a generator that was told not to fuse
     s = HMCSampler(IsotropicGaussian(), z[:, :64].contiguous(), 0.02, 3, variable_name='x',
                    rng=DeviceRNG(1, device, fused=False))
