@@ -167,7 +167,9 @@ class HMCSampler(object):
         of the reference's ``example_script.py:33-34``), returning the recorded
         states ``[n // thin, C, D]`` -- the state after transitions ``thin,
         2*thin, ...`` -- or None if ``record`` is false.  Results are
-        bit-identical to calling ``sample()`` n times with the same draws.
+        bit-identical to calling ``sample()`` n times with the same draws
+        (with a generator that draws inside the kernel, one launch takes one
+        stream position, so n single calls see other -- equally valid -- draws).
 
         For PDFs with a fused kernel this is ONE launch of the persistent
         kernel (state kept in registers between transitions); otherwise it

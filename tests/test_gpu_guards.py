@@ -204,3 +204,40 @@ def test_long_chain_kernels_stay_inside_their_buffers(device, D, C):
         assert np.array_equal(a, b)
     assert not np.isnan(outs[0][0]).any()
     assert outs[0][1][0] == 0 and np.array_equal(outs[0][0][0], q0[0])
+
+
+@pytest.mark.parametrize('D,C,n', [(1, 3, 2), (7, 5, 2), (33, 9, 3), (258, 3, 2), (1000, 3, 2),
+                                   (1024, 70, 2), (2048, 3, 2), (3000, 2, 1), (8192, 2, 1)])
+def test_in_kernel_generator_stays_inside_its_buffers(device, D, C, n):
+    """binf_hmc_gauss_rng_draws_f64 / binf_hmc_sample_n_gauss_rng_f64 on guarded
+    windows: guard zones untouched, every element of the dump written, results
+    equal to the same calls on plain tensors."""
+    lib = _native.lib()
+    st = _native.stream_handle(device)
+    rs = np.random.RandomState(D)
+    q0 = rs.standard_normal((C, D))
+    outs = []
+    for make in (Guarded(device), None):
+        t = make if make is not None else (lambda a, dtype=torch.float64: plain(a, device, dtype))
+        pd, ud = t(np.full((n, C, D), 77.0)), t(np.full((n, C), 77.0))
+        rc = lib.binf_hmc_gauss_rng_draws_f64(pd.data_ptr(), ud.data_ptr(), C, D, n, 5, 2, st)
+        assert rc == 0
+        tq, qo, smp = t(q0), t(np.zeros((C, D))), t(np.zeros((n, C, D)))
+        acc = t(np.zeros((n, C), dtype=np.uint8), torch.uint8)
+        nacc = t(np.zeros(C, dtype=np.int64), torch.int64)
+        eb, ea = t(np.zeros((n, C))), t(np.zeros((n, C)))
+        dtc = t(np.full(C, 0.1))
+        rc = lib.binf_hmc_sample_n_gauss_rng_f64(
+            tq.data_ptr(), qo.data_ptr(), smp.data_ptr(), acc.data_ptr(), nacc.data_ptr(),
+            eb.data_ptr(), ea.data_ptr(), 0.1, dtc.data_ptr(), C, D, 4, n, 1, 2.5, 0.3, n, 1.05,
+            0.95, _native.MODE_EXACT, 5, 2, st)
+        assert rc == 0
+        if make is not None:
+            make.check()
+        outs.append([x.cpu().numpy().copy() for x in (pd, ud, qo, smp, acc, nacc, eb, ea, dtc)])
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)
+    pd, ud = outs[0][0], outs[0][1]
+    assert not (pd == 77.0).any() and not (ud == 77.0).any()      # every draw written
+    assert np.isfinite(pd).all() and (0.0 <= ud).all() and (ud < 1.0).all()
+    assert np.isfinite(outs[0][3]).all()
