@@ -59,7 +59,10 @@ def test_clipped_exp_bounds():
     (1, 1, 1.0, 0.0, 0.5), (4, 3, 1.0, 0.0, 0.3), (7, 2, 2.5, 0.3, 0.9),
     (8, 5, 1.0, 0.0, 0.5), (33, 20, 2.5, 0.3, 0.35), (129, 4, 1.0, -1.0, 0.3),
     (300, 10, 1.0, 0.0, 0.25), (768, 20, 1.0, 0.0, 0.22),
-    (1023, 3, 2.5, 0.3, 0.1), (1024, 20, 1.0, 0.0, 0.2), (2500, 2, 1.0, 0.0, 0.1)])
+    (1023, 3, 2.5, 0.3, 0.1), (1024, 20, 1.0, 0.0, 0.2), (2500, 2, 1.0, 0.0, 0.1),
+    # longer than numpy's 8192-element reduction buffer: chunk sums chained
+    (7689, 2, 1.0, 0.0, 0.05), (8193, 2, 1.0, 0.0, 0.05), (9000, 3, 2.5, 0.3, 0.03),
+    (16389, 2, 1.0, 0.0, 0.03), (40000, 1, 1.0, -0.1, 0.02)])
 def test_c_oracle_equals_numpy_restatement(D, L, k, x0, dt):
     rs = np.random.RandomState(D * 31 + L)
     C = 5
