@@ -43,6 +43,8 @@ GAUSS_SETS = [
     ('gauss_d1024_l20',   1024, 20, 1.0, 0.0,  0.05,  4, 2, 0, 190),
     ('gauss_d1024_l20_bigdt', 1024, 20, 1.0, 0.0, 0.20, 6, 2, 0, 200),
     ('gauss_d1024_l1_adapt', 1024, 1, 2.5, 0.3, 0.18, 4, 4, 4, 210),
+    # longer than numpy's 8192-element reduction buffer (one full chunk + a ragged one)
+    ('gauss_d8200_l2_adapt', 8200, 2, 1.0, 0.0, 0.16, 2, 3, 3, 220),
 ]
 
 
@@ -158,9 +160,13 @@ def run_dist_set(n, C, ncalls, L, dt, precision, prior_k, seed):
                 likelihood_log_prob=logp, likelihood_gradient=grad)
 
 
-def main():
+def main(only=None):
+    """only: write just the sets whose name is in that collection (adding a
+    fixture must not rewrite the existing files)."""
     os.makedirs(OUT, exist_ok=True)
     for name, K, N, C, sweeps, L, dt, seed in POLY_SETS:
+        if only is not None and name not in only:
+            continue
         r = run_poly_set(K, N, C, sweeps, L, dt, seed)
         np.savez(os.path.join(OUT, name + '.npz'), K=K, N=N, L=L, timestep=dt, seed=seed,
                  provenance=PROVENANCE.replace('binf/samplers/hmc.py:92-164 + binf/pdf/__init__.py:181-191',
@@ -168,6 +174,8 @@ def main():
                  **r)
         print('%-26s acc=%s' % (name, r['accepted'].mean(axis=1)))
     for name, n, C, ncalls, L, dt, precision, prior_k, seed in DIST_SETS:
+        if only is not None and name not in only:
+            continue
         r = run_dist_set(n, C, ncalls, L, dt, precision, prior_k, seed)
         np.savez(os.path.join(OUT, name + '.npz'), n_beads=n, L=L, timestep=dt, precision=precision,
                  prior_k=prior_k, seed=seed,
@@ -176,6 +184,8 @@ def main():
                  **r)
         print('%-26s acc=%s' % (name, r['accepted'].mean(axis=1)))
     for name, D, L, k, x0, dt, C, ncalls, limit, seed in GAUSS_SETS:
+        if only is not None and name not in only:
+            continue
         r = run_gauss_set(D, L, k, x0, dt, C, ncalls, limit, seed)
         np.savez(os.path.join(OUT, name + '.npz'), D=D, L=L, k=k, x0=x0,
                  timestep=dt, adaption_limit=limit, seed=seed,
@@ -184,4 +194,5 @@ def main():
 
 
 if __name__ == '__main__':
-    main()
+    import sys
+    main(only=set(sys.argv[1:]) or None)
