@@ -388,7 +388,18 @@ def main():
     # settle: the same launches, untimed, until the clock / power controller has
     # converged (not part of the W warm-up steps; reported in the JSON line)
     n_settle = 0
+    cold_us = None
     if args.settle_ms > 0:
+        # the first launches of the run, one event each: the ramp the settle phase
+        # exists for (reported, so that the cold-start reading is in the same line)
+        cev = [torch.cuda.Event(enable_timing=True) for _ in range(21)]
+        cev[0].record()
+        for i in range(20):
+            run(sampler, i, 1)
+            cev[i + 1].record()
+        torch.cuda.synchronize()
+        cold_us = [round(cev[i].elapsed_time(cev[i + 1]) * 1e3, 1) for i in range(20)]
+        n_settle = 20
         t_s = time.perf_counter()
         while (time.perf_counter() - t_s) * 1e3 < args.settle_ms:
             run(sampler, n_settle, 4)
@@ -539,6 +550,7 @@ def main():
                        'draw_buffers': NB},
             'timed_region_ms': elapsed * 1e3,
             'settle': {'ms': args.settle_ms, 'launches': n_settle,
+                       'first_20_launch_us': cold_us,
                        'what': 'untimed pre-run of the same launches before the %d warm-up steps '
                                '(clock / power controller of the chip settles in ~50 ms of load; '
                                '--settle-ms 0 to disable)' % W},
