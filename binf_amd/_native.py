@@ -49,6 +49,12 @@ SIGNATURES = {
                                              _f64, _vp, _i64, _i64, _i32, _f64,
                                              _f64, _i32, _f64, _f64, _i32, _vp,
                                              _i64, _vp]),
+    'binf_hmc_sample_gauss_big_rng_f64': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _f64, _vp,
+                                                 _i64, _i64, _i32, _f64, _f64, _i32,
+                                                 _f64, _f64, _i32, ctypes.c_uint64,
+                                                 ctypes.c_uint64, _vp, _i64, _vp]),
+    'binf_hmc_gauss_big_rng_draws_f64': (_i32, [_vp, _vp, _i64, _i64, ctypes.c_uint64,
+                                                ctypes.c_uint64, _vp]),
     'binf_hmc_sample_n_gauss_rng_f64': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                                _f64, _vp, _i64, _i64, _i32, _i32,
                                                _i32, _f64, _f64, _i32, _f64, _f64,
@@ -571,6 +577,40 @@ def hmc_sample_gauss_big(q0, p0, u, q_out, accepted, n_accepted, e_before, e_aft
         float(k), float(x0), int(bool(adapt)), float(uprate), float(downrate), int(mode),
         dptr(ws), nbytes, stream_handle(q0.device))
     check(rc, 'binf_hmc_sample_gauss_big_f64')
+
+
+@_launcher
+def hmc_sample_gauss_big_rng(q0, q_out, accepted, n_accepted, e_before, e_after, timestep,
+                             dt_chain, nsteps, k, x0, adapt, uprate, downrate, mode, seed,
+                             offset):
+    """binf_hmc_sample_gauss_big_rng_f64 (long chains, draws generated in the
+    kernels) on torch's current stream."""
+    C, D = _cd(q0)
+    nbytes = lib().binf_hmc_sample_gauss_big_workspace_bytes(C, D)
+    ws = torch.empty(max(1, nbytes // 8), dtype=torch.float64, device=q0.device)
+    rc = lib().binf_hmc_sample_gauss_big_rng_f64(
+        dptr(q0, numel=C * D, name='q0'), dptr(q_out, numel=C * D, name='q_out'),
+        dptr(accepted, torch.uint8, C, 'accepted'),
+        dptr(n_accepted, torch.int64, C, 'n_accepted'),
+        dptr(e_before, numel=C, name='e_before'), dptr(e_after, numel=C, name='e_after'),
+        float(timestep), dptr(dt_chain, numel=C, name='dt_chain'), C, D, int(nsteps),
+        float(k), float(x0), int(bool(adapt)), float(uprate), float(downrate), int(mode),
+        int(seed) & (2 ** 64 - 1), int(offset) & (2 ** 64 - 1), dptr(ws), nbytes,
+        stream_handle(q0.device))
+    check(rc, 'binf_hmc_sample_gauss_big_rng_f64')
+
+
+def hmc_gauss_big_rng_draws(C, D, seed, offset, device):
+    """(p0 [C, D], u [C]): the draws hmc_sample_gauss_big_rng consumes."""
+    C, D = int(C), int(D)
+    p0 = torch.empty((C, D), dtype=torch.float64, device=device)
+    u = torch.empty(C, dtype=torch.float64, device=device)
+    with torch.cuda.device(p0.device):
+        rc = lib().binf_hmc_gauss_big_rng_draws_f64(
+            dptr(p0), dptr(u), C, D, int(seed) & (2 ** 64 - 1), int(offset) & (2 ** 64 - 1),
+            stream_handle(p0.device))
+    check(rc, 'binf_hmc_gauss_big_rng_draws_f64')
+    return p0, u
 
 
 @_launcher

@@ -23,6 +23,7 @@
 //     only (accepted chains cost one flag read per 2 KiB).
 #include "gauss_common.hpp"
 #include "rowsum.hpp"
+#include "xoshiro.hpp"
 
 namespace binf {
 
@@ -42,7 +43,18 @@ struct BigArgs {
     int32_t H;               // tree height of the chunks this launch covers (<= 7)
     int32_t chunk0;          // first chunk of this launch
     int32_t chunks_here;     // chunks per chain in this launch
+    // draws generated in the kernel (RNG != 0)
+    uint64_t rng_seed;
+    uint64_t rng_offset;
+    double *p_dump;          // [C x D], RNG == 2 only
 };
+
+// RNG = 0: the momentum is read from HBM; 1: generated in the kernel (xoshiro.hpp),
+// no momentum buffer; 2: only written out (p_dump), nothing integrated -- the
+// handle by which the in-kernel generator is tested (fused == sampling from its dump).
+enum { BIG_RNG_HBM = 0, BIG_RNG_FUSED = 1, BIG_RNG_DUMP = 2 };
+// the stream of the chain's acceptance draw (finish kernel): its own id space
+constexpr uint64_t BIG_U_STREAM = 1ull << 62;
 
 // Leaf sum of per-lane register values: in-lane running sum r over t < T
 // (numpy's accumulator j), combined ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)), then
@@ -67,12 +79,17 @@ __device__ inline double leaf_finish(double r, double tail, int T, int rem, int 
 
 // REG: full 8192-element chunks -- 64 leaves of 128 elements, tree height 6, no
 // ragged leaves, no masks; !REG: the last, shorter chunk of a chain (any length).
-template <bool UNIT, bool FMA, bool REG>
+template <bool UNIT, bool FMA, bool REG, int RNG = BIG_RNG_HBM>
 __global__ void __launch_bounds__(256) hmc_gauss_big_traj_kernel(const BigArgs a)
 {
     constexpr int GS = 8;                    // a lane's 16 elements, in two halves
     __shared__ double S[4][128];
     __shared__ int dep[128];
+    __shared__ double zx[RNG == BIG_RNG_HBM ? 1 : XZIG_C + 1];
+    if (RNG != BIG_RNG_HBM) {
+        xzig_load_table(zx, threadIdx.x, 256);
+        __syncthreads();
+    }
     const int H = a.H;
     const int npaths = 1 << H;
     const int lane = threadIdx.x & 63;
@@ -88,6 +105,12 @@ __global__ void __launch_bounds__(256) hmc_gauss_big_traj_kernel(const BigArgs a
     const double *q0 = a.q0 + c * a.D + cbase;
     const double *p0 = a.p0 + c * a.D + cbase;
     double *qo = a.q_out + c * a.D + cbase;
+    // one random stream per lane and (chain, chunk): it serves the lane's leaves in
+    // the order the workgroup walks them (lane group g: paths g, g + 32, ...)
+    Xo128 gen = {0u, 0u, 0u, 0u};
+    if (RNG != BIG_RNG_HBM)
+        gen = xo_seed((((uint64_t)c * (uint64_t)a.nchunks + (uint64_t)chunk) * 32 + (uint64_t)group) * 8
+                          + (uint64_t)j, a.rng_seed, a.rng_offset);
 
     // A lane integrates its leaf in two halves of GS = 8 elements.  The halves of
     // consecutive leaves form one stream of work items through a two-deep
@@ -117,12 +140,27 @@ __global__ void __launch_bounds__(256) hmc_gauss_big_traj_kernel(const BigArgs a
         for (int i = 0; i < GS; ++i) {
             const int e = 8 * (h * GS + i) + j;
             const bool m = REG || (it.work && (e < it.L.len));
-            q[i] = m ? q0[it.L.off + e] : 0.0;
-            p[i] = m ? p0[it.L.off + e] : 0.0;
+            q[i] = (m && RNG != BIG_RNG_DUMP) ? q0[it.L.off + e] : 0.0;
+            if (RNG == BIG_RNG_HBM) p[i] = m ? p0[it.L.off + e] : 0.0;
         }
     };
     LaneSum sq0, sp0, sqL, spL;
     auto run_half = [&](double(&q)[GS], double(&p)[GS], const Item &it, int h, int T) {
+        if (RNG != BIG_RNG_HBM) {
+            // this half's momentum draw, np.random.normal (hmc.py:146)
+            unsigned want = 0;
+#pragma unroll
+            for (int i = 0; i < GS; ++i)
+                if (REG || (it.work && (8 * (h * GS + i) + j < it.L.len))) want |= 1u << i;
+            xzig_normals<GS>(p, want, gen, zx);
+            if (RNG == BIG_RNG_DUMP) {
+                double *po = a.p_dump + c * a.D + cbase;
+#pragma unroll
+                for (int i = 0; i < GS; ++i)
+                    if (want & (1u << i)) po[it.L.off + 8 * (h * GS + i) + j] = p[i];
+                return;
+            }
+        }
 #pragma unroll
         for (int i = 0; i < GS; ++i) {                         // hmc.py:143,148
             const double d = UNIT ? q[i] : q[i] - a.x0;
@@ -186,6 +224,7 @@ __global__ void __launch_bounds__(256) hmc_gauss_big_traj_kernel(const BigArgs a
         }
         cur = nxt;
     }
+    if (RNG == BIG_RNG_DUMP) return;
     __syncthreads();
     // redundant paths take the sums of the leaf they coincide with
     if (!REG && (int)threadIdx.x < npaths) {
@@ -221,7 +260,10 @@ __global__ void __launch_bounds__(256) hmc_gauss_big_traj_kernel(const BigArgs a
 
 struct BigFinishArgs {
     const double *ws;
-    const double *u;
+    const double *u;         // null: the acceptance draw comes from the generator
+    double *u_dump;          // write it out (tests)
+    uint64_t rng_seed;
+    uint64_t rng_offset;
     uint8_t *accepted;
     int64_t *n_accepted;
     double *e_before;
@@ -241,7 +283,7 @@ __global__ void __launch_bounds__(256) hmc_gauss_big_finish_kernel(const BigFini
     if (c >= a.C) return;
     double t[4] = {0.0, 0.0, 0.0, 0.0};      // the reduction's identity, then chunk after chunk
     const double *w = a.ws + c * a.nchunks * 4;
-    for (int ch = 0; ch < a.nchunks; ++ch) {
+    for (int ch = 0; a.ws && ch < a.nchunks; ++ch) {
 #pragma unroll
         for (int v = 0; v < 4; ++v) t[v] = t[v] + w[ch * 4 + v];
     }
@@ -251,7 +293,16 @@ __global__ void __launch_bounds__(256) hmc_gauss_big_finish_kernel(const BigFini
     double x = -(Ea - Eb);                                    // hmc.py:151
     x = (x < -308.0) ? -308.0 : x;
     x = (x > 709.0) ? 709.0 : x;
-    const bool acc = a.u[c] < exp_clipped_range(x);
+    double uu;
+    if (a.u) {
+        uu = a.u[c];
+    } else {                                                  // np.random.uniform, hmc.py:151
+        Xo128 gen = xo_seed(BIG_U_STREAM + (uint64_t)c, a.rng_seed, a.rng_offset);
+        uu = xo_uniform53(gen);
+    }
+    if (a.u_dump) a.u_dump[c] = uu;
+    if (!a.ws) return;                                        // draw dump only
+    const bool acc = uu < exp_clipped_range(x);
     a.accepted[c] = acc ? 1 : 0;
     if (a.e_before) a.e_before[c] = Eb;
     if (a.e_after) a.e_after[c] = Ea;
@@ -299,50 +350,44 @@ extern "C" int64_t binf_hmc_sample_gauss_big_workspace_bytes(int64_t C, int64_t 
     return C * (int64_t)big_chunks(D) * 4 * (int64_t)sizeof(double);
 }
 
-extern "C" int32_t binf_hmc_sample_gauss_big_f64(
-    const double *q0, const double *p0, const double *u, double *q_out, uint8_t *accepted,
-    int64_t *n_accepted, double *e_before, double *e_after, double timestep, double *dt_chain,
-    int64_t C, int64_t D, int32_t nsteps, double k, double x0, int32_t adapt, double uprate,
-    double downrate, int32_t mode, void *workspace, int64_t workspace_bytes, void *stream)
+template <bool REG, int RNG>
+static void big_launch_traj(const BigArgs &a, bool unit, bool fma, dim3 grid, hipStream_t st)
 {
-    const char *what = "hmc_sample_gauss_big";
-    if (C < 0 || D < 1 || nsteps < 1) return fail(BINF_E_ARG, "%s: need C>=0, D>=1, nsteps>=1", what);
-    if (mode != BINF_MODE_EXACT && mode != BINF_MODE_FMA)
-        return fail(BINF_E_ARG, "%s: unknown mode %d", what, mode);
-    if (C == 0) return 0;
-    if (!q0 || !p0 || !u || !q_out || !accepted) return fail(BINF_E_ARG, "%s: null buffer", what);
-    if (adapt && !dt_chain) return fail(BINF_E_ARG, "%s: adaption needs dt_chain", what);
-    if (C > 0x7fffffffffffffffLL / D) return fail(BINF_E_ARG, "%s: C*D overflows", what);
-    const int64_t bytes = C * D * (int64_t)sizeof(double);
-    const char *qo = (const char *)q_out, *qi = (const char *)q0, *pi = (const char *)p0;
-    if ((qo < qi + bytes && qi < qo + bytes) || (qo < pi + bytes && pi < qo + bytes))
-        return fail(BINF_E_ALIAS, "%s: q_out must not overlap q0 or p0 (rejected chains are "
-                    "restored from q0)", what);
-    const int64_t need = binf_hmc_sample_gauss_big_workspace_bytes(C, D);
-    if (!workspace || workspace_bytes < need)
-        return fail(BINF_E_ARG, "%s: needs %lld bytes of workspace, got %lld", what,
-                    (long long)need, (long long)workspace_bytes);
+    if (RNG == BIG_RNG_DUMP) {
+        hmc_gauss_big_traj_kernel<true, false, REG, RNG><<<grid, 256, 0, st>>>(a);
+    } else if (unit) {
+        if (fma) hmc_gauss_big_traj_kernel<true, true, REG, RNG><<<grid, 256, 0, st>>>(a);
+        else     hmc_gauss_big_traj_kernel<true, false, REG, RNG><<<grid, 256, 0, st>>>(a);
+    } else {
+        if (fma) hmc_gauss_big_traj_kernel<false, true, REG, RNG><<<grid, 256, 0, st>>>(a);
+        else     hmc_gauss_big_traj_kernel<false, false, REG, RNG><<<grid, 256, 0, st>>>(a);
+    }
+}
+
+// The three launches (trajectory per chunk, finish per chain, restore) for one of
+// the draw sources: RNG = 0 draws read from p0 / u; 1 generated in the kernels
+// under (seed, offset); 2 only written to p_dump / u_dump.
+template <int RNG>
+static int32_t big_run(const char *what, const double *q0, const double *p0, const double *u,
+                       double *q_out, uint8_t *accepted, int64_t *n_accepted, double *e_before,
+                       double *e_after, double timestep, double *dt_chain, int64_t C, int64_t D,
+                       int32_t nsteps, double k, double x0, int32_t adapt, double uprate,
+                       double downrate, int32_t mode, void *workspace, uint64_t seed,
+                       uint64_t offset, double *p_dump, double *u_dump, hipStream_t st)
+{
     BigArgs a;
     a.q0 = q0; a.p0 = p0; a.q_out = q_out; a.ws = (double *)workspace; a.dt_chain = dt_chain;
     a.timestep = timestep; a.k = k; a.x0 = x0; a.C = C; a.D = D; a.nchunks = big_chunks(D);
-    a.nsteps = nsteps;
+    a.nsteps = nsteps; a.rng_seed = seed; a.rng_offset = offset; a.p_dump = p_dump;
     const int32_t nfull = (int32_t)(D / NPY_BUFSIZE);
     const int32_t ntail = (D % NPY_BUFSIZE) ? 1 : 0;
     if (C * (int64_t)(nfull > 0 ? nfull : 1) > 0x7fffffffLL)
         return fail(BINF_E_UNSUPPORTED, "%s: too many (chain, chunk) pairs", what);
-    hipStream_t st = (hipStream_t)stream;
     const bool unit = (k == 1.0 && x0 == 0.0), fma = (mode == BINF_MODE_FMA);
     hipError_t e;
     if (nfull > 0) {
         a.H = 6; a.chunk0 = 0; a.chunks_here = nfull;
-        const dim3 grid((unsigned)(C * nfull));
-        if (unit) {
-            if (fma) hmc_gauss_big_traj_kernel<true, true, true><<<grid, 256, 0, st>>>(a);
-            else     hmc_gauss_big_traj_kernel<true, false, true><<<grid, 256, 0, st>>>(a);
-        } else {
-            if (fma) hmc_gauss_big_traj_kernel<false, true, true><<<grid, 256, 0, st>>>(a);
-            else     hmc_gauss_big_traj_kernel<false, false, true><<<grid, 256, 0, st>>>(a);
-        }
+        big_launch_traj<true, RNG>(a, unit, fma, dim3((unsigned)(C * nfull)), st);
         e = hipGetLastError();
         if (e != hipSuccess) return hip_fail(e, "hmc_gauss_big_traj_kernel launch");
     }
@@ -350,25 +395,21 @@ extern "C" int32_t binf_hmc_sample_gauss_big_f64(
         a.H = pairwise_tree_height(D % NPY_BUFSIZE);
         if (a.H > 7) return fail(BINF_E_UNSUPPORTED, "%s: pairwise tree height %d", what, a.H);
         a.chunk0 = nfull; a.chunks_here = 1;
-        const dim3 grid((unsigned)C);
-        if (unit) {
-            if (fma) hmc_gauss_big_traj_kernel<true, true, false><<<grid, 256, 0, st>>>(a);
-            else     hmc_gauss_big_traj_kernel<true, false, false><<<grid, 256, 0, st>>>(a);
-        } else {
-            if (fma) hmc_gauss_big_traj_kernel<false, true, false><<<grid, 256, 0, st>>>(a);
-            else     hmc_gauss_big_traj_kernel<false, false, false><<<grid, 256, 0, st>>>(a);
-        }
+        big_launch_traj<false, RNG>(a, unit, fma, dim3((unsigned)C), st);
         e = hipGetLastError();
         if (e != hipSuccess) return hip_fail(e, "hmc_gauss_big_traj_kernel (tail chunk) launch");
     }
     BigFinishArgs f;
-    f.ws = (const double *)workspace; f.u = u; f.accepted = accepted; f.n_accepted = n_accepted;
+    f.ws = (RNG == BIG_RNG_DUMP) ? nullptr : (const double *)workspace;
+    f.u = (RNG == BIG_RNG_HBM) ? u : nullptr; f.u_dump = u_dump; f.rng_seed = seed;
+    f.rng_offset = offset; f.accepted = accepted; f.n_accepted = n_accepted;
     f.e_before = e_before; f.e_after = e_after; f.dt_chain = dt_chain; f.k = k;
     f.uprate = uprate; f.downrate = downrate; f.C = C; f.nchunks = a.nchunks;
     f.adapt = adapt ? 1 : 0;
     hmc_gauss_big_finish_kernel<<<dim3((unsigned)((C + 255) / 256)), 256, 0, st>>>(f);
     e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "hmc_gauss_big_finish_kernel launch");
+    if (RNG == BIG_RNG_DUMP) return 0;
     const bool vec2 = (D % 2 == 0) && ((((uintptr_t)q_out | (uintptr_t)q0) & 15) == 0);
     const int32_t segs = (int32_t)((D + RESTORE_SEG - 1) / RESTORE_SEG);
     if (C * segs > 0x7fffffffLL) return fail(BINF_E_UNSUPPORTED, "%s: too many segments", what);
@@ -378,4 +419,80 @@ extern "C" int32_t binf_hmc_sample_gauss_big_f64(
     e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "restore_rejected_kernel launch");
     return 0;
+}
+
+static int32_t big_check(const char *what, const double *q0, const double *p0, double *q_out,
+                         const uint8_t *accepted, double *dt_chain, int64_t C, int64_t D,
+                         int32_t nsteps, int32_t adapt, int32_t mode, const void *workspace,
+                         int64_t workspace_bytes)
+{
+    if (C < 0 || D < 1 || nsteps < 1) return fail(BINF_E_ARG, "%s: need C>=0, D>=1, nsteps>=1", what);
+    if (mode != BINF_MODE_EXACT && mode != BINF_MODE_FMA)
+        return fail(BINF_E_ARG, "%s: unknown mode %d", what, mode);
+    if (C == 0) return 0;
+    if (!q0 || !q_out || !accepted) return fail(BINF_E_ARG, "%s: null buffer", what);
+    if (adapt && !dt_chain) return fail(BINF_E_ARG, "%s: adaption needs dt_chain", what);
+    if (C > 0x7fffffffffffffffLL / D) return fail(BINF_E_ARG, "%s: C*D overflows", what);
+    const int64_t bytes = C * D * (int64_t)sizeof(double);
+    const char *qo = (const char *)q_out, *qi = (const char *)q0, *pi = (const char *)p0;
+    if ((qo < qi + bytes && qi < qo + bytes) || (pi && qo < pi + bytes && pi < qo + bytes))
+        return fail(BINF_E_ALIAS, "%s: q_out must not overlap q0 or p0 (rejected chains are "
+                    "restored from q0)", what);
+    const int64_t need = binf_hmc_sample_gauss_big_workspace_bytes(C, D);
+    if (!workspace || workspace_bytes < need)
+        return fail(BINF_E_ARG, "%s: needs %lld bytes of workspace, got %lld", what,
+                    (long long)need, (long long)workspace_bytes);
+    return 0;
+}
+
+extern "C" int32_t binf_hmc_sample_gauss_big_f64(
+    const double *q0, const double *p0, const double *u, double *q_out, uint8_t *accepted,
+    int64_t *n_accepted, double *e_before, double *e_after, double timestep, double *dt_chain,
+    int64_t C, int64_t D, int32_t nsteps, double k, double x0, int32_t adapt, double uprate,
+    double downrate, int32_t mode, void *workspace, int64_t workspace_bytes, void *stream)
+{
+    const char *what = "hmc_sample_gauss_big";
+    if (C > 0 && D >= 1 && nsteps >= 1 && (!p0 || !u)) return fail(BINF_E_ARG, "%s: null buffer", what);
+    if (int32_t rc = big_check(what, q0, p0, q_out, accepted, dt_chain, C, D, nsteps, adapt, mode,
+                               workspace, workspace_bytes)) return rc;
+    if (C == 0) return 0;
+    return big_run<BIG_RNG_HBM>(what, q0, p0, u, q_out, accepted, n_accepted, e_before, e_after,
+                                timestep, dt_chain, C, D, nsteps, k, x0, adapt, uprate, downrate,
+                                mode, workspace, 0, 0, nullptr, nullptr, (hipStream_t)stream);
+}
+
+// The same transition with its draws generated inside the kernels (momentum: one
+// xoshiro128++ stream per lane and (chain, chunk); acceptance draw: one per chain
+// in the finish kernel), keyed by (seed, offset): no momentum buffer.
+extern "C" int32_t binf_hmc_sample_gauss_big_rng_f64(
+    const double *q0, double *q_out, uint8_t *accepted, int64_t *n_accepted, double *e_before,
+    double *e_after, double timestep, double *dt_chain, int64_t C, int64_t D, int32_t nsteps,
+    double k, double x0, int32_t adapt, double uprate, double downrate, int32_t mode,
+    uint64_t seed, uint64_t offset, void *workspace, int64_t workspace_bytes, void *stream)
+{
+    const char *what = "hmc_sample_gauss_big_rng";
+    if (int32_t rc = big_check(what, q0, nullptr, q_out, accepted, dt_chain, C, D, nsteps, adapt,
+                               mode, workspace, workspace_bytes)) return rc;
+    if (C == 0) return 0;
+    return big_run<BIG_RNG_FUSED>(what, q0, nullptr, nullptr, q_out, accepted, n_accepted, e_before,
+                                  e_after, timestep, dt_chain, C, D, nsteps, k, x0, adapt, uprate,
+                                  downrate, mode, workspace, seed, offset, nullptr, nullptr,
+                                  (hipStream_t)stream);
+}
+
+// The draws binf_hmc_sample_gauss_big_rng_f64 consumes for (seed, offset, C, D),
+// written out: p0_out [C*D], u_out [C].
+extern "C" int32_t binf_hmc_gauss_big_rng_draws_f64(double *p0_out, double *u_out, int64_t C,
+                                                    int64_t D, uint64_t seed, uint64_t offset,
+                                                    void *stream)
+{
+    const char *what = "hmc_gauss_big_rng_draws";
+    if (C < 0 || D < 1) return fail(BINF_E_ARG, "%s: need C>=0, D>=1", what);
+    if (C == 0) return 0;
+    if (!p0_out || !u_out) return fail(BINF_E_ARG, "%s: null buffer", what);
+    if (C > 0x7fffffffffffffffLL / D) return fail(BINF_E_ARG, "%s: C*D overflows", what);
+    return big_run<BIG_RNG_DUMP>(what, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                 nullptr, 0.0, nullptr, C, D, 1, 1.0, 0.0, 0, 1.0, 1.0,
+                                 BINF_MODE_EXACT, nullptr, seed, offset, p0_out, u_out,
+                                 (hipStream_t)stream);
 }

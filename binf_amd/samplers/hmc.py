@@ -128,7 +128,9 @@ class HMCSampler(object):
         dev = q0.device
         if p0 is None and u is None and self._fused_rng(name, D, C):
             # the draws are generated inside the sampling kernel
-            return self._sample_n_fused_rng(1)
+            if _native.gauss_persist_covers(D):
+                return self._sample_n_fused_rng(1)
+            return self._sample_long_fused_rng(name, q0, shape)
         if p0 is None:
             p0 = self.rng.normal((C, D), dev)
             own_p = True
@@ -190,7 +192,8 @@ class HMCSampler(object):
         C, D = q0.shape
         dev = q0.device
         nrec = n // thin
-        fused_rng = p0 is None and u is None and self._fused_rng(name, D, C)
+        fused_rng = p0 is None and u is None and self._fused_rng(name, D, C) and \
+            _native.gauss_persist_covers(D)
         if not fused_rng:
             if p0 is None:
                 p0 = self.rng.normal((n, C, D), dev)
@@ -279,11 +282,42 @@ class HMCSampler(object):
         if not getattr(self.rng, 'fused', False):
             return False
         spec = self._fused_spec(name, D)
-        if spec is None or spec[0] != 'gauss' or not _native.fused_rng_covers(D):
+        if spec is None or spec[0] != 'gauss':
             return False
+        if not _native.gauss_persist_covers(D):
+            return True                # long chains: hmc_gauss_big.hip draws its own as well
         if getattr(self.rng, 'fused', False) == 'always' or C is None:
             return True
         return D > 1024 or _native.gauss_waves_per_chain(C, D) < 4
+
+    def _sample_long_fused_rng(self, name, q0, shape):
+        """sample() for chains beyond the persistent kernel's reach with the
+        draws generated in the kernels (csrc/hmc_gauss_big.hip)."""
+        _, k, x0 = self._fused_spec(name, q0.shape[1])
+        C = q0.shape[0]
+        dev = q0.device
+        adapt = (self.counter + 1) < self.timestep_adaption_limit
+        if adapt and self._dt_chain is None:
+            self._dt_chain = torch.full((C,), float(self._timestep), dtype=torch.float64,
+                                        device=dev)
+        if not isinstance(self.n_accepted, torch.Tensor):
+            self.n_accepted = torch.zeros(C, dtype=torch.int64, device=dev)
+        accepted = torch.empty(C, dtype=torch.uint8, device=dev)
+        q_out = torch.empty_like(q0)
+        eb = ea = None
+        if self.record_energies:
+            eb = torch.empty(C, dtype=torch.float64, device=dev)
+            ea = torch.empty(C, dtype=torch.float64, device=dev)
+        _native.hmc_sample_gauss_big_rng(q0, q_out, accepted, self.n_accepted, eb, ea,
+                                         self._timestep, self._dt_chain, self.nsteps, k, x0,
+                                         adapt, self.adaption_uprate, self.adaption_downrate,
+                                         _MODES[self.mode], self.rng.seed,
+                                         self.rng.next_offset())
+        self.last_e_before, self.last_e_after = eb, ea
+        self._last_move_accepted = accepted.view(torch.bool)
+        self.counter += 1
+        self.state = q_out.view(shape)
+        return self.state
 
     def _sample_n_fused_rng(self, n):
         """sample() with in-kernel draws: one transition, the new state."""

@@ -148,6 +148,27 @@ int32_t binf_hmc_sample_gauss_big_f64(const double *q0, const double *p0,
                                       int32_t mode, void *workspace,
                                       int64_t workspace_bytes, void *stream);
 
+/* The long-chain transition with its draws generated inside the kernels (one
+ * xoshiro128++ stream per lane and (chain, 8192-chunk) for the momentum, one per
+ * chain for the acceptance draw; keyed by (seed, offset), a caller advances
+ * offset by one per call): binf_hmc_sample_gauss_big_f64 without p0 / u.
+ * binf_hmc_gauss_big_rng_draws_f64 writes those draws out instead (p0_out [C*D],
+ * u_out [C]); feeding them to binf_hmc_sample_gauss_big_f64 reproduces the fused
+ * call bit for bit. */
+int32_t binf_hmc_sample_gauss_big_rng_f64(const double *q0, double *q_out,
+                                          uint8_t *accepted, int64_t *n_accepted,
+                                          double *e_before, double *e_after,
+                                          double timestep, double *dt_chain,
+                                          int64_t C, int64_t D, int32_t nsteps,
+                                          double k, double x0, int32_t adapt,
+                                          double uprate, double downrate,
+                                          int32_t mode, uint64_t seed,
+                                          uint64_t offset, void *workspace,
+                                          int64_t workspace_bytes, void *stream);
+int32_t binf_hmc_gauss_big_rng_draws_f64(double *p0_out, double *u_out, int64_t C,
+                                         int64_t D, uint64_t seed, uint64_t offset,
+                                         void *stream);
+
 /* ------------------------------------------------------------------------
  * The same n transitions with the random draws generated INSIDE the kernel:
  * HMCSampler.sample() as the reference defines it, np.random.normal(size=

@@ -80,11 +80,11 @@ for case in range(n_cases):
         ok &= np.array_equal(g.last_e_after.cpu().numpy(), w['e_after'])
         ok &= np.array_equal(g.last_move_accepted.cpu().numpy(), w['accepted'].astype(bool))
     # draws generated in the kernel == sampling from the dump of the same stream
-    if _native.fused_rng_covers(D) and rs.rand() < 0.4:
+    if _native.gauss_persist_covers(D) and rs.rand() < 0.4:
         seed, mode = int(rs.randint(1 << 30)), ('exact' if rs.rand() < 0.7 else 'fma')
         kw = dict(timestep_adaption_limit=limit, variable_name='x', mode=mode, record_energies=True)
         a = HMCSampler(IsotropicGaussian(k, x0), torch.from_numpy(q0).to(dev), dt, L,
-                       rng=DeviceRNG(seed, dev), **kw)
+                       rng=DeviceRNG(seed, dev, fused='always'), **kw)
         ra = a.sample_n(n, thin=thin)
         pd, ud = _native.hmc_gauss_rng_draws(n, C, D, seed, 0, dev)
         b = HMCSampler(IsotropicGaussian(k, x0), torch.from_numpy(q0).to(dev), dt, L, **kw)

@@ -279,11 +279,11 @@ def test_fused_generator_stream_properties(device):
 def test_fused_generator_limits_and_fallback(device):
     z = torch.zeros((3, 9000), dtype=torch.float64, device=device)
     with pytest.raises(NotImplementedError):
-        _native.hmc_gauss_rng_draws(1, 3, 9000, 0, 0, device)
-    # longer chains: DeviceRNG falls back to the stand-alone generator kernels
+        _native.hmc_gauss_rng_draws(1, 3, 9000, 0, 0, device)      # the persistent kernel's entry
+    # longer chains draw inside the chunked kernels (test below)
     s = HMCSampler(IsotropicGaussian(), z, 0.02, 3, variable_name='x', rng=DeviceRNG(1, device))
-    assert not s._fused_rng('x', 9000)
-    assert s.sample_n(2).shape == (2, 3, 9000)
+    assert s._fused_rng('x', 9000, 3)
+    assert s.sample_n(2).shape == (2, 3, 9000) and s.rng.offset == 2
     # few chains of D = 1024: a chain is spread over 4 waves with draws from HBM, which beats
     # the one-wave kernel with its own generator -> stand-alone generator kernels
     for C, want in ((64, False), (1024, False), (1025, True), (2100, True), (5000, True)):
@@ -299,3 +299,42 @@ def test_fused_generator_limits_and_fallback(device):
                    rng=DeviceRNG(1, device, fused=False))
     assert not s._fused_rng('x', 64)
     assert s.sample().shape == (3, 64)
+
+
+@pytest.mark.parametrize('C,D,L,k,x0,mode,adapt', [
+    (3, 8193, 2, 1.0, 0.0, 'exact', False), (5, 20000, 3, 2.5, 0.3, 'exact', True),
+    (2, 16384, 2, 1.0, 0.0, 'fma', False), (4, 7689, 2, 1.0, 0.0, 'exact', True),
+    (70, 8192 * 2 + 5, 1, 1.0, -0.1, 'exact', False)])
+def test_long_chain_generator_equals_sampling_from_its_own_dump(device, C, D, L, k, x0, mode, adapt):
+    """Chains beyond the persistent kernel (csrc/hmc_gauss_big.hip) with the draws
+    generated in the kernels == the same kernels fed with the dump of that stream,
+    bit for bit, over consecutive calls (one stream position per call)."""
+    seed = 1234
+    q0 = torch.from_numpy(np.random.RandomState(D).standard_normal((C, D))).to(device)
+    dt = 0.9 / np.sqrt(k * D)
+    kw = dict(timestep_adaption_limit=5 if adapt else 0, variable_name='x', mode=mode,
+              record_energies=True)
+    a = HMCSampler(IsotropicGaussian(k, x0), q0, dt, L, rng=DeviceRNG(seed, device), **kw)
+    b = HMCSampler(IsotropicGaussian(k, x0), q0, dt, L, **kw)
+    assert a._fused_rng('x', D, C) and not _native.gauss_persist_covers(D)
+    for call in range(3):
+        xa = a.sample()
+        p0, u = _native.hmc_gauss_big_rng_draws(C, D, seed, call, device)
+        xb = b.sample(p0=p0, u=u)
+        assert torch.equal(xa, xb), call
+        assert torch.equal(a.last_move_accepted, b.last_move_accepted)
+        assert torch.equal(a.last_e_before, b.last_e_before)
+        assert torch.equal(a.last_e_after, b.last_e_after)
+        if adapt:
+            assert torch.equal(a.timestep, b.timestep)
+    assert a.rng.offset == 3 and torch.equal(a.n_accepted, b.n_accepted)
+    # the dump: every element written, plausible, independent of the batch size
+    p0, u = _native.hmc_gauss_big_rng_draws(C, D, seed, 7, device)
+    p1, u1 = _native.hmc_gauss_big_rng_draws(min(C, 2), D, seed, 7, device)
+    assert torch.equal(p0[:min(C, 2)], p1) and torch.equal(u[:min(C, 2)], u1)
+    z = p0.cpu().numpy()
+    assert np.isfinite(z).all() and np.abs(z).max() < 7.5
+    if z.size > 50000:
+        assert abs(z.mean()) < 5 / np.sqrt(z.size) and abs(z.var() - 1.0) < 8 / np.sqrt(z.size)
+    uu = u.cpu().numpy()
+    assert (0.0 <= uu).all() and (uu < 1.0).all()
