@@ -194,14 +194,24 @@ class HMCSampler(object):
         nrec = n // thin
         fused_rng = p0 is None and u is None and self._fused_rng(name, D, C) and \
             _native.gauss_persist_covers(D)
-        if not fused_rng:
-            if p0 is None:
-                p0 = self.rng.normal((n, C, D), dev)
-            if u is None:
-                u = self.rng.uniform(n * C, dev)
-            p0 = p0.reshape(n, C, D)
-            u = u.reshape(n, C)
         spec = self._fused_spec(name, D)
+        persist = spec is not None and spec[0] == 'gauss' and _native.gauss_persist_covers(D)
+        if persist and not fused_rng and (p0 is None or u is None):
+            # the draws of n sample() calls in the order those calls consume the
+            # generator: normal, uniform, normal, uniform, ... (hmc.py:146,151)
+            dp = torch.empty((n, C, D), dtype=torch.float64, device=dev) if p0 is None else None
+            du = torch.empty((n, C), dtype=torch.float64, device=dev) if u is None else None
+            for i in range(n):
+                if dp is not None:
+                    _fill(self.rng, 'normal', dp[i])
+                if du is not None:
+                    _fill(self.rng, 'uniform', du[i])
+            p0 = dp if p0 is None else p0
+            u = du if u is None else u
+        if p0 is not None:
+            p0 = p0.reshape(n, C, D)
+        if u is not None:
+            u = u.reshape(n, C)
         if out is not None:
             if not record or nrec < 1:
                 raise ValueError('sample_n: out= given but nothing is recorded')
@@ -209,10 +219,12 @@ class HMCSampler(object):
                     not out.is_contiguous() or out.numel() != nrec * C * D:
                 raise ValueError('sample_n: out must be a contiguous fp64 [%d, %d, %d] '
                                  'tensor on %s' % (nrec, C, D, dev))
-        if spec is None or spec[0] != 'gauss' or not _native.gauss_persist_covers(D):
+        if not persist:
+            # no persistent kernel for this PDF / shape: n single calls (each draws for
+            # itself when no draws were supplied)
             rec, flags, ebs, eas = [], [], [], []
             for i in range(n):
-                x = self.sample(p0=p0[i], u=u[i])
+                x = self.sample(p0=None if p0 is None else p0[i], u=None if u is None else u[i])
                 if record and (i + 1) % thin == 0:
                     rec.append(x)
                 flags.append(self._last_move_accepted)
@@ -441,6 +453,18 @@ class HMCSampler(object):
                               self.adaption_uprate, self.adaption_downrate)
         self.last_e_before, self.last_e_after = e_before, e_after
         return q
+
+
+def _fill(rng, kind, out):
+    """One draw of ``rng`` into the contiguous buffer ``out`` (generators without
+    fill_* methods: draw, then copy)."""
+    fill = getattr(rng, 'fill_' + kind, None)
+    if fill is not None:
+        fill(out)
+    elif kind == 'normal':
+        out.copy_(rng.normal(tuple(out.shape), out.device))
+    else:
+        out.copy_(rng.uniform(out.numel(), out.device).reshape(out.shape))
 
 
 def _native_poly_limits():

@@ -22,6 +22,12 @@ class HostLegacyRNG(object):
     def uniform(self, n, device):
         return torch.from_numpy(np.random.uniform(size=int(n))).to(device)
 
+    def fill_normal(self, out):
+        out.copy_(torch.from_numpy(np.random.normal(size=tuple(out.shape))))
+
+    def fill_uniform(self, out):
+        out.copy_(torch.from_numpy(np.random.uniform(size=out.numel())).reshape(out.shape))
+
 
 class DeviceRNG(object):
     """Throughput source: draws generated in HBM by the library's Philox
@@ -60,6 +66,17 @@ class DeviceRNG(object):
 
     def normal(self, shape, device):
         return self._fill(self._normal_kind, shape, device, 1)
+
+    def fill_normal(self, out):
+        """normal() into a caller's contiguous buffer (same stream position rules)."""
+        from binf_amd import _native
+        _native.rng_fill(self._normal_kind, out, self.seed, self.offset)
+        self.offset += 1
+
+    def fill_uniform(self, out):
+        from binf_amd import _native
+        _native.rng_fill('uniform', out, self.seed, self.offset)
+        self.offset += 1
 
     def uniform(self, n, device):
         return self._fill('uniform', (int(n),), device, 1)

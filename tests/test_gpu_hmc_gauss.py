@@ -628,3 +628,33 @@ def test_long_chains_sample_n_fma_and_errors(device):
     assert lib.binf_hmc_sample_gauss_big_f64(*args(out.data_ptr(), need)) == 0
     torch.cuda.synchronize()
     assert torch.equal(out, rec[0])
+
+
+@pytest.mark.parametrize('C,D', [(1, 33), (5, 1024), (3, 9000)])
+def test_sample_n_consumes_the_generator_like_n_sample_calls(device, C, D):
+    """Without supplied draws sample_n(n) takes them from the sampler's generator
+    in the order n sample() calls would (hmc.py:146,151: normal, uniform, normal,
+    uniform ...): the same global numpy stream position afterwards and the same
+    states, for the persistent kernel, the long-chain path, one chain as a [D] array;
+    likewise for the stand-alone device generator."""
+    from binf_amd.samplers.rng import DeviceRNG
+    q0 = np.random.RandomState(D).standard_normal((C, D))
+    state = dev_t(q0[0] if C == 1 else q0, device)
+    np.random.seed(77)
+    a = HMCSampler(IsotropicGaussian(), state, 0.1 / np.sqrt(D / 33.0), 3, variable_name='x')
+    rec = a.sample_n(3)
+    after_a = np.random.uniform()
+    np.random.seed(77)
+    b = HMCSampler(IsotropicGaussian(), state, 0.1 / np.sqrt(D / 33.0), 3, variable_name='x')
+    for i in range(3):
+        assert torch.equal(b.sample(), rec[i]), i
+    assert np.random.uniform() == after_a
+    assert rec.shape == (3,) + tuple(state.shape)
+    a = HMCSampler(IsotropicGaussian(), state, 0.1, 2, variable_name='x',
+                   rng=DeviceRNG(5, device, fused=False))
+    b = HMCSampler(IsotropicGaussian(), state, 0.1, 2, variable_name='x',
+                   rng=DeviceRNG(5, device, fused=False))
+    rec = a.sample_n(4, thin=2)
+    xs = [b.sample() for _ in range(4)]
+    assert torch.equal(rec[0], xs[1]) and torch.equal(rec[1], xs[3])
+    assert a.rng.offset == b.rng.offset == 8
