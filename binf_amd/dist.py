@@ -41,17 +41,33 @@ def shard_chains(n_chains, rank=None, world_size=None):
     return start, count
 
 
-def gather_chains(local, n_chains_total=None, group=None):
+class PendingGather(object):
+    """An all-gather in flight (``gather_chains(..., async_op=True)``): the
+    collective runs on the backend's own stream (RCCL: beside the sampling
+    kernels on xGMI), ``wait()`` returns the gathered tensor."""
+
+    def __init__(self, work, out, finish):
+        self._work, self._out, self._finish = work, out, finish
+
+    def wait(self):
+        if self._work is not None:
+            self._work.wait()
+            self._work = None
+        return self._finish(self._out)
+
+
+def gather_chains(local, n_chains_total=None, group=None, async_op=False):
     """All-gather a per-chain tensor along dim 0 (chains).  ``local`` is
     ``[C_local, ...]``; returns ``[C_total, ...]`` on every rank, rows in
     global chain order.  Uneven shards (see :func:`shard_chains`) are padded to
-    the largest shard for the collective and trimmed afterwards."""
+    the largest shard for the collective and trimmed afterwards.
+
+    ``async_op=True`` returns a :class:`PendingGather` at once: sampling can go on
+    while the collective runs (do not overwrite ``local`` before ``wait()``)."""
     dist = _dist()
-    if not (dist.is_available() and dist.is_initialized()):
-        return local
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return PendingGather(None, local, lambda t: t) if async_op else local
     ws = dist.get_world_size(group)
-    if ws == 1:
-        return local
     c_local = local.shape[0]
     if n_chains_total is None:
         counts = [c_local] * ws
@@ -74,11 +90,15 @@ def gather_chains(local, n_chains_total=None, group=None):
         send = torch.cat([send, pad], dim=0)
     out = torch.empty((ws * cmax,) + tuple(local.shape[1:]), dtype=local.dtype,
                       device=local.device)
+    def finish(t):
+        if all(c == cmax for c in counts):
+            return t
+        return torch.cat([t[r * cmax:r * cmax + counts[r]] for r in range(ws)], dim=0)
+    if async_op:
+        return PendingGather(dist.all_gather_into_tensor(out, send, group=group, async_op=True),
+                             out, finish)
     dist.all_gather_into_tensor(out, send, group=group)
-    if all(c == cmax for c in counts):
-        return out
-    parts = [out[r * cmax:r * cmax + counts[r]] for r in range(ws)]
-    return torch.cat(parts, dim=0)
+    return finish(out)
 
 
 class SampleStore(object):
@@ -117,11 +137,18 @@ class SampleStore(object):
     def local(self):
         return self.buffer[:self.n_kept]
 
-    def gather(self, n_chains_total=None, group=None):
+    def gather(self, n_chains_total=None, group=None, async_op=False):
+        """``[n_kept, C_total, D]`` on every rank; with ``async_op=True`` a
+        :class:`PendingGather` (the store may keep recording into its later slots
+        meanwhile: the draws kept so far were copied out for the collective)."""
         kept = self.local()
+        back = lambda g: g.transpose(0, 1).contiguous()
         if kept.shape[0] == 0:
-            return kept
+            return PendingGather(None, kept, lambda t: t) if async_op else kept
         # chains to dim 0 for the collective, back afterwards
-        g = gather_chains(kept.transpose(0, 1).contiguous(), n_chains_total,
-                          group)
-        return g.transpose(0, 1).contiguous()
+        g = gather_chains(kept.transpose(0, 1).contiguous(), n_chains_total, group,
+                          async_op=async_op)
+        if async_op:
+            inner = g
+            return PendingGather(None, None, lambda _t: back(inner.wait()))
+        return back(g)

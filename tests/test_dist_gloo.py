@@ -36,6 +36,7 @@ def test_sample_store_thins_and_burns_in_without_a_process_group():
     assert kept == [2, 5, 8, 11]
     assert st.local().shape == (4, 3, 2)
     assert st.gather().shape == (4, 3, 2)           # single process: identity
+    assert torch.equal(st.gather(async_op=True).wait(), st.local())
     assert [float(v) for v in st.local()[:, 0, 0]] == [2.0, 5.0, 8.0, 11.0]
     with pytest.raises(IndexError):
         for i in range(3):
@@ -73,6 +74,18 @@ def _worker(rank, ws, port, n_total, n_dims, q):
         ok = ok and g.shape == (3, n_total, n_dims)
         for k, i in enumerate((0, 2, 4)):
             ok = ok and torch.equal(g[k], glob + 1000.0 * i)
+        # the same gathers in flight while "sampling" goes on (async_op): the store
+        # keeps recording into its later slots meanwhile
+        st2 = SampleStore(capacity=4, n_chains_local=count, n_dims=n_dims)
+        st2.record(local)
+        st2.record(local + 1000.0)
+        pend = st2.gather(n_total, async_op=True)
+        st2.record(local + 2000.0)                      # does not disturb the gather in flight
+        pend_flags = gather_chains((local[:, 0] % 2 == 0).to(torch.uint8), n_total, async_op=True)
+        g2 = pend.wait()
+        ok = ok and g2.shape == (2, n_total, n_dims) and torch.equal(g2[1], glob + 1000.0)
+        ok = ok and torch.equal(pend_flags.wait(), (glob[:, 0] % 2 == 0).to(torch.uint8))
+        ok = ok and st2.gather(n_total).shape == (3, n_total, n_dims)
         # max-over-ranks timing reduction used by bench.py
         t = torch.tensor([1.0 + rank], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
