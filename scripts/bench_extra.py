@@ -74,6 +74,33 @@ def c3_polynomial(dev, C=8192, K=33, N=16384, L=20):
             'acceptance': float(s.acceptance_rate.mean())}
 
 
+def c4_gibbs(dev, C=4096, K=33, N=16384, L=20):
+    """C4 per-GPU share (32768 chains over 8 GPUs): Gibbs-within-HMC, HMC on the
+    coefficients + the conjugate precision update, through the class stack."""
+    from binf_amd.example.likelihood import POLYVAL, make_likelihood
+    from binf_amd.example.priors import GammaPrior, GaussianPrior
+    from binf_amd.example.samplers import make_hmc_sampler
+    from binf_amd.pdf.posteriors import Posterior
+    from binf_amd.samplers import BinfState
+    from binf_amd.samplers.rng import DeviceRNG
+    xs = np.linspace(-1, 1, N)
+    c_true = np.random.RandomState(7).standard_normal(K)
+    ys = POLYVAL(xs, c_true) + np.random.RandomState(9).standard_normal(N) / np.sqrt(2.5)
+    q0 = torch.from_numpy(np.random.RandomState(8).standard_normal((C, K))).to(dev)
+    lik = make_likelihood(xs, ys, POLYVAL)
+    post = Posterior({lik.name: lik},
+                     {'precision_prior': GammaPrior(1.0, 0.2),
+                      'coefficients_prior': GaussianPrior(np.zeros(K), np.ones(K) * 5)})
+    start = BinfState(dict(coefficients=q0,
+                           precision=torch.full((C,), 2.5, dtype=torch.float64, device=dev)))
+    grng = DeviceRNG(5, dev)
+    gips = make_hmc_sampler(post, 2e-4, L, start, rng=DeviceRNG(2, dev), gamma=grng.gamma)
+    t = _timed(gips.sample, 4, warm=2)
+    return {'workload': 'C4 share: Gibbs-within-HMC, polynomial K=%d, N=%d, %d chains (32768 / 8), '
+                        'L=%d' % (K, N, C, L),
+            'gibbs_sweep_ms': t * 1e3, 'chain_leapfrog_steps_per_s': C * L / t}
+
+
 def c5_distance(dev, C=256, n=256, L=20):
     """C5 per-GPU share: 3 x 256 coordinates, 256 chains (= 2048 / 8)."""
     from binf_amd.example.distance import make_distance_likelihood
@@ -158,7 +185,7 @@ def c2_strong_scaling_shares(dev, D=1024, L=20, F=64):
 
 def run_all(dev):
     res = {}
-    for name, fn in (('C3', c3_polynomial), ('C5', c5_distance),
+    for name, fn in (('C3', c3_polynomial), ('C4', c4_gibbs), ('C5', c5_distance),
                      ('C2_device_rng', c2_device_rng),
                      ('C2_strong_scaling_shares', c2_strong_scaling_shares)):
         try:
