@@ -726,3 +726,53 @@ def test_subclassed_models_are_evaluated_as_written_and_new_data_is_seen(device)
     fm.xses = xs * 0.5
     lp3 = plain.log_prob(coefficients=tc, precision=1.0).cpu().numpy()
     assert lp3[0] == -0.5 * np.sum((POLYVAL(xs * 0.5, theta[0]) - (ys + 1.0)) ** 2) * 1.0
+
+
+def test_c4_full_size_gibbs_sweep(device):
+    """BASELINE C4 at its per-GPU size (K = 33, N = 16384, 4096 chains = 32768 / 8):
+    two Gibbs sweeps (HMC with L = 20 on the coefficients, conjugate precision
+    update) through the class stack with injected draws; a sample of chains against
+    the single-chain numpy restatement inside the computed bounds, accept flags
+    identical, everything finite."""
+    K, N, C, L, dt, S = 33, 16384, 4096, 20, 2e-4, 2
+    xs, ys, _ = synth(K, N, 1, 7)
+    rs = np.random.RandomState(12)
+    c0 = 0.3 * rs.standard_normal((C, K))
+    tau0 = rs.uniform(1.5, 3.5, size=C)
+    p0 = rs.standard_normal((S, C, K))
+    u = rs.uniform(size=(S, C))
+    shape = R.gamma_shape(N, 1.0)
+    g = rs.gamma(shape, size=(S, C))
+    from binf_amd.pdf.likelihoods import Likelihood
+    from binf_amd.pdf.posteriors import Posterior
+    lik = Likelihood('points', ForwardModel(xs, POLYVAL), GaussianErrorModel(ys))
+    post = Posterior({lik.name: lik}, {'precision_prior': GammaPrior(1.0, 0.2),
+                                       'coefficients_prior': GaussianPrior(np.zeros(K), np.ones(K) * 5)})
+    start = BinfState(dict(coefficients=dev_t(c0, device), precision=dev_t(tau0, device)))
+    sweep = {'s': 0}
+    gips = make_hmc_sampler(post, dt, L, start, gamma=lambda sh, n, d: dev_t(g[sweep['s']], d))
+    hmc = gips.subsamplers['coefficients']
+    got = []
+    for s in range(S):
+        sweep['s'] = s
+        hmc.rng = type('Inject', (), {
+            'normal': staticmethod(lambda shp, d, s=s: dev_t(p0[s], d)),
+            'uniform': staticmethod(lambda n, d, s=s: dev_t(u[s], d))})()
+        st = gips.sample()
+        got.append((st.variables['coefficients'].cpu().numpy().copy(),
+                    st.variables['precision'].cpu().numpy().copy(),
+                    hmc.last_move_accepted.cpu().numpy().copy()))
+    for cs, ts, acc in got:
+        assert np.isfinite(cs).all() and np.isfinite(ts).all() and (ts > 0).all()
+    assert got[-1][2].mean() > 0.5
+    pb = PB.PolyBound(xs, ys, K, np.zeros(K), np.ones(K) * 5)
+    for c in (0, 4095):
+        ref = RE.gibbs_hmc_chain(xs, ys, c0[c], tau0[c], dt, L, p0[:, c], u[:, c], g[:, c])
+        bounds = PB.gibbs_bounds(pb, ref['coefficients'], ref['accepted'], p0[:, c],
+                                 ref['precision'], tau0[c], c0[c], dt, L,
+                                 RE.PRIOR_RATE_IN_CONDITIONALS)
+        for s in range(S):
+            assert bool(got[s][2][c]) == bool(ref['accepted'][s]), (c, s)
+            want = ref['coefficients'][s]
+            assert np.all(np.abs(got[s][0][c] - want) <= bounds[s]['bq'] + 4 * PB.U * np.abs(want)), (c, s)
+            assert abs(got[s][1][c] - ref['precision'][s]) <= bounds[s]['btau'] * ref['precision'][s], (c, s)
