@@ -25,38 +25,9 @@
 // tier computes it on the MFMA pipe, the reference with BLAS; summation order
 // is not reproducible there either -- so trajectories agree to ~1e-15
 // relative, not bitwise.
-#include "gauss_common.hpp"
+#include "hmc_poly_args.hpp"
 
 namespace binf {
-
-struct PolyHmcArgs {
-    const double *q0;          // [C x K]
-    const double *p0;          // [C x K]
-    const double *u;           // [C]
-    double *q_out;             // [C x K]
-    uint8_t *accepted;         // [C]
-    int64_t *n_accepted;       // [C] or null
-    double *e_before;          // [C] or null
-    double *e_after;           // [C] or null
-    const double *xs;          // [N]
-    const double *ys;          // [N]
-    const double *tau_chain;   // [C] or null
-    double tau;
-    const double *prior_means; // [K] or null: Gaussian prior on theta (energy only)
-    const double *prior_vars;  // [K]
-    const double *lp_pre;      // [C] or null: theta-independent log-prob terms added first
-    const double *lp_post;     // [C] or null: ... added last
-    double *dt_chain;          // [C] or null
-    double timestep;
-    double uprate;
-    double downrate;
-    int64_t C;
-    int32_t K;
-    int32_t N;
-    int32_t nsteps;
-    int32_t prior_first;
-    int32_t adapt;
-};
 
 // np.sum of the n <= 128 values f(0), f(1), ... evaluated in order by one lane
 // (n is wave-uniform): numpy's pairwise leaf, then the outer "0.0 +".
@@ -270,8 +241,8 @@ extern "C" int32_t binf_hmc_sample_poly_f64(
         return fail(BINF_E_ARG, "hmc_sample_poly: need C>=0, K>=1, N>=0, nsteps>=1");
     if (mode != BINF_MODE_EXACT && mode != BINF_MODE_FMA)
         return fail(BINF_E_ARG, "hmc_sample_poly: unknown mode %d", mode);
-    if (K > 16 || N > 128)
-        return fail(BINF_E_UNSUPPORTED, "hmc_sample_poly: K=%lld > 16 or n_data=%lld > 128 not covered by the fused kernel (use the per-step tier)", (long long)K, (long long)N);
+    if (K > 16 || N > 1024 || (N > 128 && pairwise_tree_height(N) > 3))
+        return fail(BINF_E_UNSUPPORTED, "hmc_sample_poly: K=%lld > 16 or n_data=%lld > 1024 (or a pairwise tree deeper than 3) not covered by the fused kernels (use the per-step tier)", (long long)K, (long long)N);
     if (C == 0) return 0;
     if (!q0 || !p0 || !u || !q_out || !accepted || (N > 0 && (!xs || !ys)))
         return fail(BINF_E_ARG, "hmc_sample_poly: null buffer");
@@ -296,6 +267,7 @@ extern "C" int32_t binf_hmc_sample_poly_f64(
     a.adapt = adapt ? 1 : 0;
     const bool fma = (mode == BINF_MODE_FMA);
     hipStream_t st = (hipStream_t)stream;
+    if (N > 128) return launch_poly_wave_from(a, fma, st);
     hipError_t e;
     if (K <= 4)      e = launch_poly<4>(a, fma, st);
     else if (K <= 8) e = launch_poly<8>(a, fma, st);

@@ -51,7 +51,7 @@ def gradient(likelihood, pair, fwm_vars, em_vars):
 
 
 FUSED_MAX_COEFFS = 16       # binf_hmc_sample_poly_f64 limits (include/binf_hip.h)
-FUSED_MAX_DATA = 128
+FUSED_MAX_DATA = 1024        # > 128: one wave per chain (csrc/hmc_poly_wave.hip)
 
 
 def posterior_hmc_spec(posterior, variable_name):
@@ -86,7 +86,9 @@ def posterior_hmc_spec(posterior, variable_name):
             kinds.append('prior')
         else:
             return None
-    if lik is None or len(lik.error_model.ys) > FUSED_MAX_DATA:
+    n_data = len(lik.error_model.ys) if lik is not None else 0
+    if lik is None or n_data > FUSED_MAX_DATA or \
+            (n_data > 128 and _native.pairwise_tree_height(n_data) > 3):
         return None
     theta = [i for i, k in enumerate(kinds) if k != 'c']
     n_pre, n_post = theta[0], len(kinds) - 1 - theta[-1]

@@ -148,7 +148,7 @@ class HMCSampler(object):
             self.n_accepted = torch.zeros(C, dtype=torch.int64, device=dev)
 
         accepted = torch.empty(C, dtype=torch.uint8, device=dev)
-        spec = self._fused_spec(name, D)
+        spec = self._fused_spec(name, D, C)
         if spec is not None and spec[0] == 'poly':
             q_out = self._sample_fused_poly(spec, q0, p0, u, accepted, adapt)
         elif spec is not None:
@@ -338,15 +338,23 @@ class HMCSampler(object):
             self.last_e_before, self.last_e_after = self.last_e_before[0], self.last_e_after[0]
         return self.state
 
-    def _fused_spec(self, name, D):
-        """The PDF's fused-kernel descriptor if the library covers this shape,
-        else None (generic per-step tier)."""
+    def _fused_spec(self, name, D, C=None):
+        """The PDF's fused-kernel descriptor if the library covers this shape
+        (and, for ``C`` chains, if the fused kernel is the faster choice), else
+        None (generic per-step tier)."""
         get_spec = getattr(self.pdf, 'native_hmc_spec', None)
         spec = get_spec(name) if get_spec is not None else None
         if spec is not None and spec[0] == 'gauss':
             return spec                # persistent kernel, or the chunked one for long chains
         if spec is not None and spec[0] == 'poly' and self.fused_polynomial and \
                 D <= _native_poly_limits()[0]:
+            n_data = len(spec[2].ys)
+            if n_data > 128 and C is not None and self.fused_polynomial != 'always' and \
+                    float(C) * n_data * D > _POLY_WAVE_MAX_WORK:
+                # one wave per chain wins while the batch is launch-bound (3-10x up to
+                # ~1e8 chain x data x coefficient products, scripts/probe_poly_wave.py);
+                # beyond that the MFMA gradient of the per-step tier is faster
+                return None
             return spec
         return None
 
@@ -453,6 +461,9 @@ class HMCSampler(object):
                               self.adaption_uprate, self.adaption_downrate)
         self.last_e_before, self.last_e_after = e_before, e_after
         return q
+
+
+_POLY_WAVE_MAX_WORK = 1.0e8    # chains x data points x coefficients (see _fused_spec)
 
 
 def _fill(rng, kind, out):

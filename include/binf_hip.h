@@ -324,9 +324,12 @@ int32_t binf_poly_gauss_grad_f64(const double *coeffs, const double *design,
                                  int64_t C, int64_t K, int64_t N, void *stream);
 
 /* One HMCSampler.sample() (binf/samplers/hmc.py:136-164,183-191) for every
- * chain on the example's polynomial posterior with a SMALL data set
- * (K <= 16 coefficients, N <= 128 data points; else BINF_E_UNSUPPORTED), the
- * whole transition in one launch (the per-step tier is launch-bound there):
+ * chain on the example's polynomial posterior with a SMALL or MEDIUM data set
+ * (K <= 16 coefficients; N <= 128 data points: one lane per chain; 128 < N <=
+ * 1024 with a pairwise tree of height <= 3 -- every N <= 920 and the multiples of
+ * 8 up to 1024: one wave per chain, the data spread over its lanes; else
+ * BINF_E_UNSUPPORTED), the whole transition in one launch (the per-step tier is
+ * launch-bound there):
  *   log p(theta) = [lp_pre] + {prior, likelihood in the order prior_first says} + [lp_post]
  *   likelihood = -0.5 * sum((polyval(xs, theta) - ys)**2) * precision + N/2 * log(precision)
  *                (binf/example/likelihood.py:24-26,54-57; precision per chain if

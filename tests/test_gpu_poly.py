@@ -250,7 +250,12 @@ def _small_posterior(xs, ys, K, prior, lik_name='points'):
     (8, 37, 130, 5, True, 'points', 'exact'),
     (9, 100, 6, 3, False, 'points', 'exact'),
     (13, 127, 4, 3, True, 'points', 'fma'),
-    (16, 128, 66, 2, True, 'points', 'exact')])
+    (16, 128, 66, 2, True, 'points', 'exact'),
+    # more than 128 data points: one wave per chain (csrc/hmc_poly_wave.hip)
+    (4, 129, 9, 5, True, 'points', 'exact'),
+    (8, 258, 70, 3, True, 'a_first', 'exact'),
+    (16, 700, 5, 2, False, 'points', 'fma'),
+    (3, 1024, 33, 4, True, 'points', 'exact')])
 def test_fused_small_polynomial_transition_vs_per_step_tier(device, K, N, C, L, prior,
                                                             lik_name, mode):
     """binf_hmc_sample_poly_f64 (one launch) against the per-step tier on the
@@ -328,7 +333,16 @@ class _SmallConditional(R.PolyCoefficientsConditional):
     (7, 8, 9, 4, True, 'points'),
     (8, 37, 130, 5, True, 'points'),
     (9, 100, 6, 3, False, 'points'),
-    (16, 128, 66, 2, True, 'points')])
+    (16, 128, 66, 2, True, 'points'),
+    # more than 128 data points: one wave per chain (csrc/hmc_poly_wave.hip); regular and
+    # ragged pairwise trees, several chains per wave, a partial last wave
+    (4, 129, 9, 5, True, 'points'),
+    (1, 200, 3, 3, False, 'points'),
+    (8, 258, 70, 3, True, 'a_first'),
+    (5, 512, 40, 4, True, 'points'),
+    (16, 700, 5, 2, False, 'points'),
+    (12, 1000, 17, 3, True, 'points'),
+    (3, 1024, 33, 4, True, 'points')])
 def test_fused_small_polynomial_transition_vs_oracle(device, K, N, C, L, prior, lik_name):
     """binf_hmc_sample_poly_f64 (one launch per transition) DIRECTLY against the
     numpy restatement -- RefHMCSampler on the coefficient conditional, one chain
@@ -387,10 +401,11 @@ def test_fused_small_polynomial_transition_vs_oracle(device, K, N, C, L, prior, 
 
 
 def test_fused_small_polynomial_limits_and_fallback(device):
-    """More than 128 data points or 16 coefficients: the sampler stays on the
-    per-step tier; the C entry point itself refuses."""
+    """More than 1024 data points (or a pairwise tree deeper than 3) or more than 16
+    coefficients: the sampler stays on the per-step tier; the C entry point itself
+    refuses."""
     rs = np.random.RandomState(0)
-    for K, N in ((4, 129), (17, 20)):
+    for K, N in ((4, 1025), (4, 1023), (17, 20)):
         xs = np.linspace(-1, 1, N)
         ys = rs.standard_normal(N)
         cond = _small_posterior(xs, ys, K, True).conditional_factory(precision=2.0)
@@ -405,6 +420,14 @@ def test_fused_small_polynomial_limits_and_fallback(device):
                                     None, None, None, dev_t(xs, device), dev_t(ys, device), 2.0,
                                     None, None, True, None, None, 1e-3, None, 2, False,
                                     1.05, 0.95)
+    # medium data sets: fused while the batch is launch-bound, per-step tier beyond
+    xs = np.linspace(-1, 1, 1024)
+    cond = _small_posterior(xs, rs.standard_normal(1024), 16, True).conditional_factory(precision=2.0)
+    s = HMCSampler(cond, dev_t(np.zeros((3, 16)), device), 1e-4, 2, variable_name='coefficients')
+    assert s._fused_spec('coefficients', 16, 1024) is not None
+    assert s._fused_spec('coefficients', 16, 8192) is None
+    s.fused_polynomial = 'always'
+    assert s._fused_spec('coefficients', 16, 8192) is not None
     # a posterior with another free variable is not the conditional the kernel integrates
     full = _small_posterior(np.linspace(-1, 1, 20), rs.standard_normal(20), 4, True)
     assert full.native_hmc_spec('coefficients') is None
