@@ -109,7 +109,8 @@ for case in range(n_cases):
 
     # ---- fused small polynomial transition -----------------------------------
     K = int(rs.randint(1, 17))
-    N = int(rs.randint(1, 129))
+    # one lane per chain up to 128 data points, one wave per chain up to 1024
+    N = int([rs.randint(1, 129), rs.randint(129, 921), 8 * rs.randint(17, 129)][rs.randint(3)])
     Cs = int(rs.choice([1, 5, 64, 65, 200]))
     xs = np.linspace(-1.5, 1.5, N)
     ysp = R.polyval(xs, rs.standard_normal(K)) + 0.5 * rs.standard_normal(N)
