@@ -103,7 +103,7 @@ __global__ void __launch_bounds__(256) hmc_poly_wave_kernel(const PolyHmcArgs a,
 
     auto log_prob = [&]() {
         LaneSum s = {0.0, 0.0};
-#pragma unroll 2
+#pragma unroll 4
         for (int t = 0; t < TMAX; ++t) {
             // polyval: Horner, zero-padded above K-1 (exact no-ops)
             const double x = sx[t][slot];
@@ -144,7 +144,7 @@ __global__ void __launch_bounds__(256) hmc_poly_wave_kernel(const PolyHmcArgs a,
     auto force = [&]() {
 #pragma unroll
         for (int k = 0; k < KMAX; ++k) g[k] = 0.0;
-#pragma unroll 2
+#pragma unroll 4
         for (int t = 0; t < TMAX; ++t) {
             const double x = sx[t][slot];
             double v = th[KMAX - 1];

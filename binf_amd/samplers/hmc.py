@@ -463,7 +463,7 @@ class HMCSampler(object):
         return q
 
 
-_POLY_WAVE_MAX_WORK = 1.0e8    # chains x data points x coefficients (see _fused_spec)
+_POLY_WAVE_MAX_WORK = 2.0e8    # chains x data points x coefficients (see _fused_spec)
 
 
 def _fill(rng, kind, out):

@@ -425,9 +425,10 @@ def test_fused_small_polynomial_limits_and_fallback(device):
     cond = _small_posterior(xs, rs.standard_normal(1024), 16, True).conditional_factory(precision=2.0)
     s = HMCSampler(cond, dev_t(np.zeros((3, 16)), device), 1e-4, 2, variable_name='coefficients')
     assert s._fused_spec('coefficients', 16, 1024) is not None
-    assert s._fused_spec('coefficients', 16, 8192) is None
-    s.fused_polynomial = 'always'
     assert s._fused_spec('coefficients', 16, 8192) is not None
+    assert s._fused_spec('coefficients', 16, 65536) is None
+    s.fused_polynomial = 'always'
+    assert s._fused_spec('coefficients', 16, 65536) is not None
     # a posterior with another free variable is not the conditional the kernel integrates
     full = _small_posterior(np.linspace(-1, 1, 20), rs.standard_normal(20), 4, True)
     assert full.native_hmc_spec('coefficients') is None
