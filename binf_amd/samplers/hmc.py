@@ -126,7 +126,8 @@ class HMCSampler(object):
         q0 = (state if state.dim() == 2 else state.reshape(1, -1)).contiguous()
         C, D = q0.shape
         dev = q0.device
-        if p0 is None and u is None and self._fused_rng(name, D, C):
+        spec = self._fused_spec(name, D, C)          # once per call: walks the posterior
+        if p0 is None and u is None and self._fused_rng(name, D, C, spec):
             # the draws are generated inside the sampling kernel
             if _native.gauss_persist_covers(D):
                 return self._sample_n_fused_rng(1)
@@ -148,7 +149,6 @@ class HMCSampler(object):
             self.n_accepted = torch.zeros(C, dtype=torch.int64, device=dev)
 
         accepted = torch.empty(C, dtype=torch.uint8, device=dev)
-        spec = self._fused_spec(name, D, C)
         if spec is not None and spec[0] == 'poly':
             q_out = self._sample_fused_poly(spec, q0, p0, u, accepted, adapt)
         elif spec is not None:
@@ -282,7 +282,7 @@ class HMCSampler(object):
         return samples if state.dim() == 2 else samples.reshape((nrec,) + tuple(shape))
 
     # -- fused tier ----------------------------------------------------------
-    def _fused_rng(self, name, D, C=None):
+    def _fused_rng(self, name, D, C=None, spec=False):
         """True if this sampler's draws are generated inside the sampling
         kernel: a device generator that allows it, a Gaussian with a fused
         kernel of that shape -- and a batch large enough for one wave per chain.
@@ -293,7 +293,8 @@ class HMCSampler(object):
         stand-alone generator kernels."""
         if not getattr(self.rng, 'fused', False):
             return False
-        spec = self._fused_spec(name, D)
+        if spec is False:
+            spec = self._fused_spec(name, D)
         if spec is None or spec[0] != 'gauss':
             return False
         if not _native.gauss_persist_covers(D):
