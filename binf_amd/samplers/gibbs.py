@@ -86,6 +86,12 @@ class GibbsSampler(object):
         return self._state
 
     # -- statistics ------------------------------------------------------------
+    def _calc_pacc(self):
+        """Not applicable (reference ``gibbs.py:153-157``)."""
+
+    def _propose(self):
+        """Not applicable (reference ``gibbs.py:159-163``)."""
+
     @property
     def last_draw_stats(self):
         # a subsampler's stats are keyed by ITS variable name, which must be

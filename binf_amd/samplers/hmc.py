@@ -113,6 +113,25 @@ class HMCSampler(object):
         return {self.variable_name: HMCSampleStats(self.last_move_accepted,
                                                    self.timestep)}
 
+    def _copy_state(self, state):
+        """Copies a state (reference ``hmc.py:127-134``: ``deepcopy``)."""
+        return state.clone() if isinstance(state, torch.Tensor) else state
+
+    def _adapt_timestep(self):
+        """Reference ``hmc.py:183-191`` as a method: every chain's step size times
+        ``adaption_uprate`` if its last move was accepted, else times
+        ``adaption_downrate`` (quirk Q3).  ``sample()`` / ``sample_n()`` do this
+        inside their kernels while ``counter < timestep_adaption_limit``; the
+        method is here for callers that drive the adaption themselves."""
+        acc = self._last_move_accepted
+        if not isinstance(acc, torch.Tensor):
+            raise ValueError('_adapt_timestep: no move has been made yet')
+        if self._dt_chain is None:
+            self._dt_chain = torch.full(acc.shape, float(self._timestep), dtype=torch.float64,
+                                        device=acc.device)
+        self._dt_chain = torch.where(acc, self._dt_chain * self.adaption_uprate,
+                                     self._dt_chain * self.adaption_downrate)
+
     # -- one transition ------------------------------------------------------
     def sample(self, p0=None, u=None):
         """Draw one sample per chain.  ``p0`` (``[C x D]``) and ``u`` (``[C]``)

@@ -658,3 +658,26 @@ def test_sample_n_consumes_the_generator_like_n_sample_calls(device, C, D):
     xs = [b.sample() for _ in range(4)]
     assert torch.equal(rec[0], xs[1]) and torch.equal(rec[1], xs[3])
     assert a.rng.offset == b.rng.offset == 8
+
+
+def test_private_helpers_of_the_reference_surface(device):
+    """_copy_state (hmc.py:127-134) and _adapt_timestep (hmc.py:183-191) exist as
+    methods for code that calls or overrides them."""
+    q0 = dev_t(np.random.RandomState(0).standard_normal((6, 33)), device)
+    s = HMCSampler(IsotropicGaussian(), q0, 0.3, 3, variable_name='x')
+    c = s._copy_state(q0)
+    assert torch.equal(c, q0) and c.data_ptr() != q0.data_ptr()
+    with pytest.raises(ValueError):
+        s._adapt_timestep()
+    rs = np.random.RandomState(1)
+    u = rs.uniform(size=6)
+    u[::2] = 0.9999999
+    p0 = rs.standard_normal((6, 33))
+    p0[::2] *= 6.0                                   # rejected
+    s.sample(p0=dev_t(p0, device), u=dev_t(u, device))
+    acc = s.last_move_accepted.cpu().numpy()
+    assert acc.any() and not acc.all()
+    assert s.timestep == 0.3                         # adaption limit 0: sample() does not adapt
+    s._adapt_timestep()
+    want = np.where(acc, 0.3 * 1.05, 0.3 * 0.95)
+    assert np.array_equal(s.timestep.cpu().numpy(), want)

@@ -442,3 +442,9 @@ def test_example_models_and_samplers_have_no_cpu_evaluation_path():
     import torch
     with pytest.raises(TypeError, match='a cpu tensor'):
         GaussianErrorModel(ys).log_prob(mock_data=torch.zeros(5, dtype=torch.float64), precision=1.0)
+
+
+def test_gibbs_not_applicable_hooks_exist():
+    """gibbs.py:153-163: the single-chain-MC hooks a Gibbs sampler does not use."""
+    g = make_gibbs()
+    assert g._calc_pacc() is None and g._propose() is None
