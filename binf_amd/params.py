@@ -128,7 +128,12 @@ class ParameterHolder(object):
             raise ParameterNotFoundError(name)
         if not isinstance(parameter, AbstractParameter):
             raise TypeError('%r is not a parameter object' % (parameter,))
+        self._validate(name, parameter)
         self._params[name] = parameter
+
+    def _validate(self, name, parameter):
+        """Parameter validation hook, called before a slot is filled (reference
+        ``binf/model/__init__.py:52-57``; subclasses raise to refuse a value)."""
 
     @property
     def parameters(self):

@@ -25,6 +25,18 @@ class AbstractBinfPDF(ParameterHolder, AbstractBinfNamedCallable):
         ParameterHolder.__init__(self)
         AbstractBinfNamedCallable.__init__(self, name)
 
+    # -- csb.statistics.pdf.AbstractDensity leftovers the reference keeps -------
+    @property
+    def estimator(self):
+        raise NotImplementedError          # reference binf/pdf/__init__.py:39-41
+
+    @estimator.setter
+    def estimator(self, strategy):
+        pass                               # :42-44
+
+    def estimate(self, data):
+        raise NotImplementedError          # :46-47
+
     # -- evaluation ---------------------------------------------------------
     def _evaluate_log_prob(self, **variables):
         raise NotImplementedError

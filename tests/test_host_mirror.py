@@ -448,3 +448,28 @@ def test_gibbs_not_applicable_hooks_exist():
     """gibbs.py:153-163: the single-chain-MC hooks a Gibbs sampler does not use."""
     g = make_gibbs()
     assert g._calc_pacc() is None and g._propose() is None
+
+
+def test_density_leftovers_and_validation_hook():
+    """binf/pdf/__init__.py:39-47 (estimator / estimate are not implemented in the
+    reference either) and the parameter validation hook of binf/model/__init__.py:52-57."""
+    pdf = MockBinfPDF()
+    with pytest.raises(NotImplementedError):
+        pdf.estimator
+    pdf.estimator = 'anything'               # accepted and ignored, as in the reference
+    with pytest.raises(NotImplementedError):
+        pdf.estimate([1.0])
+    seen = []
+
+    class Picky(MockBinfPDF):
+        def _validate(self, name, parameter):
+            seen.append(name)
+            if parameter.value == 13.0:
+                raise ValueError('refused')
+    p = Picky()                               # the constructor fills 'ParamA' once
+    assert seen == ['ParamA']
+    p['ParamA'] = Parameter(3.0, 'ParamA')
+    assert seen == ['ParamA', 'ParamA'] and p['ParamA'].value == 3.0
+    with pytest.raises(ValueError):
+        p['ParamA'] = Parameter(13.0, 'ParamA')
+    assert p['ParamA'].value == 3.0
