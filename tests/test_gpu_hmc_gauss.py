@@ -348,6 +348,59 @@ def test_generic_tier_bitwise_vs_oracle(device, D, C, L, k, x0, dt):
         assert np.array_equal(s.last_e_after.cpu().numpy(), want['e_after'])
 
 
+class TorchDoubleWell(object):
+    """A non-Gaussian user pdf: log p = -a sum (x^2 - 1)^2; the same expression
+    order as ``NumpyDoubleWell`` so the two round alike."""
+
+    def __init__(self, a):
+        self.a = a
+
+    def log_prob(self, x):
+        w = x * x - 1.0
+        return (-self.a) * _native.row_sum((w * w).reshape(-1, x.shape[-1]))
+
+    def gradient(self, x):
+        return (4.0 * self.a) * x * (x * x - 1.0)
+
+
+class NumpyDoubleWell(object):
+    def __init__(self, a):
+        self.a = a
+
+    def log_prob(self, x):
+        w = x * x - 1.0
+        return (-self.a) * np.sum(w * w)
+
+    def gradient(self, x):
+        return (4.0 * self.a) * x * (x * x - 1.0)
+
+
+@pytest.mark.parametrize('D,C,L,dt,adapt', [(7, 40, 5, 0.09, False), (300, 16, 8, 0.03, True),
+                                            (2500, 4, 3, 0.01, False)])
+def test_generic_tier_non_gaussian_pdf_bitwise_vs_oracle(device, D, C, L, dt, adapt):
+    """The per-step tier with a pdf the library knows nothing about, three
+    sample() calls in a row (rejections and the step-size adaption included),
+    against the numpy restatement of the reference's sampler chain by chain."""
+    rs = np.random.RandomState(D)
+    a = 1.5
+    q0 = rs.standard_normal((C, D))
+    s = HMCSampler(TorchDoubleWell(a), dev_t(q0, device), dt, L, variable_name='x',
+                   timestep_adaption_limit=3 if adapt else 0)   # adapts on calls 0 and 1
+    q, dts = q0, np.full(C, dt)
+    for call in range(3):
+        p0 = rs.standard_normal((C, D))
+        u = rs.uniform(size=C)
+        want = R.hmc_sample_batch(lambda c: NumpyDoubleWell(a), q, p0, u, dts, L,
+                                  adapt=adapt and call < 2)
+        out = s.sample(p0=dev_t(p0, device), u=dev_t(u, device))
+        assert np.array_equal(out.cpu().numpy(), want['q_out'])
+        assert np.array_equal(s.last_move_accepted.cpu().numpy(), want['accepted'].astype(bool))
+        assert np.array_equal(s.last_e_before.cpu().numpy(), want['e_before'])
+        assert np.array_equal(s.last_e_after.cpu().numpy(), want['e_after'])
+        q, dts = want['q_out'], want['timestep_out']
+        if adapt:
+            assert np.array_equal(np.broadcast_to(s.timestep.cpu().numpy(), (C,)), dts)
+
 def test_leapfrog_method_has_the_reference_signature(device):
     """HMCSampler._leapfrog(q, p, timestep, nsteps) integrates in place and
     returns (q, p) like hmc.py:92-125 -- one chain as a [D] array, or a batch

@@ -121,3 +121,14 @@ def test_example_distance_restraints_keeps_the_structure(device):
         ['--chains', '24', '--beads', '48', '--iterations', '60', '--thin', '10'])
     assert kept.shape == (6, 24, 144)
     assert torch.isfinite(kept).all()
+
+
+def test_example_custom_pdf_samples_both_wells(device):
+    """examples/custom_pdf.py: a duck-typed torch pdf (double well) on the
+    per-step tier; coordinates sit near +-1, half of them in each well."""
+    s = _load_example('custom_pdf').main(
+        ['--chains', '512', '--dims', '32', '--draws', '300'])
+    x = s.state
+    assert 0.5 < float(s.acceptance_rate.mean()) <= 1.0
+    assert abs(float((x > 0).double().mean()) - 0.5) < 0.02
+    assert 0.8 < float(x.abs().mean()) < 1.1
