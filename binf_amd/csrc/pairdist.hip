@@ -80,7 +80,7 @@ struct PairResidMake {
     __device__ static inline void stage(const PairArgs &a, int64_t row, double *lds)
     {
         const double *xc = a.x + row * 3 * a.n_beads;
-        for (int64_t k = threadIdx.x; k < 3 * a.n_beads; k += 256) lds[k] = xc[k];
+        for (int64_t k = threadIdx.x; k < 3 * a.n_beads; k += blockDim.x) lds[k] = xc[k];
     }
     __device__ static inline PairResid make_lds(const PairArgs &a, int64_t row, const double *lds)
     {
@@ -397,6 +397,274 @@ __global__ void __launch_bounds__(256 * LANES) pairdist_leapfrog_kernel(const Pa
     }
 }
 
+// ---------------------------------------------------------------------------
+// n_beads <= 256: every UNORDERED pair once, its target distance in a register.
+//
+// The all-pairs loops above give each lane the pairs (i, j = ...) of ITS bead and
+// read y[j][i] from memory for each: one CU streams the whole [n x n] target
+// matrix (512 KiB at n = 256) per force evaluation, and that stream -- not the
+// arithmetic -- is what a workgroup waits for (scripts/pairforce_probe.hip: 30 us
+// per evaluation with the loads, 10 us without, at any number of chains).  Here
+// a 1024-thread workgroup owns a chain and computes each pair {i, j} ONCE:
+//
+//  * beads in 4 blocks of 64; the 10 unordered block pairs go to the 16 waves:
+//    waves 0-3 the diagonal blocks (b, b), waves 4-15 the six off-diagonal
+//    pairs (bi < bj), two waves each (the halves h = 0, 1 of the partner range);
+//  * lane l of a wave is ROW bead i = 64 bi + l for all of its 32 steps; at step
+//    k its partner is COLUMN bead j = 64 bj + (l + off + k) mod 64 (off = 32 h,
+//    or 1 on the diagonal, where step 31 -- partner l + 32 -- is done by lanes
+//    0-31 only).  At every step the 64 lanes hold 64 different partners;
+//  * the 32 target distances of a lane never change: they are loaded ONCE per
+//    launch (tile rows through LDS, coalesced) and stay in 64 VGPRs -- the fused
+//    leapfrog reads the target matrix once per trajectory instead of L + 1 times;
+//  * one pair_weight() serves both beads: c = w (x_i - x_j) is added to the
+//    lane's own sum F (row bead) and subtracted from a second sum R that belongs
+//    to the partner bead; since the partner advances by one column per step, R
+//    is passed to the neighbouring lane after every step (wave_rol:1), so it
+//    stays with its bead.  Half the arithmetic of the one-sided loops;
+//  * a bead's 8 partial sums (partner block b' = 0..3: the diagonal wave's F and
+//    R for b' = b, else the two half-waves' sums) are added in that order by the
+//    bead's owner thread (threads 0-255) -- a fixed order that depends on n
+//    only, so results are bit-identical for any number of chains, and the fused
+//    leapfrog is bit-identical to the per-step tier (both use this scheme for
+//    n <= 256; the one-sided kernels above serve larger n).
+// ---------------------------------------------------------------------------
+constexpr int SYM_MAX_BEADS = 256;
+constexpr int SYM_STEPS = 32;
+constexpr int SYM_ROWS = 8;              // rows of a wave's 64 x 64 target tile staged at a time
+
+struct SymShared {
+    double sx[3][4][128];                // positions [axis][block][slot]; slots 64-127 repeat 0-63
+    union {
+        double part[8][3][SYM_MAX_BEADS];    // partial forces [partner block * 2 + k][axis][bead]
+        double ytile[16][SYM_ROWS][64];      // launch prologue only
+    } u;
+};
+
+__device__ inline double wave_rol1(double v)     // lane l takes lane (l + 1) mod 64's value
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x134, 0xf, 0xf, false);   // old = src: no zeroing mov
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x134, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+struct SymRole {
+    int bi, bj, h, off;
+    bool diag;
+};
+
+__device__ inline SymRole sym_role()
+{
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    SymRole r;
+    if (wave < 4) {
+        r.bi = wave; r.bj = wave; r.h = 0; r.off = 1; r.diag = true;
+    } else {
+        const int pr = (wave - 4) >> 1;            // (0,1) (0,2) (0,3) (1,2) (1,3) (2,3)
+        r.h = (wave - 4) & 1;
+        r.bi = pr < 3 ? 0 : (pr < 5 ? 1 : 2);
+        r.bj = pr < 3 ? pr + 1 : (pr < 5 ? pr - 1 : 3);
+        r.off = 32 * r.h;
+        r.diag = false;
+    }
+    return r;
+}
+
+// The lane's 32 target distances y[k] = ymat[64 bi + l][64 bj + (l + off + k) mod 64]
+// (0 where a bead does not exist), and the bit mask of its pairs that do exist.
+__device__ inline void sym_load_targets(double (&y)[SYM_STEPS], unsigned &live, SymShared &sh,
+                                        const double *ymat, int n, const SymRole &ro)
+{
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // The tile goes through a scratch area of the wave's own, SYM_ROWS rows at a
+    // time (lane = column on the way in: coalesced 512-byte rows; lane = row on the
+    // way out), the next rows' loads in flight meanwhile.  No other wave touches the
+    // scratch: LDS serves a wave's instructions in order, so wave-level fences (no
+    // s_barrier) are all the synchronisation the exchange needs.
+    const int col = 64 * ro.bj + lane;
+    double nxt[SYM_ROWS];
+    auto fetch = [&](int r0) {
+#pragma unroll
+        for (int r = 0; r < SYM_ROWS; ++r) {
+            const int row = 64 * ro.bi + r0 + r;
+            nxt[r] = (row < n && col < n) ? ymat[(int64_t)row * n + col] : 0.0;
+        }
+    };
+    fetch(0);
+    for (int r0 = 0; r0 < 64; r0 += SYM_ROWS) {
+#pragma unroll
+        for (int r = 0; r < SYM_ROWS; ++r) sh.u.ytile[wave][r][lane] = nxt[r];
+        if (r0 + SYM_ROWS < 64) fetch(r0 + SYM_ROWS);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (lane >= r0 && lane < r0 + SYM_ROWS) {
+            const double *rowp = sh.u.ytile[wave][lane - r0];
+#pragma unroll
+            for (int k = 0; k < SYM_STEPS; ++k) y[k] = rowp[(lane + ro.off + k) & 63];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    __syncthreads();                     // the scratch shares its LDS with the partial sums
+    live = 0;
+    const int i = 64 * ro.bi + lane;
+#pragma unroll
+    for (int k = 0; k < SYM_STEPS; ++k) {
+        const int j = 64 * ro.bj + ((lane + ro.off + k) & 63);
+        const bool ok = i < n && j < n && !(ro.diag && k == SYM_STEPS - 1 && lane >= 32);
+        live |= ok ? (1u << k) : 0u;
+    }
+}
+
+// One force evaluation: this wave's partial sums to sh.u.part.  Positions must be
+// in sh.sx (both copies); the caller synchronises before reading the partials.
+// FULL: n == 256, every pair exists except the diagonal waves' last half step.
+template <bool FULL>
+__device__ inline void sym_partials(const double (&y)[SYM_STEPS], unsigned live, SymShared &sh,
+                                    int n, const SymRole &ro)
+{
+    const int lane = threadIdx.x & 63;
+    double F0 = 0.0, F1 = 0.0, F2 = 0.0, R0 = 0.0, R1 = 0.0, R2 = 0.0;
+    if (64 * ro.bi < n && 64 * ro.bj < n) {            // wave-uniform
+        const double x0 = sh.sx[0][ro.bi][lane], x1 = sh.sx[1][ro.bi][lane],
+                     x2 = sh.sx[2][ro.bi][lane];
+        const double *pj0 = &sh.sx[0][ro.bj][lane + ro.off];
+        const double *pj1 = &sh.sx[1][ro.bj][lane + ro.off];
+        const double *pj2 = &sh.sx[2][ro.bj][lane + ro.off];
+#pragma unroll
+        for (int k = 0; k < SYM_STEPS; ++k) {
+            const double d0 = x0 - pj0[k], d1 = x1 - pj1[k], d2 = x2 - pj2[k];
+            double w = pair_weight(d0, d1, d2, y[k]);
+            if (FULL) {
+                if (k == SYM_STEPS - 1) w = (ro.diag && lane >= 32) ? 0.0 : w;
+            } else {
+                w = ((live >> k) & 1u) ? w : 0.0;      // also discards the NaN of a 0-distance ghost
+            }
+            const double c0 = w * d0, c1 = w * d1, c2 = w * d2;
+            F0 += c0; F1 += c1; F2 += c2;
+            R0 = wave_rol1(R0 - c0);                   // the partner's share is -c; then R moves on
+            R1 = wave_rol1(R1 - c1);
+            R2 = wave_rol1(R2 - c2);
+        }
+    }
+    const int slotF = ro.diag ? 2 * ro.bi : 2 * ro.bj + ro.h;
+    const int slotR = ro.diag ? 2 * ro.bi + 1 : 2 * ro.bi + ro.h;
+    const int bF = 64 * ro.bi + lane;
+    const int bR = 64 * ro.bj + ((lane + ro.off + SYM_STEPS) & 63);
+    sh.u.part[slotF][0][bF] = F0; sh.u.part[slotF][1][bF] = F1; sh.u.part[slotF][2][bF] = F2;
+    sh.u.part[slotR][0][bR] = R0; sh.u.part[slotR][1][bR] = R1; sh.u.part[slotR][2][bR] = R2;
+}
+
+// Owner thread t (< 256) of bead t: the bead's force, partials added in slot order.
+__device__ inline void sym_reduce(const SymShared &sh, int t, double (&f)[3])
+{
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) {
+        double v = sh.u.part[0][ax][t];
+#pragma unroll
+        for (int sl = 1; sl < 8; ++sl) v = v + sh.u.part[sl][ax][t];
+        f[ax] = v;
+    }
+}
+
+__device__ inline void sym_publish(SymShared &sh, int t, const double (&q)[3])
+{
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) {
+        sh.sx[ax][t >> 6][t & 63] = q[ax];
+        sh.sx[ax][t >> 6][(t & 63) + 64] = q[ax];
+    }
+}
+
+template <bool FULL>
+__global__ void __launch_bounds__(1024)
+pairdist_grad_sym_kernel(const double *x, const double *ymat, double tau, const double *tau_chain,
+                         double *out, int32_t n_beads)
+{
+    __shared__ SymShared sh;
+    const int n = n_beads, t = threadIdx.x;
+    const int64_t c = blockIdx.x;
+    const double *xc = x + c * 3 * (int64_t)n;
+    const SymRole ro = sym_role();
+    double y[SYM_STEPS];
+    unsigned live;
+    sym_load_targets(y, live, sh, ymat, n, ro);
+    if (t < SYM_MAX_BEADS) {
+        double q[3];
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) q[ax] = (t < n) ? xc[3 * t + ax] : 0.0;
+        sym_publish(sh, t, q);
+    }
+    __syncthreads();
+    sym_partials<FULL>(y, live, sh, n, ro);
+    __syncthreads();
+    if (t < n) {
+        double f[3];
+        sym_reduce(sh, t, f);
+        const double tc = tau_chain ? tau_chain[c] : tau;
+        double *o = out + c * 3 * (int64_t)n + 3 * t;
+        o[0] = tc * f[0]; o[1] = tc * f[1]; o[2] = tc * f[2];
+    }
+}
+
+// The whole _leapfrog() (binf/samplers/hmc.py:92-125) in one launch with the
+// scheme above: owner threads keep q and p of their bead in registers.
+template <bool FMA, bool FULL>
+__global__ void __launch_bounds__(1024) pairdist_leapfrog_sym_kernel(const PairLeapArgs a)
+{
+    __shared__ SymShared sh;
+    const int n = a.n_beads, t = threadIdx.x;
+    const int64_t c = blockIdx.x;
+    double *qc = a.q + c * 3 * (int64_t)n;
+    double *pc = a.p + c * 3 * (int64_t)n;
+    const double tau = a.tau_chain ? a.tau_chain[c] : a.tau;
+    const double dt = a.dt_chain ? a.dt_chain[c] : a.timestep;
+    const double hdt = 0.5 * dt;
+    const SymRole ro = sym_role();
+    const bool owner = t < n;
+    double y[SYM_STEPS];
+    unsigned live;
+    sym_load_targets(y, live, sh, a.ymat, n, ro);
+    double q[3] = {0.0, 0.0, 0.0}, p[3] = {0.0, 0.0, 0.0};
+    if (owner) {
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) { q[ax] = qc[3 * t + ax]; p[ax] = pc[3 * t + ax]; }
+    }
+    if (t < SYM_MAX_BEADS) sym_publish(sh, t, q);
+    __syncthreads();
+    // nsteps + 1 force evaluations: half kick, (nsteps - 1) x [drift, kick], drift, half kick
+    for (int e = 0; e <= a.nsteps; ++e) {
+        sym_partials<FULL>(y, live, sh, n, ro);
+        __syncthreads();
+        if (owner) {
+            double f[3];
+            sym_reduce(sh, t, f);
+            const double step = (e == 0 || e == a.nsteps) ? hdt : dt;
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) {
+                const double gl = tau * f[ax];
+                double g = gl;
+                if (a.has_prior) {
+                    const double gp = a.prior_k * (q[ax] - a.prior_x0);
+                    g = a.prior_first ? gp + gl : gl + gp;
+                }
+                p[ax] = FMA ? __builtin_fma(-step, g, p[ax]) : p[ax] - step * g;
+                if (e < a.nsteps)
+                    q[ax] = FMA ? __builtin_fma(p[ax], dt, q[ax]) : q[ax] + p[ax] * dt;
+            }
+            if (e < a.nsteps) sym_publish(sh, t, q);
+        }
+        __syncthreads();
+    }
+    if (owner) {
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) { qc[3 * t + ax] = q[ax]; pc[3 * t + ax] = p[ax]; }
+    }
+}
+
 }  // namespace binf
 
 using namespace binf;
@@ -442,9 +710,12 @@ extern "C" int32_t binf_pairdist_gauss_logp_f64(const double *x, const int32_t *
     hipStream_t st = (hipStream_t)stream;
     int32_t rc;
     if (n_beads <= 2048)            // 48 KiB of coordinates fit the static LDS budget
+        // fewer rows than ~4 workgroups per CU: 16 waves per row instead of 4
+        // (256 chains: 41 -> 30 us; 2048 chains: 141 vs 122 us, so not there)
         rc = row_reduce_launch<PairResidMake, PairArgs, true>(a, C, n_pairs, 1.0, out, st, true,
                                                              "pairdist_gauss_logp",
-                                                             (size_t)n_beads * 3 * sizeof(double));
+                                                             (size_t)n_beads * 3 * sizeof(double),
+                                                             C < 1024);
     else
         rc = row_reduce_launch<PairResidMake, PairArgs>(a, C, n_pairs, 1.0, out, st, true,
                                                        "pairdist_gauss_logp");
@@ -468,7 +739,14 @@ extern "C" int32_t binf_pairdist_gauss_grad_f64(const double *x, const double *y
     if (n_beads > 46340 || C > 0x7fffffffLL)
         return fail(BINF_E_UNSUPPORTED, "pairdist_gauss_grad: too large");
     const size_t lds = (size_t)n_beads * 3 * sizeof(double);
-    if (n_beads <= 1024 && lanes_per_bead(C) == 4)
+    hipStream_t gst = (hipStream_t)stream;
+    if (n_beads == SYM_MAX_BEADS)
+        pairdist_grad_sym_kernel<true><<<dim3((unsigned)C), 1024, 0, gst>>>(
+            x, ymat, precision, precision_chain, out, (int32_t)n_beads);
+    else if (n_beads < SYM_MAX_BEADS)
+        pairdist_grad_sym_kernel<false><<<dim3((unsigned)C), 1024, 0, gst>>>(
+            x, ymat, precision, precision_chain, out, (int32_t)n_beads);
+    else if (n_beads <= 1024 && lanes_per_bead(C) == 4)
         pairdist_grad4_kernel<<<dim3((unsigned)C), 1024, lds, (hipStream_t)stream>>>(
             x, ymat, precision, precision_chain, out, (int32_t)n_beads);
     else if (n_beads <= 1024)
@@ -509,6 +787,19 @@ extern "C" int32_t binf_pairdist_leapfrog_f64(double *q, double *p, const double
     const bool fma = mode == BINF_MODE_FMA;
     const int nb = (int)((n_beads + 255) / 256);
     const bool four = lanes_per_bead(C) == 4;
+    if (n_beads <= SYM_MAX_BEADS) {
+        const bool full = n_beads == SYM_MAX_BEADS;
+        if (fma) {
+            if (full) pairdist_leapfrog_sym_kernel<true, true><<<grid, 1024, 0, st>>>(a);
+            else      pairdist_leapfrog_sym_kernel<true, false><<<grid, 1024, 0, st>>>(a);
+        } else {
+            if (full) pairdist_leapfrog_sym_kernel<false, true><<<grid, 1024, 0, st>>>(a);
+            else      pairdist_leapfrog_sym_kernel<false, false><<<grid, 1024, 0, st>>>(a);
+        }
+        hipError_t es = hipGetLastError();
+        if (es != hipSuccess) return hip_fail(es, "pairdist_leapfrog launch");
+        return 0;
+    }
 #define LAUNCH(NBV)                                                                         \
     do {                                                                                    \
         if (four) {                                                                         \

@@ -84,17 +84,20 @@ row_reduce_wave_kernel(const ARGS args, const RowGeom g, double *out)
 // (FM::stage, all 256 threads) and builds the element functor on top of it
 // (FM::make_lds) -- for element functions that gather from a small per-row
 // table (pair distances: the chain's coordinates).
-template <class FM, class ARGS, bool STAGED = false>
-__global__ void __launch_bounds__(256)
+// THREADS: 256, or 1024 when a launch has too few rows to fill the chip with
+// 4-wave workgroups (16 waves per row hide the latency of the element function).
+template <class FM, class ARGS, bool STAGED = false, int THREADS = 256>
+__global__ void __launch_bounds__(THREADS)
 row_reduce_block_kernel(const ARGS args, const RowGeom g, double *out)
 {
+    constexpr int GROUPS = THREADS / 8;
     __shared__ double S[128];
     __shared__ int dep[128];
     extern __shared__ double row_lds[];
     const int H = g.H;
     const int npaths = 1 << H;
     const int lane = threadIdx.x & 63;
-    const int group = threadIdx.x >> 3;      // 32 groups of 8 lanes
+    const int group = threadIdx.x >> 3;      // GROUPS groups of 8 lanes
     const int64_t row = blockIdx.x;
     if constexpr (STAGED) {
         FM::stage(args, row, row_lds);
@@ -107,7 +110,7 @@ row_reduce_block_kernel(const ARGS args, const RowGeom g, double *out)
     double total = 0.0;                      // the reduction's identity
     for (int cbase = 0; cbase == 0 || cbase < g.D; cbase += NPY_BUFSIZE) {
         const int n = (g.D - cbase < NPY_BUFSIZE) ? g.D - cbase : NPY_BUFSIZE;
-        for (int base = 0; base < npaths; base += 32) {
+        for (int base = 0; base < npaths; base += GROUPS) {
             const int path = base + group;
             const bool act = path < npaths;
             const Leaf L = pairwise_leaf(n, H, act ? path : 0);
@@ -139,7 +142,7 @@ template <class FM, class ARGS, bool STAGED = false>
 static int32_t row_reduce_launch(const ARGS &args, int64_t C, int64_t D,
                                  double scale, double *out, hipStream_t st,
                                  bool force_block, const char *what,
-                                 size_t staged_bytes = 0)
+                                 size_t staged_bytes = 0, bool wide = false)
 {
     if (C > 0x7fffffffLL || D > 0x7fffffffLL)
         return fail(BINF_E_UNSUPPORTED, "%s: too large", what);
@@ -152,7 +155,10 @@ static int32_t row_reduce_launch(const ARGS &args, int64_t C, int64_t D,
     }
     if (g.H > 7) return fail(BINF_E_UNSUPPORTED, "%s: pairwise tree height %d", what, g.H);
     if constexpr (STAGED) {
-        row_reduce_block_kernel<FM, ARGS, true><<<dim3((unsigned)C), 256, staged_bytes, st>>>(args, g, out);
+        if (wide)
+            row_reduce_block_kernel<FM, ARGS, true, 1024><<<dim3((unsigned)C), 1024, staged_bytes, st>>>(args, g, out);
+        else
+            row_reduce_block_kernel<FM, ARGS, true><<<dim3((unsigned)C), 256, staged_bytes, st>>>(args, g, out);
     } else if (g.H <= 3 && !force_block) {
         const int64_t rows_per_wave = 64 >> (3 + g.H);
         const int64_t waves = (C + rows_per_wave - 1) / rows_per_wave;

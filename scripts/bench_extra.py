@@ -118,16 +118,29 @@ def c5_distance(dev, C=256, n=256, L=20):
     lik = make_distance_likelihood(ys, n)
     prior = IsotropicGaussian(0.05, 0.0, name='coordinates_prior', variable_name='coordinates')
     cond = Posterior({lik.name: lik}, {prior.name: prior}).conditional_factory(precision=4.0)
+    from binf_amd import _native
     t_g = _timed(lambda: lik.gradient(coordinates=x, precision=4.0), 20)
+    # one force evaluation INSIDE the fused trajectory kernel: launch time against the
+    # trajectory length (the target distances reach registers once per launch)
+    ymat = lik.error_model.ymat_device(dev)
+    q, p = x.clone(), torch.zeros_like(x)
+    t_l = {}
+    for nst in (1, L):
+        t_l[nst] = _timed(lambda: _native.pairdist_leapfrog(q, p, ymat, 4.0, (0.05, 0.0), True,
+                                                            1e-5, None, nst), 40, warm=5)
+    t_e = (t_l[L] - t_l[1]) / (L - 1)
     s = HMCSampler(cond, x, 0.002, L, variable_name='coordinates', rng=DeviceRNG(0, dev))
     t_h = _timed(s.sample, 5, warm=1)
-    pairs = float(C) * n * n                      # ordered pairs evaluated per force call
+    pairs = float(C) * n * (n - 1)                # ordered pairs per force evaluation
     return {'workload': 'C5 share: %d beads x 3, %d chains, L=%d' % (n, C, L),
             'force_kernel_ms': t_g * 1e3,
-            'pair_interactions_per_s': pairs / t_g,
-            # 36 VALU instructions per ordered pair and lane (PMC) against
-            # the issue rate of the chip (one VALU instruction per lane and clock)
-            'valu_frac': 36.0 * pairs / t_g / VALU_PEAK_LANEOPS,
+            'leapfrog_kernel_ms': t_l[L] * 1e3,
+            'force_eval_in_trajectory_us': t_e * 1e6,
+            'pair_interactions_per_s': pairs / t_e,
+            # 29 VALU instructions per UNORDERED pair and lane (ISA of the n <= 256 scheme,
+            # DESIGN.md 4.4) against the issue rate of the chip (one VALU instruction per
+            # lane and clock)
+            'valu_frac': 29.0 * 0.5 * pairs / t_e / VALU_PEAK_LANEOPS,
             'hmc_sample_ms': t_h * 1e3,
             'chain_leapfrog_steps_per_s': C * L / t_h,
             'acceptance': float(s.acceptance_rate.mean())}

@@ -43,7 +43,10 @@ def test_forward_distances_bitwise(device, n, C):
     assert np.array_equal(got, want)
 
 
-@pytest.mark.parametrize('n,C', [(3, 5), (10, 17), (64, 9), (256, 6), (300, 2)])
+@pytest.mark.parametrize('n,C', [(3, 5), (10, 17), (64, 9), (256, 6), (300, 2),
+                                 # around the 64-bead blocks of the n <= 256 force scheme
+                                 (2, 2), (63, 3), (65, 3), (127, 2), (128, 2), (129, 2), (191, 2),
+                                 (192, 2), (193, 2), (255, 2), (257, 2)])
 def test_likelihood_logp_and_force(device, n, C):
     ys, x = synth(n, C, n + 1)
     L = make_distance_likelihood(ys, n)
@@ -153,15 +156,17 @@ def test_leapfrog_spec_rejects_unsupported_structures(device):
     assert post.conditional_factory(precision=1.0).native_leapfrog_spec('coefficients') is None
 
 
-def test_force_is_independent_of_the_batch_size(device):
-    """Few chains use four lanes per bead, many chains one; both sum in the
-    same order, so a chain's force and trajectory do not depend on how many
-    other chains share the launch."""
-    n = 64
+@pytest.mark.parametrize('n', [64, 200, 256, 300])
+def test_force_is_independent_of_the_batch_size(device, n):
+    """A chain's force and trajectory do not depend on how many other chains
+    share the launch: up to 256 beads every batch size runs the same
+    one-workgroup-per-chain scheme (a summation order fixed by n alone); above,
+    few chains use four lanes per bead and many chains one, and both add in the
+    same order."""
     ys, x = synth(n, 1100, 7)
     L_ = make_distance_likelihood(ys, n)
-    big = L_.gradient(coordinates=dev_t(x, device), precision=2.0).cpu().numpy()       # 1 lane / bead
-    small = L_.gradient(coordinates=dev_t(x[:40], device), precision=2.0).cpu().numpy()  # 4 lanes / bead
+    big = L_.gradient(coordinates=dev_t(x, device), precision=2.0).cpu().numpy()
+    small = L_.gradient(coordinates=dev_t(x[:40], device), precision=2.0).cpu().numpy()
     assert np.array_equal(big[:40], small)
     q1, p1 = dev_t(x, device), dev_t(x[::-1].copy(), device)
     q2, p2 = q1[:40].clone(), p1[:40].clone()
@@ -171,7 +176,24 @@ def test_force_is_independent_of_the_batch_size(device):
     assert torch.equal(q1[:40], q2) and torch.equal(p1[:40], p2)
 
 
-@pytest.mark.parametrize('n,C', [(2, 3), (17, 5), (128, 4), (129, 3), (256, 6), (300, 2)])
+def test_force_counts_every_pair_once_in_each_direction(device):
+    """The n <= 256 scheme evaluates an unordered pair once and books it on both
+    beads.  With all targets 0 the pair weight is exactly 1, so the force on
+    bead i is sum_j (x_i - x_j): integer coordinates make every partial sum
+    exact, and any pair dropped, doubled or booked on the wrong bead shows."""
+    for n in (2, 31, 64, 65, 130, 200, 256):
+        rs = np.random.RandomState(n)
+        x = rs.randint(-50, 50, size=(3, n, 3)).astype(np.float64)
+        # distinct beads (a zero distance has no direction)
+        x[:, :, 0] += 200.0 * np.arange(n)[None, :]
+        ymat = torch.zeros((n, n), dtype=torch.float64, device=device)
+        g = _native.pairdist_gauss_grad(dev_t(x.reshape(3, -1), device), ymat, 1.0).cpu().numpy()
+        want = n * x - x.sum(axis=1, keepdims=True)
+        assert np.array_equal(g.reshape(3, n, 3), want), n
+
+
+@pytest.mark.parametrize('n,C', [(2, 3), (3, 2), (9, 4), (17, 5), (128, 4), (129, 3), (256, 6), (300, 2),
+                                 (700, 2), (17, 1030), (130, 1025)])
 def test_fused_log_prob_is_forward_plus_error_model_bitwise(device, n, C):
     """binf_pairdist_gauss_logp_f64 (distances never written to HBM) against
     the two-kernel path it replaces, including n_pairs = 8128 / 8256 / 32640 /
