@@ -137,10 +137,10 @@ def c5_distance(dev, C=256, n=256, L=20):
             'leapfrog_kernel_ms': t_l[L] * 1e3,
             'force_eval_in_trajectory_us': t_e * 1e6,
             'pair_interactions_per_s': pairs / t_e,
-            # 29 VALU instructions per UNORDERED pair and lane (ISA of the n <= 256 scheme,
+            # 24 VALU instructions per UNORDERED pair and lane (ISA of the n <= 256 scheme,
             # DESIGN.md 4.4) against the issue rate of the chip (one VALU instruction per
             # lane and clock)
-            'valu_frac': 29.0 * 0.5 * pairs / t_e / VALU_PEAK_LANEOPS,
+            'valu_frac': 24.0 * 0.5 * pairs / t_e / VALU_PEAK_LANEOPS,
             'hmc_sample_ms': t_h * 1e3,
             'chain_leapfrog_steps_per_s': C * L / t_h,
             'acceptance': float(s.acceptance_rate.mean())}
