@@ -162,7 +162,32 @@ __global__ void __launch_bounds__(64) hmc_poly_small_kernel(const PolyHmcArgs a)
     auto force = [&]() {
 #pragma unroll
         for (int k = 0; k < KMAX; ++k) g[k] = 0.0;
-        for (int n = 0; n < N; ++n) {
+        // four data points per round: their LDS reads and Horner chains overlap (one
+        // point at a time the loop waited ~100 cycles for LDS per point, with a single
+        // wave per SIMD at the example's batch sizes); each g[k] still receives its
+        // terms in the order n = 0, 1, 2, ... -- the same bits as the plain loop
+        int n = 0;
+        for (; n + 4 <= N; n += 4) {
+            double x[4], y[4], v[4], r[4], pw[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { x[u] = sx[n + u]; y[u] = sy[n + u]; v[u] = th[KMAX - 1]; }
+#pragma unroll
+            for (int k = KMAX - 2; k >= 0; --k) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = __builtin_fma(v[u], x[u], th[k]);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { r[u] = (v[u] - y[u]) * tau; pw[u] = 1.0; }
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    g[k] = __builtin_fma(pw[u], r[u], g[k]);
+                    pw[u] = pw[u] * x[u];
+                }
+            }
+        }
+        for (; n < N; ++n) {
             const double x = sx[n];
             double v = th[KMAX - 1];
 #pragma unroll
