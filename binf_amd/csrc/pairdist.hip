@@ -298,6 +298,7 @@ struct PairLeapArgs {
     int32_t prior_first;     // prior term added before the likelihood term
     int32_t nsteps;
     int32_t n_beads;
+    int64_t n_chains;        // sym kernels: a workgroup walks chains blockIdx.x, + gridDim.x, ...
 };
 
 template <int NB, bool FMA, int LANES>
@@ -584,34 +585,39 @@ __device__ inline void sym_publish(SymShared &sh, int t, const double (&q)[3])
     }
 }
 
+// A workgroup loads its target distances once and then walks chains blockIdx.x,
+// blockIdx.x + gridDim.x, ...: the launchers start one workgroup per CU (a
+// 1024-thread workgroup with 126 VGPRs fills a CU), so with more chains than CUs
+// the target load is paid once per CU, not once per chain.
 template <bool FULL>
 __global__ void __launch_bounds__(1024)
 pairdist_grad_sym_kernel(const double *x, const double *ymat, double tau, const double *tau_chain,
-                         double *out, int32_t n_beads)
+                         double *out, int32_t n_beads, int64_t n_chains)
 {
     __shared__ SymShared sh;
     const int n = n_beads, t = threadIdx.x;
-    const int64_t c = blockIdx.x;
-    const double *xc = x + c * 3 * (int64_t)n;
     const SymRole ro = sym_role();
     double y[SYM_STEPS];
     unsigned live;
     sym_load_targets(y, live, sh, ymat, n, ro);
-    if (t < SYM_MAX_BEADS) {
-        double q[3];
+    for (int64_t c = blockIdx.x; c < n_chains; c += gridDim.x) {
+        const double *xc = x + c * 3 * (int64_t)n;
+        if (t < SYM_MAX_BEADS) {
+            double q[3];
 #pragma unroll
-        for (int ax = 0; ax < 3; ++ax) q[ax] = (t < n) ? xc[3 * t + ax] : 0.0;
-        sym_publish(sh, t, q);
-    }
-    __syncthreads();
-    sym_partials<FULL>(y, live, sh, n, ro);
-    __syncthreads();
-    if (t < n) {
-        double f[3];
-        sym_reduce(sh, t, f);
-        const double tc = tau_chain ? tau_chain[c] : tau;
-        double *o = out + c * 3 * (int64_t)n + 3 * t;
-        o[0] = tc * f[0]; o[1] = tc * f[1]; o[2] = tc * f[2];
+            for (int ax = 0; ax < 3; ++ax) q[ax] = (t < n) ? xc[3 * t + ax] : 0.0;
+            sym_publish(sh, t, q);
+        }
+        __syncthreads();
+        sym_partials<FULL>(y, live, sh, n, ro);
+        __syncthreads();
+        if (t < n) {
+            double f[3];
+            sym_reduce(sh, t, f);
+            const double tc = tau_chain ? tau_chain[c] : tau;
+            double *o = out + c * 3 * (int64_t)n + 3 * t;
+            o[0] = tc * f[0]; o[1] = tc * f[1]; o[2] = tc * f[2];
+        }
     }
 }
 
@@ -622,51 +628,52 @@ __global__ void __launch_bounds__(1024) pairdist_leapfrog_sym_kernel(const PairL
 {
     __shared__ SymShared sh;
     const int n = a.n_beads, t = threadIdx.x;
-    const int64_t c = blockIdx.x;
-    double *qc = a.q + c * 3 * (int64_t)n;
-    double *pc = a.p + c * 3 * (int64_t)n;
-    const double tau = a.tau_chain ? a.tau_chain[c] : a.tau;
-    const double dt = a.dt_chain ? a.dt_chain[c] : a.timestep;
-    const double hdt = 0.5 * dt;
     const SymRole ro = sym_role();
     const bool owner = t < n;
     double y[SYM_STEPS];
     unsigned live;
     sym_load_targets(y, live, sh, a.ymat, n, ro);
-    double q[3] = {0.0, 0.0, 0.0}, p[3] = {0.0, 0.0, 0.0};
-    if (owner) {
-#pragma unroll
-        for (int ax = 0; ax < 3; ++ax) { q[ax] = qc[3 * t + ax]; p[ax] = pc[3 * t + ax]; }
-    }
-    if (t < SYM_MAX_BEADS) sym_publish(sh, t, q);
-    __syncthreads();
-    // nsteps + 1 force evaluations: half kick, (nsteps - 1) x [drift, kick], drift, half kick
-    for (int e = 0; e <= a.nsteps; ++e) {
-        sym_partials<FULL>(y, live, sh, n, ro);
-        __syncthreads();
+    for (int64_t c = blockIdx.x; c < a.n_chains; c += gridDim.x) {
+        double *qc = a.q + c * 3 * (int64_t)n;
+        double *pc = a.p + c * 3 * (int64_t)n;
+        const double tau = a.tau_chain ? a.tau_chain[c] : a.tau;
+        const double dt = a.dt_chain ? a.dt_chain[c] : a.timestep;
+        const double hdt = 0.5 * dt;
+        double q[3] = {0.0, 0.0, 0.0}, p[3] = {0.0, 0.0, 0.0};
         if (owner) {
-            double f[3];
-            sym_reduce(sh, t, f);
-            const double step = (e == 0 || e == a.nsteps) ? hdt : dt;
 #pragma unroll
-            for (int ax = 0; ax < 3; ++ax) {
-                const double gl = tau * f[ax];
-                double g = gl;
-                if (a.has_prior) {
-                    const double gp = a.prior_k * (q[ax] - a.prior_x0);
-                    g = a.prior_first ? gp + gl : gl + gp;
-                }
-                p[ax] = FMA ? __builtin_fma(-step, g, p[ax]) : p[ax] - step * g;
-                if (e < a.nsteps)
-                    q[ax] = FMA ? __builtin_fma(p[ax], dt, q[ax]) : q[ax] + p[ax] * dt;
-            }
-            if (e < a.nsteps) sym_publish(sh, t, q);
+            for (int ax = 0; ax < 3; ++ax) { q[ax] = qc[3 * t + ax]; p[ax] = pc[3 * t + ax]; }
         }
+        if (t < SYM_MAX_BEADS) sym_publish(sh, t, q);
         __syncthreads();
-    }
-    if (owner) {
+        // nsteps + 1 force evaluations: half kick, (nsteps - 1) x [drift, kick], drift, half kick
+        for (int e = 0; e <= a.nsteps; ++e) {
+            sym_partials<FULL>(y, live, sh, n, ro);
+            __syncthreads();
+            if (owner) {
+                double f[3];
+                sym_reduce(sh, t, f);
+                const double step = (e == 0 || e == a.nsteps) ? hdt : dt;
 #pragma unroll
-        for (int ax = 0; ax < 3; ++ax) { qc[3 * t + ax] = q[ax]; pc[3 * t + ax] = p[ax]; }
+                for (int ax = 0; ax < 3; ++ax) {
+                    const double gl = tau * f[ax];
+                    double g = gl;
+                    if (a.has_prior) {
+                        const double gp = a.prior_k * (q[ax] - a.prior_x0);
+                        g = a.prior_first ? gp + gl : gl + gp;
+                    }
+                    p[ax] = FMA ? __builtin_fma(-step, g, p[ax]) : p[ax] - step * g;
+                    if (e < a.nsteps)
+                        q[ax] = FMA ? __builtin_fma(p[ax], dt, q[ax]) : q[ax] + p[ax] * dt;
+                }
+                if (e < a.nsteps) sym_publish(sh, t, q);
+            }
+            __syncthreads();
+        }
+        if (owner) {
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) { qc[3 * t + ax] = q[ax]; pc[3 * t + ax] = p[ax]; }
+        }
     }
 }
 
@@ -677,6 +684,19 @@ using namespace binf;
 // Few chains (less than ~4 workgroups of 256 threads per CU): four lanes per
 // bead; many chains: one.  Both sum in the same order (bit-identical results).
 static int lanes_per_bead(int64_t C) { return C < 1024 ? 4 : 1; }
+
+// workgroups of the n <= 256 kernels: one per CU (each walks its share of the chains)
+static unsigned sym_grid(int64_t C)
+{
+    static int cus = 0;
+    if (cus <= 0) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+            cus = 256;
+    }
+    return (unsigned)(C < cus ? C : cus);
+}
 
 extern "C" int32_t binf_pairdist_forward_f64(const double *x, const int32_t *pair_i,
                                              const int32_t *pair_j, double *out,
@@ -746,11 +766,11 @@ extern "C" int32_t binf_pairdist_gauss_grad_f64(const double *x, const double *y
     const size_t lds = (size_t)n_beads * 3 * sizeof(double);
     hipStream_t gst = (hipStream_t)stream;
     if (n_beads == SYM_MAX_BEADS)
-        pairdist_grad_sym_kernel<true><<<dim3((unsigned)C), 1024, 0, gst>>>(
-            x, ymat, precision, precision_chain, out, (int32_t)n_beads);
+        pairdist_grad_sym_kernel<true><<<dim3(sym_grid(C)), 1024, 0, gst>>>(
+            x, ymat, precision, precision_chain, out, (int32_t)n_beads, C);
     else if (n_beads < SYM_MAX_BEADS)
-        pairdist_grad_sym_kernel<false><<<dim3((unsigned)C), 1024, 0, gst>>>(
-            x, ymat, precision, precision_chain, out, (int32_t)n_beads);
+        pairdist_grad_sym_kernel<false><<<dim3(sym_grid(C)), 1024, 0, gst>>>(
+            x, ymat, precision, precision_chain, out, (int32_t)n_beads, C);
     else if (n_beads <= 1024 && lanes_per_bead(C) == 4)
         pairdist_grad4_kernel<<<dim3((unsigned)C), 1024, lds, (hipStream_t)stream>>>(
             x, ymat, precision, precision_chain, out, (int32_t)n_beads);
@@ -785,7 +805,7 @@ extern "C" int32_t binf_pairdist_leapfrog_f64(double *q, double *p, const double
     a.q = q; a.p = p; a.ymat = ymat; a.tau_chain = precision_chain; a.dt_chain = dt_chain;
     a.tau = precision; a.timestep = timestep; a.prior_k = prior_k; a.prior_x0 = prior_x0;
     a.has_prior = has_prior ? 1 : 0; a.prior_first = prior_first ? 1 : 0;
-    a.nsteps = nsteps; a.n_beads = (int32_t)n_beads;
+    a.nsteps = nsteps; a.n_beads = (int32_t)n_beads; a.n_chains = C;
     const size_t lds = (size_t)n_beads * 3 * sizeof(double);
     dim3 grid((unsigned)C);
     hipStream_t st = (hipStream_t)stream;
@@ -794,12 +814,13 @@ extern "C" int32_t binf_pairdist_leapfrog_f64(double *q, double *p, const double
     const bool four = lanes_per_bead(C) == 4;
     if (n_beads <= SYM_MAX_BEADS) {
         const bool full = n_beads == SYM_MAX_BEADS;
+        const dim3 sgrid(sym_grid(C));
         if (fma) {
-            if (full) pairdist_leapfrog_sym_kernel<true, true><<<grid, 1024, 0, st>>>(a);
-            else      pairdist_leapfrog_sym_kernel<true, false><<<grid, 1024, 0, st>>>(a);
+            if (full) pairdist_leapfrog_sym_kernel<true, true><<<sgrid, 1024, 0, st>>>(a);
+            else      pairdist_leapfrog_sym_kernel<true, false><<<sgrid, 1024, 0, st>>>(a);
         } else {
-            if (full) pairdist_leapfrog_sym_kernel<false, true><<<grid, 1024, 0, st>>>(a);
-            else      pairdist_leapfrog_sym_kernel<false, false><<<grid, 1024, 0, st>>>(a);
+            if (full) pairdist_leapfrog_sym_kernel<false, true><<<sgrid, 1024, 0, st>>>(a);
+            else      pairdist_leapfrog_sym_kernel<false, false><<<sgrid, 1024, 0, st>>>(a);
         }
         hipError_t es = hipGetLastError();
         if (es != hipSuccess) return hip_fail(es, "pairdist_leapfrog launch");
