@@ -458,15 +458,12 @@ extern "C" int32_t binf_poly_gauss_logp_f64(const double *coeffs, const double *
     // up to 1024 data points a row is one lane group of a wave (8 .. 64 lanes; the
     // example's 20 points: 8 rows per wave instead of a 256-thread workgroup each,
     // 9.7 -> 3 us at 8192 chains); beyond, one workgroup per chain.  Same np.sum order.
-#define CALL(KM) rc = row_reduce_launch<ResidSqMake<KM>, PolyArgs>(a, C, N, 1.0, out, st, false, "poly_gauss_logp")
+    GaussFinish fin;                // the error model's log-prob is the reduction's epilogue
+    fin.on = 1; fin.tau = precision; fin.tau_chain = precision_chain; fin.n_data = (double)N;
+#define CALL(KM) rc = row_reduce_launch<ResidSqMake<KM>, PolyArgs>(a, C, N, 1.0, out, st, false, "poly_gauss_logp", 0, false, &fin)
     BINF_KMAX_DISPATCH(K, CALL);
 #undef CALL
-    if (rc) return rc;
-    gauss_logp_finish_kernel<<<dim3((unsigned)((C + 255) / 256)), 256, 0, st>>>(
-        out, precision, precision_chain, out, C, (double)N);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return hip_fail(e, "poly_gauss_logp launch");
-    return 0;
+    return rc;
 }
 
 extern "C" int64_t binf_poly_gauss_grad_workspace_bytes(int64_t C, int64_t K, int64_t N)

@@ -40,12 +40,32 @@ __device__ inline double leaf_sum_f(const F &f, int off, int n, int lane,
     return res;
 }
 
+// Optional epilogue of a chi^2 reduction: the Gaussian error model's log-prob
+//   lp[c] = -0.5 * chi2[c] * tau_c + N * 0.5 * log(tau_c)         likelihood.py:54-57
+// written by the reduction itself instead of a second launch.
+struct GaussFinish {
+    int32_t on;
+    double tau;
+    const double *tau_chain;
+    double n_data;
+};
+
 struct RowGeom {
     int64_t C;
     int32_t D;
     int32_t H;       // largest pairwise tree height among the row's 8192-element chunks
     double scale;
+    GaussFinish fin;
 };
+
+__device__ inline double row_result(const RowGeom &g, int64_t row, double sum)
+{
+    const double v = g.scale * sum;
+    if (!g.fin.on) return v;
+    const double t = g.fin.tau_chain ? g.fin.tau_chain[row] : g.fin.tau;
+    const double logZ = g.fin.n_data * 0.5 * log(t);
+    return -0.5 * v * t + logZ;
+}
 
 // FM: functor factory -- FM::make(args, row) returns the per-row element
 // functor; ARGS is passed by value as kernel argument.
@@ -71,7 +91,7 @@ row_reduce_wave_kernel(const ARGS args, const RowGeom g, double *out)
         const double s = res + o;
         res = (L.depth >= H - l) ? s : res;
     }
-    if (valid && slot == 0) out[row] = g.scale * (0.0 + res);
+    if (valid && slot == 0) out[row] = row_result(g, row, 0.0 + res);
 }
 
 // Any D: one 256-thread workgroup per row.  numpy's buffered reduction feeds
@@ -135,19 +155,22 @@ row_reduce_block_kernel(const ARGS args, const RowGeom g, double *out)
         total = total + S[0];
         __syncthreads();
     }
-    if (threadIdx.x == 0) out[row] = g.scale * total;
+    if (threadIdx.x == 0) out[row] = row_result(g, row, total);
 }
 
 template <class FM, class ARGS, bool STAGED = false>
 static int32_t row_reduce_launch(const ARGS &args, int64_t C, int64_t D,
                                  double scale, double *out, hipStream_t st,
                                  bool force_block, const char *what,
-                                 size_t staged_bytes = 0, bool wide = false)
+                                 size_t staged_bytes = 0, bool wide = false,
+                                 const GaussFinish *fin = nullptr)
 {
     if (C > 0x7fffffffLL || D > 0x7fffffffLL)
         return fail(BINF_E_UNSUPPORTED, "%s: too large", what);
     RowGeom g;
     g.C = C; g.D = (int32_t)D; g.scale = scale;
+    if (fin) g.fin = *fin;
+    else { g.fin.on = 0; g.fin.tau = 1.0; g.fin.tau_chain = nullptr; g.fin.n_data = 0.0; }
     g.H = pairwise_tree_height(D < NPY_BUFSIZE ? D : NPY_BUFSIZE);
     if (D > NPY_BUFSIZE && D % NPY_BUFSIZE != 0) {
         const int32_t h_last = pairwise_tree_height(D % NPY_BUFSIZE);
