@@ -68,6 +68,7 @@ SIGNATURES = {
                                         _i32, _i32, _f64, _f64, _i32, _vp]),
     'binf_clipped_exp_f64': (_i32, [_vp, _vp, _i64, _vp]),
     'binf_row_sum_f64': (_i32, [_vp, _vp, _i64, _i64, _i32, _f64, _f64, _vp]),
+    'binf_hmc_energy_f64': (_i32, [_vp, _vp, _vp, _i64, _i64, _vp]),
     'binf_leapfrog_kick_f64': (_i32, [_vp, _vp, _f64, _vp, _i32, _i64, _i64,
                                       _i32, _vp]),
     'binf_leapfrog_drift_f64': (_i32, [_vp, _vp, _f64, _vp, _i64, _i64, _i32,
@@ -289,6 +290,19 @@ def row_sum(x, op=ROW_SUM, shift=0.0, scale=1.0, out=None):
                                 float(shift), float(scale),
                                 stream_handle(x.device))
     check(rc, 'binf_row_sum_f64')
+    return out
+
+
+@_launcher
+def hmc_energy(p, log_prob):
+    """``-log_prob + 0.5 * np.sum(p**2)`` per chain (hmc.py:143,148,150), one
+    launch; ``log_prob`` is a contiguous ``[C]`` tensor."""
+    C, D = _cd(p)
+    out = torch.empty(C, dtype=torch.float64, device=p.device)
+    rc = lib().binf_hmc_energy_f64(dptr(p, numel=C * D, name='p'),
+                                   dptr(log_prob, numel=C, name='log_prob'), dptr(out), C, D,
+                                   stream_handle(p.device))
+    check(rc, 'binf_hmc_energy_f64')
     return out
 
 

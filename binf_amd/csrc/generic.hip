@@ -303,6 +303,23 @@ extern "C" int32_t binf_row_sum_f64(const double *x, double *out, int64_t C,
     }
 }
 
+// E[c] = -log_prob[c] + 0.5 * np.sum(p[c]**2) (hmc.py:143,148,150) in one launch:
+// the kinetic row sum with the subtraction as its epilogue.  (-lp) + k and k - lp
+// are the same IEEE operation, so the bits equal the three-launch form.
+extern "C" int32_t binf_hmc_energy_f64(const double *p, const double *log_prob, double *out,
+                                       int64_t C, int64_t D, void *stream)
+{
+    if (C < 0 || D < 0) return fail(BINF_E_ARG, "hmc_energy: negative size");
+    if (C == 0) return 0;
+    if ((!p && D > 0) || !log_prob || !out) return fail(BINF_E_ARG, "hmc_energy: null buffer");
+    RedArgs a;
+    a.x = p; a.y = nullptr; a.w = nullptr; a.shift = 0.0; a.D = D;
+    GaussFinish fin;
+    fin.on = 2; fin.tau = 1.0; fin.tau_chain = nullptr; fin.n_data = 0.0; fin.minus = log_prob;
+    return row_reduce_launch<RedMake<OP_SUMSQ>, RedArgs>(a, C, D, 0.5, out, (hipStream_t)stream, false,
+                                                        "hmc_energy", 0, false, &fin);
+}
+
 extern "C" int32_t binf_row_sumsq_diff_f64(const double *x, const double *y,
                                            const double *w, double *out,
                                            int64_t C, int64_t D, double scale,

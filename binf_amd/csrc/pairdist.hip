@@ -735,7 +735,7 @@ extern "C" int32_t binf_pairdist_gauss_logp_f64(const double *x, const int32_t *
     hipStream_t st = (hipStream_t)stream;
     int32_t rc;
     GaussFinish fin;                // lp = -0.5 chi2 tau + N/2 log tau, written by the reduction
-    fin.on = 1; fin.tau = precision; fin.tau_chain = precision_chain; fin.n_data = (double)n_pairs;
+    fin.on = 1; fin.minus = nullptr; fin.tau = precision; fin.tau_chain = precision_chain; fin.n_data = (double)n_pairs;
     if (n_beads <= 2048)            // 48 KiB of coordinates fit the static LDS budget
         // fewer rows than ~4 workgroups per CU: 16 waves per row instead of 4
         // (256 chains: 41 -> 30 us; 2048 chains: 141 vs 122 us, so not there)

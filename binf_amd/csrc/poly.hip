@@ -459,7 +459,7 @@ extern "C" int32_t binf_poly_gauss_logp_f64(const double *coeffs, const double *
     // example's 20 points: 8 rows per wave instead of a 256-thread workgroup each,
     // 9.7 -> 3 us at 8192 chains); beyond, one workgroup per chain.  Same np.sum order.
     GaussFinish fin;                // the error model's log-prob is the reduction's epilogue
-    fin.on = 1; fin.tau = precision; fin.tau_chain = precision_chain; fin.n_data = (double)N;
+    fin.on = 1; fin.minus = nullptr; fin.tau = precision; fin.tau_chain = precision_chain; fin.n_data = (double)N;
 #define CALL(KM) rc = row_reduce_launch<ResidSqMake<KM>, PolyArgs>(a, C, N, 1.0, out, st, false, "poly_gauss_logp", 0, false, &fin)
     BINF_KMAX_DISPATCH(K, CALL);
 #undef CALL

@@ -44,10 +44,11 @@ __device__ inline double leaf_sum_f(const F &f, int off, int n, int lane,
 //   lp[c] = -0.5 * chi2[c] * tau_c + N * 0.5 * log(tau_c)         likelihood.py:54-57
 // written by the reduction itself instead of a second launch.
 struct GaussFinish {
-    int32_t on;
+    int32_t on;              // 1: the log-prob above; 2: scale * sum - minus[row]
     double tau;
     const double *tau_chain;
     double n_data;
+    const double *minus;     // on == 2 (HMC energy: 0.5 sum p^2 - log_prob, hmc.py:148)
 };
 
 struct RowGeom {
@@ -62,6 +63,7 @@ __device__ inline double row_result(const RowGeom &g, int64_t row, double sum)
 {
     const double v = g.scale * sum;
     if (!g.fin.on) return v;
+    if (g.fin.on == 2) return v - g.fin.minus[row];
     const double t = g.fin.tau_chain ? g.fin.tau_chain[row] : g.fin.tau;
     const double logZ = g.fin.n_data * 0.5 * log(t);
     return -0.5 * v * t + logZ;
@@ -170,7 +172,7 @@ static int32_t row_reduce_launch(const ARGS &args, int64_t C, int64_t D,
     RowGeom g;
     g.C = C; g.D = (int32_t)D; g.scale = scale;
     if (fin) g.fin = *fin;
-    else { g.fin.on = 0; g.fin.tau = 1.0; g.fin.tau_chain = nullptr; g.fin.n_data = 0.0; }
+    else { g.fin.on = 0; g.fin.tau = 1.0; g.fin.tau_chain = nullptr; g.fin.n_data = 0.0; g.fin.minus = nullptr; }
     g.H = pairwise_tree_height(D < NPY_BUFSIZE ? D : NPY_BUFSIZE);
     if (D > NPY_BUFSIZE && D % NPY_BUFSIZE != 0) {
         const int32_t h_last = pairwise_tree_height(D % NPY_BUFSIZE);

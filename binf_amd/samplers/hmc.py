@@ -468,14 +468,17 @@ class HMCSampler(object):
         mode = _MODES[self.mode]
         shape = state.shape
         dtc = self._dt_chain
-        V = lambda x: -_as_chain_vector(pdf.log_prob(**{name: x.view(shape)})).contiguous()
+        # E = -log_prob + 0.5 sum p^2 (hmc.py:143,148,150): the kinetic row sum with the
+        # subtraction as its epilogue (one launch; the same bits as negate, sum, add)
+        E = lambda x, mom: _native.hmc_energy(
+            mom, _as_chain_vector(pdf.log_prob(**{name: x.view(shape)})).contiguous())
 
         q = q0.clone()
         p = p0 if own_p else p0.clone()
-        e_before = V(q) + _native.row_sum(p, _native.ROW_SUMSQ, scale=0.5)
+        e_before = E(q, p)
         self._leapfrog(q.view(shape), p.view(shape),
                        self._timestep if dtc is None else dtc, self.nsteps)
-        e_after = V(q) + _native.row_sum(p, _native.ROW_SUMSQ, scale=0.5)
+        e_after = E(q, p)
         _native.accept_select(q, q0, e_before, e_after, u, q, accepted,
                               self.n_accepted, dtc, adapt,
                               self.adaption_uprate, self.adaption_downrate)

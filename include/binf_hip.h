@@ -222,6 +222,14 @@ int32_t binf_hmc_gauss_rng_draws_f64(double *p0_out, double *u_out, int64_t C,
 int32_t binf_row_sum_f64(const double *x, double *out, int64_t C, int64_t D,
                          int32_t op, double shift, double scale, void *stream);
 
+/* HMCSampler.sample()'s energy (binf/samplers/hmc.py:143,148,150)
+ *   out[c] = -log_prob[c] + 0.5 * np.sum(p[c,:]**2)
+ * in one launch (the kinetic row sum in numpy's order, the subtraction as its
+ * epilogue; bit-identical to negating, summing and adding separately).
+ * p device [C*D], log_prob / out device [C] (out may alias log_prob). */
+int32_t binf_hmc_energy_f64(const double *p, const double *log_prob, double *out,
+                            int64_t C, int64_t D, void *stream);
+
 /* p[c,:] -= (half ? 0.5*dt : dt) * grad[c,:]     hmc.py:116,120,123
  * dt = dt_chain[c] if dt_chain != NULL else timestep. */
 int32_t binf_leapfrog_kick_f64(double *p, const double *grad, double timestep,

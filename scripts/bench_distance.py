@@ -30,7 +30,10 @@ cond = Posterior({lik.name: lik}, {prior.name: prior}).conditional_factory(preci
 
 
 def timed(fn, k):
-    fn(); torch.cuda.synchronize(); t = time.perf_counter()
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < 0.1:        # let the clocks settle under this load
+        fn(); torch.cuda.synchronize()
+    t = time.perf_counter()
     for _ in range(k):
         fn()
     torch.cuda.synchronize()
@@ -40,7 +43,7 @@ def timed(fn, k):
 t_g = timed(lambda: lik.gradient(coordinates=x, precision=4.0), 20)
 t_l = timed(lambda: lik.log_prob(coordinates=x, precision=4.0), 20)
 s = HMCSampler(cond, x, 0.002, L, variable_name='coordinates', rng=DeviceRNG(0, dev))
-t_h = timed(s.sample, 5)
+t_h = timed(s.sample, 30)
 print(json.dumps({'config': {'chains': C, 'beads': n, 'L': L},
                   'force_kernel_ms': t_g * 1e3, 'pair_interactions_per_s': C * n * n / t_g,
                   'logp_ms': t_l * 1e3, 'hmc_sample_ms': t_h * 1e3,

@@ -119,7 +119,7 @@ def c5_distance(dev, C=256, n=256, L=20):
     prior = IsotropicGaussian(0.05, 0.0, name='coordinates_prior', variable_name='coordinates')
     cond = Posterior({lik.name: lik}, {prior.name: prior}).conditional_factory(precision=4.0)
     from binf_amd import _native
-    t_g = _timed(lambda: lik.gradient(coordinates=x, precision=4.0), 20)
+    t_g = _timed(lambda: lik.gradient(coordinates=x, precision=4.0), 20, settle_s=0.1)
     # one force evaluation INSIDE the fused trajectory kernel: launch time against the
     # trajectory length (the target distances reach registers once per launch)
     ymat = lik.error_model.ymat_device(dev)
@@ -130,7 +130,7 @@ def c5_distance(dev, C=256, n=256, L=20):
                                                             1e-5, None, nst), 40, warm=5)
     t_e = (t_l[L] - t_l[1]) / (L - 1)
     s = HMCSampler(cond, x, 0.002, L, variable_name='coordinates', rng=DeviceRNG(0, dev))
-    t_h = _timed(s.sample, 5, warm=1)
+    t_h = _timed(s.sample, 30, warm=3, settle_s=0.1)
     pairs = float(C) * n * (n - 1)                # ordered pairs per force evaluation
     return {'workload': 'C5 share: %d beads x 3, %d chains, L=%d' % (n, C, L),
             'force_kernel_ms': t_g * 1e3,
