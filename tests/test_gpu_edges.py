@@ -104,6 +104,25 @@ def test_row_sum_many_rows_and_long_rows(device):
     assert np.array_equal(got, np.array([np.sum(r ** 2) for r in y]))
 
 
+@pytest.mark.parametrize('C,D', [(1, 1), (7, 5), (33, 129), (4, 1024), (3, 8200), (2, 20000)])
+def test_hmc_energy_is_the_three_step_expression_bitwise(device, C, D):
+    """binf_hmc_energy_f64 against hmc.py:143,148: -log_prob + 0.5 * np.sum(p**2),
+    including signed zeros and infinities of the log-prob."""
+    rs = np.random.RandomState(C + D)
+    p = rs.standard_normal((C, D))
+    lp = rs.standard_normal(C) * 100.0
+    lp[0] = -np.inf if C > 2 else lp[0]
+    if C > 3:
+        lp[1], lp[2] = 0.0, -0.0
+        p[2] = 0.0
+    got = _native.hmc_energy(dev_t(p, device), dev_t(lp, device)).cpu().numpy()
+    want = np.array([-lp[c] + 0.5 * np.sum(p[c] ** 2) for c in range(C)])
+    assert np.array_equal(got, want)
+    assert np.array_equal(np.signbit(got), np.signbit(want))
+    with pytest.raises(ValueError):
+        _native.hmc_energy(dev_t(p, device), dev_t(lp[:-1] if C > 1 else np.zeros(2), device))
+
+
 def test_non_contiguous_inputs_are_accepted(device):
     """A transposed state / momentum view and a user PDF that returns a
     non-contiguous gradient must give the same result as contiguous data."""
