@@ -31,6 +31,10 @@ for case in range(n_cases):
                          np.array([0.5 * np.sum(r ** 2) for r in x]))
     ok &= np.array_equal(_native.row_sumsq_diff(t(x), t(y), scale=-0.5, weights=t(w)).cpu().numpy(),
                          np.array([-0.5 * np.sum((r - y) ** 2 / w) for r in x]))
+    if D > 0:
+        lp = rs.standard_normal(C) * 10 ** rs.uniform(-2, 4)
+        ok &= np.array_equal(_native.hmc_energy(t(x), t(lp)).cpu().numpy(),
+                             np.array([-lp[c] + 0.5 * np.sum(x[c] ** 2) for c in range(C)]))
     if not ok:
         bad += 1
         print('MISMATCH row reduction', dict(D=D, C=C), flush=True)
