@@ -6,7 +6,7 @@ from binf_amd.example.misc import make_posterior
 from binf_amd.example.samplers import make_hmc_sampler
 from binf_amd.samplers import BinfState
 from binf_amd.samplers.rng import DeviceRNG
-dev = torch.device('cuda:0'); C = 4096
+dev = torch.device('cuda:0'); C = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 polynomial = np.polynomial.polynomial.polyval
 xses = np.linspace(-2, 2, 20)
 ys = np.random.RandomState(0).normal(loc=polynomial(xses, np.array([2., -4., 1., 1.5])), scale=1 / np.sqrt(2.5))
