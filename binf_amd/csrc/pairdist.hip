@@ -14,6 +14,7 @@
 // the chain's coordinates staged in LDS; the [3n x n(n-1)/2] Jacobian the
 // generic Likelihood path would need (200 MB per chain at n = 256) is never
 // formed.
+#include <stdlib.h>
 #include "rowsum.hpp"
 
 namespace binf {
@@ -399,18 +400,19 @@ __global__ void __launch_bounds__(256 * LANES) pairdist_leapfrog_kernel(const Pa
 }
 
 // ---------------------------------------------------------------------------
-// n_beads <= 256: every UNORDERED pair once, its target distance in a register.
+// 32 <= n_beads <= 256: every UNORDERED pair once, its target distance in a register.
 //
 // The all-pairs loops above give each lane the pairs (i, j = ...) of ITS bead and
 // read y[j][i] from memory for each: one CU streams the whole [n x n] target
 // matrix (512 KiB at n = 256) per force evaluation, and that stream -- not the
 // arithmetic -- is what a workgroup waits for (scripts/pairforce_probe.hip: 30 us
 // per evaluation with the loads, 10 us without, at any number of chains).  Here
-// a 1024-thread workgroup owns a chain and computes each pair {i, j} ONCE:
+// one workgroup owns a chain and computes each pair {i, j} ONCE:
 //
-//  * beads in 4 blocks of 64; the 10 unordered block pairs go to the 16 waves:
-//    waves 0-3 the diagonal blocks (b, b), waves 4-15 the six off-diagonal
-//    pairs (bi < bj), two waves each (the halves h = 0, 1 of the partner range);
+//  * beads in NBLK = ceil(n / 64) blocks of 64; the unordered block pairs go to
+//    NBLK^2 waves (n = 256: 16 waves, a 1024-thread workgroup): waves 0..NBLK-1 the
+//    diagonal blocks (b, b), the others the off-diagonal pairs (bi < bj), two
+//    waves each (the halves h = 0, 1 of the partner range);
 //  * lane l of a wave is ROW bead i = 64 bi + l for all of its 32 steps; at step
 //    k its partner is COLUMN bead j = 64 bj + (l + off + k) mod 64 (off = 32 h,
 //    or 1 on the diagonal, where step 31 -- partner l + 32 -- is done by lanes
@@ -431,14 +433,22 @@ __global__ void __launch_bounds__(256 * LANES) pairdist_leapfrog_kernel(const Pa
 //    n <= 256; the one-sided kernels above serve larger n).
 // ---------------------------------------------------------------------------
 constexpr int SYM_MAX_BEADS = 256;
+constexpr int SYM_MIN_BEADS = 32;        // fewer: most of the 32 steps would be masked (one-sided loops)
 constexpr int SYM_STEPS = 32;
 constexpr int SYM_ROWS = 8;              // rows of a wave's 64 x 64 target tile staged at a time
 
+// NBLK = ceil(n / 64) blocks of 64 beads -> NBLK^2 waves (NBLK diagonal blocks one wave
+// each, NBLK (NBLK - 1) / 2 off-diagonal pairs two waves each): a 64- / 256- / 576- /
+// 1024-thread workgroup.  A wave computes the same partial sums whatever NBLK is, a
+// bead's partials are added in slot order, and the slots of blocks that do not exist
+// would hold +0.0 and come last -- so choosing NBLK from n (small workgroups for few
+// beads: 16 / 4 chains per CU at a time instead of 1) does not change a bit.
+template <int NBLK>
 struct SymShared {
-    double sx[3][4][128];                // positions [axis][block][slot]; slots 64-127 repeat 0-63
+    double sx[3][NBLK][128];             // positions [axis][block][slot]; slots 64-127 repeat 0-63
     union {
-        double part[8][3][SYM_MAX_BEADS];    // partial forces [partner block * 2 + k][axis][bead]
-        double ytile[16][SYM_ROWS][64];      // launch prologue only
+        double part[2 * NBLK][3][64 * NBLK];     // partial forces [partner block * 2 + k][axis][bead]
+        double ytile[NBLK * NBLK][SYM_ROWS][64]; // launch prologue only
     } u;
 };
 
@@ -455,17 +465,19 @@ struct SymRole {
     bool diag;
 };
 
+template <int NBLK>
 __device__ inline SymRole sym_role()
 {
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     SymRole r;
-    if (wave < 4) {
+    if (wave < NBLK) {
         r.bi = wave; r.bj = wave; r.h = 0; r.off = 1; r.diag = true;
     } else {
-        const int pr = (wave - 4) >> 1;            // (0,1) (0,2) (0,3) (1,2) (1,3) (2,3)
-        r.h = (wave - 4) & 1;
-        r.bi = pr < 3 ? 0 : (pr < 5 ? 1 : 2);
-        r.bj = pr < 3 ? pr + 1 : (pr < 5 ? pr - 1 : 3);
+        int rem = (wave - NBLK) >> 1;              // pairs in the order (0,1) (0,2) .. (1,2) ..
+        r.h = (wave - NBLK) & 1;
+        r.bi = 0;
+        while (rem >= NBLK - 1 - r.bi) { rem -= NBLK - 1 - r.bi; ++r.bi; }
+        r.bj = r.bi + 1 + rem;
         r.off = 32 * r.h;
         r.diag = false;
     }
@@ -474,7 +486,8 @@ __device__ inline SymRole sym_role()
 
 // The lane's 32 target distances y[k] = ymat[64 bi + l][64 bj + (l + off + k) mod 64]
 // (0 where a bead does not exist), and the bit mask of its pairs that do exist.
-__device__ inline void sym_load_targets(double (&y)[SYM_STEPS], unsigned &live, SymShared &sh,
+template <int NBLK>
+__device__ inline void sym_load_targets(double (&y)[SYM_STEPS], unsigned &live, SymShared<NBLK> &sh,
                                         const double *ymat, int n, const SymRole &ro)
 {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -522,9 +535,9 @@ __device__ inline void sym_load_targets(double (&y)[SYM_STEPS], unsigned &live, 
 
 // One force evaluation: this wave's partial sums to sh.u.part.  Positions must be
 // in sh.sx (both copies); the caller synchronises before reading the partials.
-// FULL: n == 256, every pair exists except the diagonal waves' last half step.
-template <bool FULL>
-__device__ inline void sym_partials(const double (&y)[SYM_STEPS], unsigned live, SymShared &sh,
+// FULL: n == 64 NBLK, every pair exists except the diagonal waves' last half step.
+template <bool FULL, int NBLK>
+__device__ inline void sym_partials(const double (&y)[SYM_STEPS], unsigned live, SymShared<NBLK> &sh,
                                     int n, const SymRole &ro)
 {
     const int lane = threadIdx.x & 63;
@@ -564,19 +577,21 @@ __device__ inline void sym_partials(const double (&y)[SYM_STEPS], unsigned live,
     sh.u.part[slotR][0][bR] = R0; sh.u.part[slotR][1][bR] = R1; sh.u.part[slotR][2][bR] = R2;
 }
 
-// Owner thread t (< 256) of bead t: the bead's force, partials added in slot order.
-__device__ inline void sym_reduce(const SymShared &sh, int t, double (&f)[3])
+// Owner thread t (< 64 NBLK) of bead t: the bead's force, partials added in slot order.
+template <int NBLK>
+__device__ inline void sym_reduce(const SymShared<NBLK> &sh, int t, double (&f)[3])
 {
 #pragma unroll
     for (int ax = 0; ax < 3; ++ax) {
         double v = sh.u.part[0][ax][t];
 #pragma unroll
-        for (int sl = 1; sl < 8; ++sl) v = v + sh.u.part[sl][ax][t];
+        for (int sl = 1; sl < 2 * NBLK; ++sl) v = v + sh.u.part[sl][ax][t];
         f[ax] = v;
     }
 }
 
-__device__ inline void sym_publish(SymShared &sh, int t, const double (&q)[3])
+template <int NBLK>
+__device__ inline void sym_publish(SymShared<NBLK> &sh, int t, const double (&q)[3])
 {
 #pragma unroll
     for (int ax = 0; ax < 3; ++ax) {
@@ -586,34 +601,35 @@ __device__ inline void sym_publish(SymShared &sh, int t, const double (&q)[3])
 }
 
 // A workgroup loads its target distances once and then walks chains blockIdx.x,
-// blockIdx.x + gridDim.x, ...: the launchers start one workgroup per CU (a
-// 1024-thread workgroup with 126 VGPRs fills a CU), so with more chains than CUs
-// the target load is paid once per CU, not once per chain.
-template <bool FULL>
+// blockIdx.x + gridDim.x, ...: the launchers start as many workgroups as the chip
+// holds at a time (126 VGPRs: 16 waves per CU), so with more chains than that the
+// target load is paid once per workgroup, not once per chain.
+// __launch_bounds__(1024) whatever NBLK: it is what keeps the kernel within 128 VGPRs.
+template <bool FULL, int NBLK>
 __global__ void __launch_bounds__(1024)
 pairdist_grad_sym_kernel(const double *x, const double *ymat, double tau, const double *tau_chain,
                          double *out, int32_t n_beads, int64_t n_chains)
 {
-    __shared__ SymShared sh;
+    __shared__ SymShared<NBLK> sh;
     const int n = n_beads, t = threadIdx.x;
-    const SymRole ro = sym_role();
+    const SymRole ro = sym_role<NBLK>();
     double y[SYM_STEPS];
     unsigned live;
-    sym_load_targets(y, live, sh, ymat, n, ro);
+    sym_load_targets<NBLK>(y, live, sh, ymat, n, ro);
     for (int64_t c = blockIdx.x; c < n_chains; c += gridDim.x) {
         const double *xc = x + c * 3 * (int64_t)n;
-        if (t < SYM_MAX_BEADS) {
+        if (t < 64 * NBLK) {
             double q[3];
 #pragma unroll
             for (int ax = 0; ax < 3; ++ax) q[ax] = (t < n) ? xc[3 * t + ax] : 0.0;
-            sym_publish(sh, t, q);
+            sym_publish<NBLK>(sh, t, q);
         }
         __syncthreads();
-        sym_partials<FULL>(y, live, sh, n, ro);
+        sym_partials<FULL, NBLK>(y, live, sh, n, ro);
         __syncthreads();
         if (t < n) {
             double f[3];
-            sym_reduce(sh, t, f);
+            sym_reduce<NBLK>(sh, t, f);
             const double tc = tau_chain ? tau_chain[c] : tau;
             double *o = out + c * 3 * (int64_t)n + 3 * t;
             o[0] = tc * f[0]; o[1] = tc * f[1]; o[2] = tc * f[2];
@@ -623,16 +639,16 @@ pairdist_grad_sym_kernel(const double *x, const double *ymat, double tau, const 
 
 // The whole _leapfrog() (binf/samplers/hmc.py:92-125) in one launch with the
 // scheme above: owner threads keep q and p of their bead in registers.
-template <bool FMA, bool FULL>
+template <bool FMA, bool FULL, int NBLK>
 __global__ void __launch_bounds__(1024) pairdist_leapfrog_sym_kernel(const PairLeapArgs a)
 {
-    __shared__ SymShared sh;
+    __shared__ SymShared<NBLK> sh;
     const int n = a.n_beads, t = threadIdx.x;
-    const SymRole ro = sym_role();
+    const SymRole ro = sym_role<NBLK>();
     const bool owner = t < n;
     double y[SYM_STEPS];
     unsigned live;
-    sym_load_targets(y, live, sh, a.ymat, n, ro);
+    sym_load_targets<NBLK>(y, live, sh, a.ymat, n, ro);
     for (int64_t c = blockIdx.x; c < a.n_chains; c += gridDim.x) {
         double *qc = a.q + c * 3 * (int64_t)n;
         double *pc = a.p + c * 3 * (int64_t)n;
@@ -644,15 +660,15 @@ __global__ void __launch_bounds__(1024) pairdist_leapfrog_sym_kernel(const PairL
 #pragma unroll
             for (int ax = 0; ax < 3; ++ax) { q[ax] = qc[3 * t + ax]; p[ax] = pc[3 * t + ax]; }
         }
-        if (t < SYM_MAX_BEADS) sym_publish(sh, t, q);
+        if (t < 64 * NBLK) sym_publish<NBLK>(sh, t, q);
         __syncthreads();
         // nsteps + 1 force evaluations: half kick, (nsteps - 1) x [drift, kick], drift, half kick
         for (int e = 0; e <= a.nsteps; ++e) {
-            sym_partials<FULL>(y, live, sh, n, ro);
+            sym_partials<FULL, NBLK>(y, live, sh, n, ro);
             __syncthreads();
             if (owner) {
                 double f[3];
-                sym_reduce(sh, t, f);
+                sym_reduce<NBLK>(sh, t, f);
                 const double step = (e == 0 || e == a.nsteps) ? hdt : dt;
 #pragma unroll
                 for (int ax = 0; ax < 3; ++ax) {
@@ -666,7 +682,7 @@ __global__ void __launch_bounds__(1024) pairdist_leapfrog_sym_kernel(const PairL
                     if (e < a.nsteps)
                         q[ax] = FMA ? __builtin_fma(p[ax], dt, q[ax]) : q[ax] + p[ax] * dt;
                 }
-                if (e < a.nsteps) sym_publish(sh, t, q);
+                if (e < a.nsteps) sym_publish<NBLK>(sh, t, q);
             }
             __syncthreads();
         }
@@ -686,7 +702,21 @@ using namespace binf;
 static int lanes_per_bead(int64_t C) { return C < 1024 ? 4 : 1; }
 
 // workgroups of the n <= 256 kernels: one per CU (each walks its share of the chains)
-static unsigned sym_grid(int64_t C)
+// development aid: BINF_PD_SYM=0 sends n <= 256 to the one-sided kernels as well
+static bool sym_enabled()
+{
+    static int on = -1;
+    if (on < 0) {
+        const char *e = getenv("BINF_PD_SYM");
+        on = (e && e[0] == '0') ? 0 : 1;
+    }
+    return on != 0;
+}
+
+// workgroups of the n <= 256 kernels: as many as the chip holds at a time (16 waves per
+// CU at 126 VGPRs: 16 / 4 / 1 / 1 workgroups of 1 / 4 / 9 / 16 waves); each walks its
+// share of the chains
+static unsigned sym_grid(int64_t C, int nblk)
 {
     static int cus = 0;
     if (cus <= 0) {
@@ -695,7 +725,36 @@ static unsigned sym_grid(int64_t C)
             hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
             cus = 256;
     }
-    return (unsigned)(C < cus ? C : cus);
+    const int64_t slots = (int64_t)cus * (nblk == 1 ? 16 : (nblk == 2 ? 4 : 1));
+    return (unsigned)(C < slots ? C : slots);
+}
+
+template <int NBLK>
+static void launch_grad_sym(const double *x, const double *ymat, double precision,
+                            const double *precision_chain, double *out, int64_t C, int64_t n,
+                            hipStream_t st)
+{
+    const dim3 grid(sym_grid(C, NBLK)), block(64 * NBLK * NBLK);
+    if (n == 64 * NBLK)
+        pairdist_grad_sym_kernel<true, NBLK><<<grid, block, 0, st>>>(x, ymat, precision, precision_chain,
+                                                                     out, (int32_t)n, C);
+    else
+        pairdist_grad_sym_kernel<false, NBLK><<<grid, block, 0, st>>>(x, ymat, precision, precision_chain,
+                                                                      out, (int32_t)n, C);
+}
+
+template <int NBLK>
+static void launch_leapfrog_sym(const PairLeapArgs &a, bool fma, hipStream_t st)
+{
+    const dim3 grid(sym_grid(a.n_chains, NBLK)), block(64 * NBLK * NBLK);
+    const bool full = a.n_beads == 64 * NBLK;
+    if (fma) {
+        if (full) pairdist_leapfrog_sym_kernel<true, true, NBLK><<<grid, block, 0, st>>>(a);
+        else      pairdist_leapfrog_sym_kernel<true, false, NBLK><<<grid, block, 0, st>>>(a);
+    } else {
+        if (full) pairdist_leapfrog_sym_kernel<false, true, NBLK><<<grid, block, 0, st>>>(a);
+        else      pairdist_leapfrog_sym_kernel<false, false, NBLK><<<grid, block, 0, st>>>(a);
+    }
 }
 
 extern "C" int32_t binf_pairdist_forward_f64(const double *x, const int32_t *pair_i,
@@ -763,12 +822,13 @@ extern "C" int32_t binf_pairdist_gauss_grad_f64(const double *x, const double *y
         return fail(BINF_E_UNSUPPORTED, "pairdist_gauss_grad: too large");
     const size_t lds = (size_t)n_beads * 3 * sizeof(double);
     hipStream_t gst = (hipStream_t)stream;
-    if (n_beads == SYM_MAX_BEADS)
-        pairdist_grad_sym_kernel<true><<<dim3(sym_grid(C)), 1024, 0, gst>>>(
-            x, ymat, precision, precision_chain, out, (int32_t)n_beads, C);
-    else if (n_beads < SYM_MAX_BEADS)
-        pairdist_grad_sym_kernel<false><<<dim3(sym_grid(C)), 1024, 0, gst>>>(
-            x, ymat, precision, precision_chain, out, (int32_t)n_beads, C);
+    if (n_beads >= SYM_MIN_BEADS && n_beads <= SYM_MAX_BEADS && sym_enabled()) {
+        const int nblk = (int)((n_beads + 63) / 64);
+        if (nblk == 1)      launch_grad_sym<1>(x, ymat, precision, precision_chain, out, C, n_beads, gst);
+        else if (nblk == 2) launch_grad_sym<2>(x, ymat, precision, precision_chain, out, C, n_beads, gst);
+        else if (nblk == 3) launch_grad_sym<3>(x, ymat, precision, precision_chain, out, C, n_beads, gst);
+        else                launch_grad_sym<4>(x, ymat, precision, precision_chain, out, C, n_beads, gst);
+    }
     else if (n_beads <= 1024 && lanes_per_bead(C) == 4)
         pairdist_grad4_kernel<<<dim3((unsigned)C), 1024, lds, (hipStream_t)stream>>>(
             x, ymat, precision, precision_chain, out, (int32_t)n_beads);
@@ -810,16 +870,12 @@ extern "C" int32_t binf_pairdist_leapfrog_f64(double *q, double *p, const double
     const bool fma = mode == BINF_MODE_FMA;
     const int nb = (int)((n_beads + 255) / 256);
     const bool four = lanes_per_bead(C) == 4;
-    if (n_beads <= SYM_MAX_BEADS) {
-        const bool full = n_beads == SYM_MAX_BEADS;
-        const dim3 sgrid(sym_grid(C));
-        if (fma) {
-            if (full) pairdist_leapfrog_sym_kernel<true, true><<<sgrid, 1024, 0, st>>>(a);
-            else      pairdist_leapfrog_sym_kernel<true, false><<<sgrid, 1024, 0, st>>>(a);
-        } else {
-            if (full) pairdist_leapfrog_sym_kernel<false, true><<<sgrid, 1024, 0, st>>>(a);
-            else      pairdist_leapfrog_sym_kernel<false, false><<<sgrid, 1024, 0, st>>>(a);
-        }
+    if (n_beads >= SYM_MIN_BEADS && n_beads <= SYM_MAX_BEADS && sym_enabled()) {
+        const int nblk = (int)((n_beads + 63) / 64);
+        if (nblk == 1)      launch_leapfrog_sym<1>(a, fma, st);
+        else if (nblk == 2) launch_leapfrog_sym<2>(a, fma, st);
+        else if (nblk == 3) launch_leapfrog_sym<3>(a, fma, st);
+        else                launch_leapfrog_sym<4>(a, fma, st);
         hipError_t es = hipGetLastError();
         if (es != hipSuccess) return hip_fail(es, "pairdist_leapfrog launch");
         return 0;

@@ -45,8 +45,9 @@ def test_forward_distances_bitwise(device, n, C):
 
 @pytest.mark.parametrize('n,C', [(3, 5), (10, 17), (64, 9), (256, 6), (300, 2),
                                  # around the 64-bead blocks of the n <= 256 force scheme
-                                 (2, 2), (63, 3), (65, 3), (127, 2), (128, 2), (129, 2), (191, 2),
-                                 (192, 2), (193, 2), (255, 2), (257, 2)])
+                                 # (32 .. 256 beads; below and above, the one-sided loops)
+                                 (2, 2), (31, 3), (32, 3), (33, 3), (63, 3), (65, 3), (127, 2), (128, 2),
+                                 (129, 2), (191, 2), (192, 2), (193, 2), (255, 2), (257, 2)])
 def test_likelihood_logp_and_force(device, n, C):
     ys, x = synth(n, C, n + 1)
     L = make_distance_likelihood(ys, n)
@@ -156,14 +157,15 @@ def test_leapfrog_spec_rejects_unsupported_structures(device):
     assert post.conditional_factory(precision=1.0).native_leapfrog_spec('coefficients') is None
 
 
-@pytest.mark.parametrize('n', [64, 200, 256, 300])
+@pytest.mark.parametrize('n', [24, 40, 64, 100, 150, 200, 256, 300])
 def test_force_is_independent_of_the_batch_size(device, n):
     """A chain's force and trajectory do not depend on how many other chains
-    share the launch: up to 256 beads every batch size runs the same
-    one-workgroup-per-chain scheme (a summation order fixed by n alone); above,
-    few chains use four lanes per bead and many chains one, and both add in the
-    same order."""
-    ys, x = synth(n, 1100, 7)
+    share the launch: from 32 to 256 beads every batch size runs the same
+    one-workgroup-per-chain scheme (1, 4, 9 or 16 waves by the bead count; a
+    summation order fixed by n alone, workgroups walking several chains when
+    there are more chains than the chip holds); outside that range, few chains
+    use four lanes per bead and many chains one, and both add in the same order."""
+    ys, x = synth(n, 1100 if n > 64 else 5000, 7)     # more chains than workgroup slots on the chip
     L_ = make_distance_likelihood(ys, n)
     big = L_.gradient(coordinates=dev_t(x, device), precision=2.0).cpu().numpy()
     small = L_.gradient(coordinates=dev_t(x[:40], device), precision=2.0).cpu().numpy()
@@ -177,11 +179,11 @@ def test_force_is_independent_of_the_batch_size(device, n):
 
 
 def test_force_counts_every_pair_once_in_each_direction(device):
-    """The n <= 256 scheme evaluates an unordered pair once and books it on both
+    """The 32 <= n <= 256 scheme evaluates an unordered pair once and books it on both
     beads.  With all targets 0 the pair weight is exactly 1, so the force on
     bead i is sum_j (x_i - x_j): integer coordinates make every partial sum
     exact, and any pair dropped, doubled or booked on the wrong bead shows."""
-    for n in (2, 31, 64, 65, 130, 200, 256):
+    for n in (2, 31, 32, 33, 64, 65, 128, 130, 192, 200, 256):
         rs = np.random.RandomState(n)
         x = rs.randint(-50, 50, size=(3, n, 3)).astype(np.float64)
         # distinct beads (a zero distance has no direction)
