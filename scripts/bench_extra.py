@@ -102,7 +102,8 @@ def c4_gibbs(dev, C=4096, K=33, N=16384, L=20):
 
 
 def c5_distance(dev, C=256, n=256, L=20):
-    """C5 per-GPU share: 3 x 256 coordinates, 256 chains (= 2048 / 8)."""
+    """C5: 3 x 256 coordinates; 256 chains = the per-GPU share of its 2048 chains on 8 GPUs
+    (2048: the whole configuration on one GPU)."""
     from binf_amd.example.distance import make_distance_likelihood
     from binf_amd.pdf import IsotropicGaussian
     from binf_amd.pdf.posteriors import Posterior
@@ -132,7 +133,7 @@ def c5_distance(dev, C=256, n=256, L=20):
     s = HMCSampler(cond, x, 0.002, L, variable_name='coordinates', rng=DeviceRNG(0, dev))
     t_h = _timed(s.sample, 30, warm=3, settle_s=0.1)
     pairs = float(C) * n * (n - 1)                # ordered pairs per force evaluation
-    return {'workload': 'C5 share: %d beads x 3, %d chains, L=%d' % (n, C, L),
+    return {'workload': 'C5%s: %d beads x 3, %d chains, L=%d' % (' share' if C < 2048 else ' on one GPU', n, C, L),
             'force_kernel_ms': t_g * 1e3,
             'leapfrog_kernel_ms': t_l[L] * 1e3,
             'force_eval_in_trajectory_us': t_e * 1e6,
@@ -199,6 +200,7 @@ def c2_strong_scaling_shares(dev, D=1024, L=20, F=64):
 def run_all(dev):
     res = {}
     for name, fn in (('C3', c3_polynomial), ('C4', c4_gibbs), ('C5', c5_distance),
+                     ('C5_2048_chains', lambda d: c5_distance(d, C=2048)),
                      ('C2_device_rng', c2_device_rng),
                      ('C2_strong_scaling_shares', c2_strong_scaling_shares)):
         try:
