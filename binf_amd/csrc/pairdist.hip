@@ -796,12 +796,13 @@ extern "C" int32_t binf_pairdist_gauss_logp_f64(const double *x, const int32_t *
     GaussFinish fin;                // lp = -0.5 chi2 tau + N/2 log tau, written by the reduction
     fin.on = 1; fin.minus = nullptr; fin.tau = precision; fin.tau_chain = precision_chain; fin.n_data = (double)n_pairs;
     if (n_beads <= 2048)            // 48 KiB of coordinates fit the static LDS budget
-        // fewer rows than ~4 workgroups per CU: 16 waves per row instead of 4
+        // fewer rows than ~4 workgroups per CU (and rows long enough to feed them):
+        // 16 waves per row instead of 4
         // (256 chains: 41 -> 30 us; 2048 chains: 141 vs 122 us, so not there)
         rc = row_reduce_launch<PairResidMake, PairArgs, true>(a, C, n_pairs, 1.0, out, st, true,
                                                              "pairdist_gauss_logp",
                                                              (size_t)n_beads * 3 * sizeof(double),
-                                                             C < 1024, &fin);
+                                                             C < 1024 && n_pairs >= 2048, &fin);
     else
         rc = row_reduce_launch<PairResidMake, PairArgs>(a, C, n_pairs, 1.0, out, st, true,
                                                        "pairdist_gauss_logp", 0, false, &fin);
