@@ -10,10 +10,14 @@
 //   forward : d_p = sqrt(((xi-xj)**2).sum()) for pair p = (i<j) in np.triu order
 //   energy gradient w.r.t. bead i:  tau * sum_{j != i} (d_ij - y_ij) (x_i - x_j)/d_ij
 //
-// The force kernel is the O(n^2) all-pairs loop, one workgroup per chain with
-// the chain's coordinates staged in LDS; the [3n x n(n-1)/2] Jacobian the
-// generic Likelihood path would need (200 MB per chain at n = 256) is never
-// formed.
+// Force kernels (the [3n x n(n-1)/2] Jacobian the generic Likelihood path would
+// need -- 200 MB per chain at n = 256 -- is never formed):
+//   32 <= n <= 256  every unordered pair once, target distances in registers, one
+//                   workgroup of 1 / 4 / 9 / 16 waves per chain (second half of this file);
+//   other n         one-sided all-pairs loops, the chain's coordinates staged in LDS,
+//                   target distances read from a symmetric [n x n] matrix.
+// Each has a force-only kernel and a fused leapfrog (the whole _leapfrog() of
+// binf/samplers/hmc.py:92-125 in one launch) that are bit-identical to each other.
 #include <stdlib.h>
 #include "rowsum.hpp"
 
