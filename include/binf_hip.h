@@ -399,8 +399,12 @@ int32_t binf_pairdist_gauss_logp_f64(const double *x, const int32_t *pair_i,
 /* Energy gradient of the Gaussian restraint likelihood,
  *   out[c, 3i+a] = precision_c * sum_{j != i} (d_ij - ymat[j][i]) (x_i - x_j)[a] / d_ij,
  * i.e. Likelihood._evaluate_gradient (binf/pdf/likelihoods.py:148-155) without
- * forming the [3n x n(n-1)/2] Jacobian: all-pairs loop, coordinates in LDS.
- * ymat: device, symmetric [n_beads x n_beads] target distances. */
+ * forming the [3n x n(n-1)/2] Jacobian (coordinates in LDS; 32..256 beads: every
+ * unordered pair once with its target distance in a register, otherwise
+ * one-sided all-pairs loops).  Held to 1e-10 of the numpy expression; the
+ * summation order depends on n_beads only, so a chain's result does not depend on
+ * C.  ymat: device, SYMMETRIC [n_beads x n_beads] target distances (ymat[i][j] ==
+ * ymat[j][i] is relied upon; the diagonal is ignored). */
 int32_t binf_pairdist_gauss_grad_f64(const double *x, const double *ymat,
                                      double precision, const double *precision_chain,
                                      double *out, int64_t C, int64_t n_beads,
