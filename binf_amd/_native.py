@@ -69,6 +69,7 @@ SIGNATURES = {
     'binf_clipped_exp_f64': (_i32, [_vp, _vp, _i64, _vp]),
     'binf_row_sum_f64': (_i32, [_vp, _vp, _i64, _i64, _i32, _f64, _f64, _vp]),
     'binf_hmc_energy_f64': (_i32, [_vp, _vp, _vp, _i64, _i64, _vp]),
+    'binf_gamma_logp_f64': (_i32, [_vp, _f64, _f64, _vp, _i64, _vp]),
     'binf_leapfrog_kick_f64': (_i32, [_vp, _vp, _f64, _vp, _i32, _i64, _i64,
                                       _i32, _vp]),
     'binf_leapfrog_drift_f64': (_i32, [_vp, _vp, _f64, _vp, _i64, _i64, _i32,
@@ -544,6 +545,18 @@ def gamma_precision_update(g, lp_unit, prior_rate):
         dptr(g, numel=C, name='g'), dptr(lp_unit, numel=C, name='lp_unit'),
         float(prior_rate), dptr(out), C, stream_handle(g.device))
     check(rc, 'binf_gamma_precision_update_f64')
+    return out
+
+
+@_launcher
+def gamma_logp(precision, shape, rate):
+    """``(shape - 1) * log(precision) - precision * rate`` per chain
+    (priors.py:10-25), one launch."""
+    C = precision.numel()
+    out = torch.empty(precision.shape, dtype=torch.float64, device=precision.device)
+    rc = lib().binf_gamma_logp_f64(dptr(precision, numel=C, name='precision'), float(shape),
+                                   float(rate), dptr(out), C, stream_handle(precision.device))
+    check(rc, 'binf_gamma_logp_f64')
     return out
 
 

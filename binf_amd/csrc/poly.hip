@@ -108,6 +108,16 @@ __global__ void gamma_update_kernel(const double *g, const double *lp1,
     out[c] = g[c] / rate;
 }
 
+// GammaPrior._evaluate_log_prob: (shape - 1) * log(tau) - tau * rate      priors.py:10-25
+__global__ void gamma_logp_kernel(const double *tau, double shape_m1, double rate, double *out,
+                                  int64_t C)
+{
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const double t = tau[c];
+    out[c] = shape_m1 * log(t) - t * rate;
+}
+
 // ---------------------------------------------------------------------------
 // gradient: two chained f64 MFMA products per (16 data points x 16 chains)
 // ---------------------------------------------------------------------------
@@ -464,6 +474,19 @@ extern "C" int32_t binf_poly_gauss_logp_f64(const double *coeffs, const double *
     BINF_KMAX_DISPATCH(K, CALL);
 #undef CALL
     return rc;
+}
+
+extern "C" int32_t binf_gamma_logp_f64(const double *precision, double shape, double rate,
+                                       double *out, int64_t C, void *stream)
+{
+    if (C < 0) return fail(BINF_E_ARG, "gamma_logp: negative size");
+    if (C == 0) return 0;
+    if (!precision || !out) return fail(BINF_E_ARG, "gamma_logp: null buffer");
+    gamma_logp_kernel<<<dim3((unsigned)((C + 255) / 256)), 256, 0, (hipStream_t)stream>>>(
+        precision, shape - 1.0, rate, out, C);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "gamma_logp launch");
+    return 0;
 }
 
 extern "C" int64_t binf_poly_gauss_grad_workspace_bytes(int64_t C, int64_t K, int64_t N)

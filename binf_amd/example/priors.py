@@ -25,6 +25,10 @@ class GammaPrior(AbstractPrior):
         self._set_original_variables()
 
     def _evaluate_log_prob(self, precision):
+        if isinstance(precision, torch.Tensor) and precision.is_cuda and \
+                precision.dtype == torch.float64 and precision.is_contiguous():
+            # one launch instead of four torch ops, the same roundings
+            return _native.gamma_logp(precision, self.shape, self.rate)
         log = torch.log if isinstance(precision, torch.Tensor) else np.log
         return (self.shape - 1.0) * log(precision) - precision * self.rate
 

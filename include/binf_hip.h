@@ -366,6 +366,13 @@ int32_t binf_hmc_sample_poly_f64(const double *q0, const double *p0,
                                  double uprate, double downrate, int32_t mode,
                                  void *stream);
 
+/* GammaPrior._evaluate_log_prob (binf/example/priors.py:10-25), one value per chain:
+ *   out[c] = (shape - 1) * log(precision[c]) - precision[c] * rate
+ * (each operation rounded on its own, as the numpy / torch expression).
+ * precision / out device [C] (out may alias precision). */
+int32_t binf_gamma_logp_f64(const double *precision, double shape, double rate,
+                            double *out, int64_t C, void *stream);
+
 /* Conjugate precision draw, GammaSampler.sample (binf/example/samplers.py:34-51):
  * out[c] = g[c] / (-lp_unit[c] + prior_rate), g = supplied Gamma(shape) variates,
  * lp_unit = likelihood log-prob evaluated at precision = 1. */

@@ -800,3 +800,22 @@ def test_c4_full_size_gibbs_sweep(device):
             want = ref['coefficients'][s]
             assert np.all(np.abs(got[s][0][c] - want) <= bounds[s]['bq'] + 4 * PB.U * np.abs(want)), (c, s)
             assert abs(got[s][1][c] - ref['precision'][s]) <= bounds[s]['btau'] * ref['precision'][s], (c, s)
+
+
+def test_gamma_prior_log_prob_kernel_equals_the_expression(device):
+    """binf_gamma_logp_f64 against the four-operation expression of
+    binf/example/priors.py:10-25 -- bit for bit vs the torch ops it replaces, and
+    within an ulp-level tolerance of numpy (whose log is a different libm)."""
+    from binf_amd.example.priors import GammaPrior
+    rs = np.random.RandomState(4)
+    for C in (1, 5, 257, 70001):
+        tau = np.concatenate([rs.uniform(1e-3, 50.0, size=C - 1), [1.0]]) if C > 1 else np.array([2.5])
+        t = dev_t(tau, device)
+        for shape, rate in ((1.0, 0.2), (3.5, 3.5), (0.3, 7.0)):
+            got = _native.gamma_logp(t, shape, rate)
+            want_t = (shape - 1.0) * torch.log(t) - t * rate
+            assert torch.equal(got, want_t)
+            want = (shape - 1.0) * np.log(tau) - tau * rate
+            assert np.allclose(got.cpu().numpy(), want, rtol=0, atol=4e-16 * np.maximum(1.0, np.abs(want)).max() * 8)
+            pr = GammaPrior(shape, rate)
+            assert torch.equal(pr.log_prob(precision=t), got)
