@@ -89,6 +89,10 @@ POLY_SETS = [
 DIST_SETS = [
     ('dist_n12', 12, 4, 2, 10, 0.01, 4.0, 0.05, 400),
     ('dist_n40', 40, 2, 2, 5, 0.004, 2.0, 0.0, 410),
+    # round 2: the every-pair-once force scheme (4 / 16 waves) and the size above it
+    ('dist_n100', 100, 2, 2, 4, 0.002, 3.0, 0.05, 420),
+    ('dist_n256', 256, 2, 2, 3, 0.001, 4.0, 0.05, 430),      # BASELINE C5's bead count
+    ('dist_n300', 300, 1, 2, 2, 0.001, 4.0, 0.0, 440),
 ]
 
 
