@@ -52,16 +52,16 @@ SIGNATURES = {
     'binf_hmc_sample_gauss_big_rng_f64': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _f64, _vp,
                                                  _i64, _i64, _i32, _f64, _f64, _i32,
                                                  _f64, _f64, _i32, ctypes.c_uint64,
-                                                 ctypes.c_uint64, _vp, _i64, _vp]),
+                                                 ctypes.c_uint64, _i64, _vp, _i64, _vp]),
     'binf_hmc_gauss_big_rng_draws_f64': (_i32, [_vp, _vp, _i64, _i64, ctypes.c_uint64,
-                                                ctypes.c_uint64, _vp]),
+                                                ctypes.c_uint64, _i64, _vp]),
     'binf_hmc_sample_n_gauss_rng_f64': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                                _f64, _vp, _i64, _i64, _i32, _i32,
                                                _i32, _f64, _f64, _i32, _f64, _f64,
                                                _i32, ctypes.c_uint64,
-                                               ctypes.c_uint64, _vp]),
+                                               ctypes.c_uint64, _i64, _vp]),
     'binf_hmc_gauss_rng_draws_f64': (_i32, [_vp, _vp, _i64, _i64, _i32,
-                                            ctypes.c_uint64, ctypes.c_uint64, _vp]),
+                                            ctypes.c_uint64, ctypes.c_uint64, _i64, _vp]),
     'binf_hmc_sample_poly_f64': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                         _vp, _vp, _f64, _vp, _vp, _vp, _i32,
                                         _vp, _vp, _f64, _vp, _i64, _i64, _i64,
@@ -102,13 +102,17 @@ SIGNATURES = {
                                           _f64, _i32, _f64, _vp, _i32, _i64,
                                           _i64, _i32, _vp]),
     'binf_rng_uniform_f64': (_i32, [_vp, _i64, ctypes.c_uint64, ctypes.c_uint64,
-                                    _vp]),
+                                    _i64, _vp]),
     'binf_rng_normal_f64': (_i32, [_vp, _i64, ctypes.c_uint64, ctypes.c_uint64,
-                                   _vp]),
+                                   _i64, _vp]),
     'binf_rng_normal_zig_f64': (_i32, [_vp, _i64, ctypes.c_uint64,
-                                       ctypes.c_uint64, _vp]),
+                                       ctypes.c_uint64, _i64, _vp]),
     'binf_rng_gamma_f64': (_i32, [_vp, _i64, _f64, ctypes.c_uint64,
-                                  ctypes.c_uint64, _vp]),
+                                  ctypes.c_uint64, _i64, _vp]),
+    'binf_rwmc_propose_f64': (_i32, [_vp, _vp, _vp, _f64, _i64, _i64, ctypes.c_uint64,
+                                     ctypes.c_uint64, _i64, _vp]),
+    'binf_rwmc_accept_f64': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64,
+                                    ctypes.c_uint64, ctypes.c_uint64, _i64, _vp]),
     'binf_rng_philox4x32_10': (_i32, [ctypes.POINTER(ctypes.c_uint32),
                                       ctypes.POINTER(ctypes.c_uint32),
                                       ctypes.POINTER(ctypes.c_uint32)]),
@@ -118,7 +122,7 @@ SIGNATURES = {
                                   ctypes.POINTER(_i32), ctypes.POINTER(_i32)]),
 }
 
-ABI_VERSION = 1
+ABI_VERSION = 2        # keep in step with BINF_ABI_VERSION (include/binf_hip.h)
 
 
 def lib():
@@ -619,7 +623,7 @@ def hmc_sample_gauss_big(q0, p0, u, q_out, accepted, n_accepted, e_before, e_aft
 @_launcher
 def hmc_sample_gauss_big_rng(q0, q_out, accepted, n_accepted, e_before, e_after, timestep,
                              dt_chain, nsteps, k, x0, adapt, uprate, downrate, mode, seed,
-                             offset):
+                             offset, chain_offset=0):
     """binf_hmc_sample_gauss_big_rng_f64 (long chains, draws generated in the
     kernels) on torch's current stream."""
     C, D = _cd(q0)
@@ -632,20 +636,21 @@ def hmc_sample_gauss_big_rng(q0, q_out, accepted, n_accepted, e_before, e_after,
         dptr(e_before, numel=C, name='e_before'), dptr(e_after, numel=C, name='e_after'),
         float(timestep), dptr(dt_chain, numel=C, name='dt_chain'), C, D, int(nsteps),
         float(k), float(x0), int(bool(adapt)), float(uprate), float(downrate), int(mode),
-        int(seed) & (2 ** 64 - 1), int(offset) & (2 ** 64 - 1), dptr(ws), nbytes,
-        stream_handle(q0.device))
+        int(seed) & (2 ** 64 - 1), int(offset) & (2 ** 64 - 1), int(chain_offset), dptr(ws),
+        nbytes, stream_handle(q0.device))
     check(rc, 'binf_hmc_sample_gauss_big_rng_f64')
 
 
-def hmc_gauss_big_rng_draws(C, D, seed, offset, device):
-    """(p0 [C, D], u [C]): the draws hmc_sample_gauss_big_rng consumes."""
+def hmc_gauss_big_rng_draws(C, D, seed, offset, device, chain_offset=0):
+    """(p0 [C, D], u [C]): the draws hmc_sample_gauss_big_rng consumes for global
+    chains ``chain_offset .. chain_offset + C - 1``."""
     C, D = int(C), int(D)
     p0 = torch.empty((C, D), dtype=torch.float64, device=device)
     u = torch.empty(C, dtype=torch.float64, device=device)
     with torch.cuda.device(p0.device):
         rc = lib().binf_hmc_gauss_big_rng_draws_f64(
             dptr(p0), dptr(u), C, D, int(seed) & (2 ** 64 - 1), int(offset) & (2 ** 64 - 1),
-            stream_handle(p0.device))
+            int(chain_offset), stream_handle(p0.device))
     check(rc, 'binf_hmc_gauss_big_rng_draws_f64')
     return p0, u
 
@@ -653,7 +658,7 @@ def hmc_gauss_big_rng_draws(C, D, seed, offset, device):
 @_launcher
 def hmc_sample_n_gauss_rng(q0, q_out, samples, accepted, n_accepted, e_before,
                            e_after, timestep, dt_chain, nsteps, n, thin, k, x0,
-                           n_adapt, uprate, downrate, mode, seed, offset):
+                           n_adapt, uprate, downrate, mode, seed, offset, chain_offset=0):
     """binf_hmc_sample_n_gauss_rng_f64 (draws generated in the kernel) on
     torch's current stream."""
     C, D = _cd(q0)
@@ -671,26 +676,27 @@ def hmc_sample_n_gauss_rng(q0, q_out, samples, accepted, n_accepted, e_before,
         dptr(dt_chain, numel=C, name='dt_chain'), C, D, int(nsteps), n, thin,
         float(k), float(x0), int(n_adapt), float(uprate), float(downrate),
         int(mode), int(seed) & (2 ** 64 - 1), int(offset) & (2 ** 64 - 1),
-        stream_handle(q0.device))
+        int(chain_offset), stream_handle(q0.device))
     check(rc, 'binf_hmc_sample_n_gauss_rng_f64')
 
 
-def hmc_gauss_rng_draws(n, C, D, seed, offset, device):
+def hmc_gauss_rng_draws(n, C, D, seed, offset, device, chain_offset=0, out=None):
     """(p0 [n, C, D], u [n, C]): the draws the fused-generator kernel consumes
-    for (seed, offset) at this batch shape."""
+    for (seed, offset) and global chains ``chain_offset .. chain_offset + C - 1``
+    (``out = (p0, u)``: fill the caller's buffers instead of new ones)."""
     n, C, D = int(n), int(C), int(D)
-    p0 = torch.empty((n, C, D), dtype=torch.float64, device=device)
-    u = torch.empty((n, C), dtype=torch.float64, device=device)
-    rc = lib().binf_hmc_gauss_rng_draws_f64(
-        dptr(p0), dptr(u), C, D, n, int(seed) & (2 ** 64 - 1),
-        int(offset) & (2 ** 64 - 1), stream_handle(p0.device))
+    if out is None:
+        p0 = torch.empty((n, C, D), dtype=torch.float64, device=device)
+        u = torch.empty((n, C), dtype=torch.float64, device=device)
+    else:
+        p0, u = out
+    with torch.cuda.device(p0.device):
+        rc = lib().binf_hmc_gauss_rng_draws_f64(
+            dptr(p0, numel=n * C * D, name='p0'), dptr(u, numel=n * C, name='u'), C, D, n,
+            int(seed) & (2 ** 64 - 1), int(offset) & (2 ** 64 - 1), int(chain_offset),
+            stream_handle(p0.device))
     check(rc, 'binf_hmc_gauss_rng_draws_f64')
     return p0, u
-
-
-def fused_rng_covers(D):
-    """Shapes binf_hmc_sample_n_gauss_rng_f64 accepts (= the persistent kernel's)."""
-    return 1 <= D <= 8192 and pairwise_tree_height(D) <= 6
 
 
 @_launcher
@@ -743,6 +749,39 @@ def pairdist_gauss_grad(x, ymat, precision):
     return out
 
 
+@_launcher
+def rwmc_propose(state, stepsize, change=None, seed=0, offset=0, chain_offset=0, out=None):
+    """``state + uniform(-stepsize, stepsize)`` (samplers.py:81-83); ``change``
+    supplied, or drawn on the device from the Philox stream (seed, offset)."""
+    C, K = _cd(state)
+    if out is None:
+        out = torch.empty_like(state)
+    rc = lib().binf_rwmc_propose_f64(
+        dptr(state, numel=C * K, name='state'), dptr(change, numel=C * K, name='change'),
+        dptr(out, numel=C * K, name='proposal'), float(stepsize), C, K,
+        int(seed) & (2 ** 64 - 1), int(offset) & (2 ** 64 - 1), int(chain_offset),
+        stream_handle(state.device))
+    check(rc, 'binf_rwmc_propose_f64')
+    return out
+
+
+@_launcher
+def rwmc_accept(proposal, state, lp_old, lp_new, state_out, accepted=None, n_accepted=None,
+                u=None, seed=0, offset=0, chain_offset=0):
+    """Metropolis test with numpy's exp + select + counters (samplers.py:84-90);
+    ``u`` supplied or drawn on the device."""
+    C, K = _cd(proposal)
+    rc = lib().binf_rwmc_accept_f64(
+        dptr(proposal, numel=C * K, name='proposal'), dptr(state, numel=C * K, name='state'),
+        dptr(lp_old, numel=C, name='lp_old'), dptr(lp_new, numel=C, name='lp_new'),
+        dptr(u, numel=C, name='u'), dptr(state_out, numel=C * K, name='state_out'),
+        dptr(accepted, torch.uint8, C, 'accepted'),
+        dptr(n_accepted, torch.int64, C, 'n_accepted'), C, K,
+        int(seed) & (2 ** 64 - 1), int(offset) & (2 ** 64 - 1), int(chain_offset),
+        stream_handle(proposal.device))
+    check(rc, 'binf_rwmc_accept_f64')
+
+
 def philox4x32_10(counter, key):
     c = (ctypes.c_uint32 * 4)(*[int(x) & 0xffffffff for x in counter])
     k = (ctypes.c_uint32 * 2)(*[int(x) & 0xffffffff for x in key])
@@ -752,21 +791,23 @@ def philox4x32_10(counter, key):
 
 
 @_launcher
-def rng_fill(kind, out, seed, offset, shape=None):
+def rng_fill(kind, out, seed, offset, shape=None, elem_offset=0):
     """Fill the contiguous f64 device tensor `out` with uniform / normal /
-    gamma(shape) draws of the Philox stream (seed, offset)."""
+    gamma(shape) draws of the Philox stream (seed, offset); ``out[l]`` receives
+    global element ``elem_offset + l`` of the stream."""
     n = out.numel()
     p = dptr(out, numel=n, name='out')
     st = stream_handle(out.device)
     seed, offset = int(seed) & (2 ** 64 - 1), int(offset) & (2 ** 64 - 1)
+    e0 = int(elem_offset)
     if kind == 'uniform':
-        rc = lib().binf_rng_uniform_f64(p, n, seed, offset, st)
+        rc = lib().binf_rng_uniform_f64(p, n, seed, offset, e0, st)
     elif kind == 'normal':
-        rc = lib().binf_rng_normal_f64(p, n, seed, offset, st)
+        rc = lib().binf_rng_normal_f64(p, n, seed, offset, e0, st)
     elif kind == 'normal_zig':
-        rc = lib().binf_rng_normal_zig_f64(p, n, seed, offset, st)
+        rc = lib().binf_rng_normal_zig_f64(p, n, seed, offset, e0, st)
     elif kind == 'gamma':
-        rc = lib().binf_rng_gamma_f64(p, n, float(shape), seed, offset, st)
+        rc = lib().binf_rng_gamma_f64(p, n, float(shape), seed, offset, e0, st)
     else:
         raise ValueError('unknown draw kind %r' % (kind,))
     check(rc, 'binf_rng_%s_f64' % kind)

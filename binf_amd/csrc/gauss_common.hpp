@@ -33,6 +33,7 @@ struct GaussNArgs {
     // draws generated in the kernel (hmc_gauss_rng.hip)
     uint64_t rng_seed;
     uint64_t rng_offset;
+    int64_t chain_offset;    // global index of this launch's first chain (sharded runs)
     double *p_dump;          // [n x C x D], GAUSS_RNG_DUMP only
     double *u_dump;          // [n x C],     GAUSS_RNG_DUMP only
 };
@@ -180,6 +181,17 @@ __device__ inline double exp_clipped_range(double x)
     p = __builtin_fma(r, p, 1.0);
     p = __builtin_fma(r, p, 1.0);
     return __builtin_ldexp(p, (int)n);
+}
+
+// np.exp on the whole real line (the accept test of the RWMC sampler,
+// binf/example/samplers.py:86, uses numpy's exp, not csb's clipped one): +inf above
+// the overflow threshold, subnormals and 0 below, NaN for NaN -- the same
+// polynomial as every other accept test here.
+__device__ inline double np_exp(double x)
+{
+    if (x > 709.782712893384) return __builtin_inf();
+    if (x < -745.2) return 0.0;
+    return exp_clipped_range(x);
 }
 
 template <bool UNIT>

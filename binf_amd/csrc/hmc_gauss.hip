@@ -117,7 +117,7 @@ extern "C" int32_t binf_hmc_sample_n_gauss_f64(
     a.D = (int32_t)D; a.nsteps = nsteps; a.H = H; a.n = n; a.thin = thin;
     a.n_adapt = n_adapt < n ? n_adapt : n;
     a.stagger = gauss_stagger(n);
-    a.rng_seed = 0; a.rng_offset = 0; a.p_dump = nullptr; a.u_dump = nullptr;
+    a.rng_seed = 0; a.rng_offset = 0; a.chain_offset = 0; a.p_dump = nullptr; a.u_dump = nullptr;
 
     const int64_t blocks = plan.blocks;
     if (blocks > 0x7fffffffLL)

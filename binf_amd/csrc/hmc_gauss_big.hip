@@ -46,6 +46,7 @@ struct BigArgs {
     // draws generated in the kernel (RNG != 0)
     uint64_t rng_seed;
     uint64_t rng_offset;
+    int64_t chain_offset;    // global index of this launch's first chain (sharded runs)
     double *p_dump;          // [C x D], RNG == 2 only
 };
 
@@ -109,7 +110,7 @@ __global__ void __launch_bounds__(256) hmc_gauss_big_traj_kernel(const BigArgs a
     // the order the workgroup walks them (lane group g: paths g, g + 32, ...)
     Xo128 gen = {0u, 0u, 0u, 0u};
     if (RNG != BIG_RNG_HBM)
-        gen = xo_seed((((uint64_t)c * (uint64_t)a.nchunks + (uint64_t)chunk) * 32 + (uint64_t)group) * 8
+        gen = xo_seed((((uint64_t)(c + a.chain_offset) * (uint64_t)a.nchunks + (uint64_t)chunk) * 32 + (uint64_t)group) * 8
                           + (uint64_t)j, a.rng_seed, a.rng_offset);
 
     // A lane integrates its leaf in two halves of GS = 8 elements.  The halves of
@@ -264,6 +265,7 @@ struct BigFinishArgs {
     double *u_dump;          // write it out (tests)
     uint64_t rng_seed;
     uint64_t rng_offset;
+    int64_t chain_offset;
     uint8_t *accepted;
     int64_t *n_accepted;
     double *e_before;
@@ -297,7 +299,7 @@ __global__ void __launch_bounds__(256) hmc_gauss_big_finish_kernel(const BigFini
     if (a.u) {
         uu = a.u[c];
     } else {                                                  // np.random.uniform, hmc.py:151
-        Xo128 gen = xo_seed(BIG_U_STREAM + (uint64_t)c, a.rng_seed, a.rng_offset);
+        Xo128 gen = xo_seed(BIG_U_STREAM + (uint64_t)(c + a.chain_offset), a.rng_seed, a.rng_offset);
         uu = xo_uniform53(gen);
     }
     if (a.u_dump) a.u_dump[c] = uu;
@@ -373,12 +375,14 @@ static int32_t big_run(const char *what, const double *q0, const double *p0, con
                        double *e_after, double timestep, double *dt_chain, int64_t C, int64_t D,
                        int32_t nsteps, double k, double x0, int32_t adapt, double uprate,
                        double downrate, int32_t mode, void *workspace, uint64_t seed,
-                       uint64_t offset, double *p_dump, double *u_dump, hipStream_t st)
+                       uint64_t offset, int64_t chain_offset, double *p_dump, double *u_dump,
+                       hipStream_t st)
 {
     BigArgs a;
     a.q0 = q0; a.p0 = p0; a.q_out = q_out; a.ws = (double *)workspace; a.dt_chain = dt_chain;
     a.timestep = timestep; a.k = k; a.x0 = x0; a.C = C; a.D = D; a.nchunks = big_chunks(D);
-    a.nsteps = nsteps; a.rng_seed = seed; a.rng_offset = offset; a.p_dump = p_dump;
+    a.nsteps = nsteps; a.rng_seed = seed; a.rng_offset = offset; a.chain_offset = chain_offset;
+    a.p_dump = p_dump;
     const int32_t nfull = (int32_t)(D / NPY_BUFSIZE);
     const int32_t ntail = (D % NPY_BUFSIZE) ? 1 : 0;
     if (C * (int64_t)(nfull > 0 ? nfull : 1) > 0x7fffffffLL)
@@ -402,7 +406,7 @@ static int32_t big_run(const char *what, const double *q0, const double *p0, con
     BigFinishArgs f;
     f.ws = (RNG == BIG_RNG_DUMP) ? nullptr : (const double *)workspace;
     f.u = (RNG == BIG_RNG_HBM) ? u : nullptr; f.u_dump = u_dump; f.rng_seed = seed;
-    f.rng_offset = offset; f.accepted = accepted; f.n_accepted = n_accepted;
+    f.rng_offset = offset; f.chain_offset = chain_offset; f.accepted = accepted; f.n_accepted = n_accepted;
     f.e_before = e_before; f.e_after = e_after; f.dt_chain = dt_chain; f.k = k;
     f.uprate = uprate; f.downrate = downrate; f.C = C; f.nchunks = a.nchunks;
     f.adapt = adapt ? 1 : 0;
@@ -458,7 +462,7 @@ extern "C" int32_t binf_hmc_sample_gauss_big_f64(
     if (C == 0) return 0;
     return big_run<BIG_RNG_HBM>(what, q0, p0, u, q_out, accepted, n_accepted, e_before, e_after,
                                 timestep, dt_chain, C, D, nsteps, k, x0, adapt, uprate, downrate,
-                                mode, workspace, 0, 0, nullptr, nullptr, (hipStream_t)stream);
+                                mode, workspace, 0, 0, 0, nullptr, nullptr, (hipStream_t)stream);
 }
 
 // The same transition with its draws generated inside the kernels (momentum: one
@@ -468,15 +472,18 @@ extern "C" int32_t binf_hmc_sample_gauss_big_rng_f64(
     const double *q0, double *q_out, uint8_t *accepted, int64_t *n_accepted, double *e_before,
     double *e_after, double timestep, double *dt_chain, int64_t C, int64_t D, int32_t nsteps,
     double k, double x0, int32_t adapt, double uprate, double downrate, int32_t mode,
-    uint64_t seed, uint64_t offset, void *workspace, int64_t workspace_bytes, void *stream)
+    uint64_t seed, uint64_t offset, int64_t chain_offset, void *workspace,
+    int64_t workspace_bytes, void *stream)
 {
     const char *what = "hmc_sample_gauss_big_rng";
+    if (chain_offset < 0) return fail(BINF_E_ARG, "%s: chain_offset < 0", what);
     if (int32_t rc = big_check(what, q0, nullptr, q_out, accepted, dt_chain, C, D, nsteps, adapt,
                                mode, workspace, workspace_bytes)) return rc;
     if (C == 0) return 0;
     return big_run<BIG_RNG_FUSED>(what, q0, nullptr, nullptr, q_out, accepted, n_accepted, e_before,
                                   e_after, timestep, dt_chain, C, D, nsteps, k, x0, adapt, uprate,
-                                  downrate, mode, workspace, seed, offset, nullptr, nullptr,
+                                  downrate, mode, workspace, seed, offset, chain_offset, nullptr,
+                                  nullptr,
                                   (hipStream_t)stream);
 }
 
@@ -484,15 +491,16 @@ extern "C" int32_t binf_hmc_sample_gauss_big_rng_f64(
 // written out: p0_out [C*D], u_out [C].
 extern "C" int32_t binf_hmc_gauss_big_rng_draws_f64(double *p0_out, double *u_out, int64_t C,
                                                     int64_t D, uint64_t seed, uint64_t offset,
-                                                    void *stream)
+                                                    int64_t chain_offset, void *stream)
 {
     const char *what = "hmc_gauss_big_rng_draws";
-    if (C < 0 || D < 1) return fail(BINF_E_ARG, "%s: need C>=0, D>=1", what);
+    if (C < 0 || D < 1 || chain_offset < 0)
+        return fail(BINF_E_ARG, "%s: need C>=0, D>=1, chain_offset>=0", what);
     if (C == 0) return 0;
     if (!p0_out || !u_out) return fail(BINF_E_ARG, "%s: null buffer", what);
     if (C > 0x7fffffffffffffffLL / D) return fail(BINF_E_ARG, "%s: C*D overflows", what);
     return big_run<BIG_RNG_DUMP>(what, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
                                  nullptr, 0.0, nullptr, C, D, 1, 1.0, 0.0, 0, 1.0, 1.0,
-                                 BINF_MODE_EXACT, nullptr, seed, offset, p0_out, u_out,
+                                 BINF_MODE_EXACT, nullptr, seed, offset, chain_offset, p0_out, u_out,
                                  (hipStream_t)stream);
 }

@@ -77,13 +77,14 @@ hmc_gauss_persist_kernel(const GaussNArgs a)
     double dt = a.dt_chain ? a.dt_chain[chain] : a.timestep;
     double uu = 0.0;
     if (RNG == GAUSS_RNG_HBM) uu = a.u[chain];
-    // the lane's random stream: identified by (chain, leaf, accumulator), i.e.
-    // by WHICH elements the lane owns, not by where it runs; the redundant
-    // groups of a ragged tree share the stream of the leaf they recompute
+    // the lane's random stream: identified by (GLOBAL chain, leaf, accumulator),
+    // i.e. by WHICH elements the lane owns, not by where it runs (nor by which
+    // rank's shard the chain sits in: chain_offset); the redundant groups of a
+    // ragged tree share the stream of the leaf they recompute
     Xo128 gen = {0u, 0u, 0u, 0u};
     if (RNG != GAUSS_RNG_HBM) {
         const int cgrp = grp & ~((1 << (H - leafdepth)) - 1);
-        gen = xo_seed((uint64_t)chain * (uint64_t)(8 << H) + (uint64_t)(cgrp * 8 + j),
+        gen = xo_seed((uint64_t)(chain + a.chain_offset) * (uint64_t)(8 << H) + (uint64_t)(cgrp * 8 + j),
                       a.rng_seed, a.rng_offset);
     }
     if (a.stagger > 0) {

@@ -58,11 +58,12 @@ extern "C" int32_t binf_hmc_sample_n_gauss_rng_f64(
     int64_t *n_accepted, double *e_before, double *e_after, double timestep,
     double *dt_chain, int64_t C, int64_t D, int32_t nsteps, int32_t n, int32_t thin,
     double k, double x0, int32_t n_adapt, double uprate, double downrate, int32_t mode,
-    uint64_t seed, uint64_t offset, void *stream)
+    uint64_t seed, uint64_t offset, int64_t chain_offset, void *stream)
 {
     const char *what = "hmc_sample_n_gauss_rng";
-    if (C < 0 || D < 1 || nsteps < 1 || n < 1 || thin < 1 || n_adapt < 0)
-        return fail(BINF_E_ARG, "%s: need C>=0, D>=1, nsteps>=1, n>=1, thin>=1, n_adapt>=0", what);
+    if (C < 0 || D < 1 || nsteps < 1 || n < 1 || thin < 1 || n_adapt < 0 || chain_offset < 0)
+        return fail(BINF_E_ARG, "%s: need C>=0, D>=1, nsteps>=1, n>=1, thin>=1, n_adapt>=0, "
+                    "chain_offset>=0", what);
     if (mode != BINF_MODE_EXACT && mode != BINF_MODE_FMA)
         return fail(BINF_E_ARG, "%s: unknown mode %d", what, mode);
     if (C == 0) return 0;
@@ -82,7 +83,8 @@ extern "C" int32_t binf_hmc_sample_n_gauss_rng_f64(
     a.D = (int32_t)D; a.nsteps = nsteps; a.H = p.H; a.n = n; a.thin = thin;
     a.n_adapt = n_adapt < n ? n_adapt : n;
     a.stagger = 0;
-    a.rng_seed = seed; a.rng_offset = offset; a.p_dump = nullptr; a.u_dump = nullptr;
+    a.rng_seed = seed; a.rng_offset = offset; a.chain_offset = chain_offset;
+    a.p_dump = nullptr; a.u_dump = nullptr;
     const hipError_t e = launch_rng<GAUSS_RNG_FUSED>(a, p, k == 1.0 && x0 == 0.0,
                                                     mode == BINF_MODE_FMA, (hipStream_t)stream);
     if (e != hipSuccess) return hip_fail(e, "hmc_gauss_persist_kernel (fused generator) launch");
@@ -91,10 +93,12 @@ extern "C" int32_t binf_hmc_sample_n_gauss_rng_f64(
 
 extern "C" int32_t binf_hmc_gauss_rng_draws_f64(double *p0_out, double *u_out, int64_t C,
                                                 int64_t D, int32_t n, uint64_t seed,
-                                                uint64_t offset, void *stream)
+                                                uint64_t offset, int64_t chain_offset,
+                                                void *stream)
 {
     const char *what = "hmc_gauss_rng_draws";
-    if (C < 0 || D < 1 || n < 1) return fail(BINF_E_ARG, "%s: need C>=0, D>=1, n>=1", what);
+    if (C < 0 || D < 1 || n < 1 || chain_offset < 0)
+        return fail(BINF_E_ARG, "%s: need C>=0, D>=1, n>=1, chain_offset>=0", what);
     if (C == 0) return 0;
     if (!p0_out || !u_out) return fail(BINF_E_ARG, "%s: null buffer", what);
     GaussPlan p;
@@ -102,7 +106,8 @@ extern "C" int32_t binf_hmc_gauss_rng_draws_f64(double *p0_out, double *u_out, i
     GaussNArgs a = {};
     a.C = C; a.D = (int32_t)D; a.nsteps = 1; a.H = p.H; a.n = n; a.thin = 1;
     a.k = 1.0;
-    a.rng_seed = seed; a.rng_offset = offset; a.p_dump = p0_out; a.u_dump = u_out;
+    a.rng_seed = seed; a.rng_offset = offset; a.chain_offset = chain_offset;
+    a.p_dump = p0_out; a.u_dump = u_out;
     const hipError_t e = launch_rng<GAUSS_RNG_DUMP>(a, p, true, false, (hipStream_t)stream);
     if (e != hipSuccess) return hip_fail(e, "hmc_gauss_persist_kernel (draw dump) launch");
     return 0;

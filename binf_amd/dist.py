@@ -56,11 +56,16 @@ class PendingGather(object):
         return self._finish(self._out)
 
 
-def gather_chains(local, n_chains_total=None, group=None, async_op=False):
-    """All-gather a per-chain tensor along dim 0 (chains).  ``local`` is
-    ``[C_local, ...]``; returns ``[C_total, ...]`` on every rank, rows in
-    global chain order.  Uneven shards (see :func:`shard_chains`) are padded to
-    the largest shard for the collective and trimmed afterwards.
+def gather_chains(local, n_chains_total=None, group=None, async_op=False, dst=None):
+    """Gather a per-chain tensor along dim 0 (chains).  ``local`` is
+    ``[C_local, ...]``; returns ``[C_total, ...]``, rows in global chain order.
+    Uneven shards (see :func:`shard_chains`) are padded to the largest shard for
+    the collective and trimmed afterwards.
+
+    ``dst=None``: all-gather, every rank gets the result.  ``dst=r``: a gather
+    to rank ``r`` only (the usual case: one rank writes the samples out) --
+    the other ranks send their shard once and get ``None``; each rank then
+    moves ``1 / world_size`` of the all-gather's receive traffic.
 
     ``async_op=True`` returns a :class:`PendingGather` at once: sampling can go on
     while the collective runs (do not overwrite ``local`` before ``wait()``)."""
@@ -68,6 +73,8 @@ def gather_chains(local, n_chains_total=None, group=None, async_op=False):
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return PendingGather(None, local, lambda t: t) if async_op else local
     ws = dist.get_world_size(group)
+    if dst is not None and not 0 <= int(dst) < ws:
+        raise ValueError('gather_chains: dst=%r outside the group of %d ranks' % (dst, ws))
     c_local = local.shape[0]
     if n_chains_total is None:
         counts = [c_local] * ws
@@ -88,12 +95,24 @@ def gather_chains(local, n_chains_total=None, group=None, async_op=False):
         pad = torch.zeros((cmax - c_local,) + tuple(local.shape[1:]),
                           dtype=local.dtype, device=local.device)
         send = torch.cat([send, pad], dim=0)
-    out = torch.empty((ws * cmax,) + tuple(local.shape[1:]), dtype=local.dtype,
-                      device=local.device)
     def finish(t):
-        if all(c == cmax for c in counts):
+        if t is None or all(c == cmax for c in counts):
             return t
         return torch.cat([t[r * cmax:r * cmax + counts[r]] for r in range(ws)], dim=0)
+    if dst is not None:
+        me = dist.get_rank(group)
+        out, parts = None, None
+        if me == int(dst):
+            out = torch.empty((ws * cmax,) + tuple(local.shape[1:]), dtype=local.dtype,
+                              device=local.device)
+            parts = list(out.view((ws, cmax) + tuple(local.shape[1:])).unbind(0))
+        gdst = dist.get_global_rank(group, int(dst)) if group is not None else int(dst)
+        work = dist.gather(send, parts, dst=gdst, group=group, async_op=async_op)
+        if async_op:
+            return PendingGather(work, out, finish)
+        return finish(out)
+    out = torch.empty((ws * cmax,) + tuple(local.shape[1:]), dtype=local.dtype,
+                      device=local.device)
     if async_op:
         return PendingGather(dist.all_gather_into_tensor(out, send, group=group, async_op=True),
                              out, finish)
@@ -137,17 +156,18 @@ class SampleStore(object):
     def local(self):
         return self.buffer[:self.n_kept]
 
-    def gather(self, n_chains_total=None, group=None, async_op=False):
-        """``[n_kept, C_total, D]`` on every rank; with ``async_op=True`` a
-        :class:`PendingGather` (the store may keep recording into its later slots
-        meanwhile: the draws kept so far were copied out for the collective)."""
+    def gather(self, n_chains_total=None, group=None, async_op=False, dst=None):
+        """``[n_kept, C_total, D]`` on every rank (``dst=r``: on rank ``r`` only,
+        ``None`` elsewhere); with ``async_op=True`` a :class:`PendingGather` (the
+        store may keep recording into its later slots meanwhile: the draws kept
+        so far were copied out for the collective)."""
         kept = self.local()
-        back = lambda g: g.transpose(0, 1).contiguous()
+        back = lambda g: None if g is None else g.transpose(0, 1).contiguous()
         if kept.shape[0] == 0:
             return PendingGather(None, kept, lambda t: t) if async_op else kept
         # chains to dim 0 for the collective, back afterwards
         g = gather_chains(kept.transpose(0, 1).contiguous(), n_chains_total, group,
-                          async_op=async_op)
+                          async_op=async_op, dst=dst)
         if async_op:
             inner = g
             return PendingGather(None, None, lambda _t: back(inner.wait()))

@@ -22,14 +22,24 @@ class GammaSampler(object):
     The prior is read from ``self.pdf`` -- under a GibbsSampler that is the
     CONDITIONAL posterior, whose GammaPrior copy has rate == shape (quirk Q6).
 
-    ``gamma`` (optional): callable ``(shape, n_chains, device) -> [C]`` tensor
-    of Gamma(shape, 1) variates; default draws ``np.random.gamma`` from the
-    global legacy stream like the reference (``:47``).
+    Where the Gamma(shape, 1) variates come from (reference ``:47``:
+    ``np.random.gamma(shape)``):
+
+    * ``rng`` -- a generator with a ``gamma(shape, n_chains, device)`` method
+      (:class:`binf_amd.samplers.rng.DeviceRNG`): drawn ON THE DEVICE, one
+      per chain, keyed by the global chain index; nothing crosses PCIe;
+    * ``gamma`` -- a callable ``(shape, n_chains, device) -> [C]`` tensor;
+    * neither: ``np.random.gamma`` from the global legacy stream like the
+      reference, uploaded (parity mode; a host draw + H2D copy per sweep).
     """
 
-    def __init__(self, pdf, state, gamma=None):
+    def __init__(self, pdf, state, gamma=None, rng=None):
         self.pdf = pdf
         self.state = state
+        if gamma is None and rng is not None:
+            gamma = getattr(rng, 'gamma', None)
+            if gamma is None:
+                raise TypeError('GammaSampler: rng has no gamma(shape, n, device) method')
         self.gamma = gamma
 
     def _get_prior(self):
@@ -70,14 +80,25 @@ class GammaSampler(object):
 class RWMCSampler(object):
     """Random-walk Metropolis on ``coefficients`` (reference ``:54-92``):
     uniform proposal of half-width ``stepsize``, accept with
-    ``random() < exp(-(E_new - E_old))``.  Per-chain acceptance counts."""
+    ``random() < np.exp(-(E_new - E_old))``.  Per-chain acceptance counts.
 
-    def __init__(self, pdf, state, stepsize):
+    ``rng=None``: the reference's draws -- ``np.random.uniform(size=K)`` then
+    ``np.random.random()`` from the global legacy stream (for C chains:
+    ``size=(C, K)``, ``size=C``), uploaded; one chain consumes the stream
+    exactly as the reference does.  ``rng=DeviceRNG(...)``: both draws are
+    generated inside the proposal / accept kernels from the generator's Philox
+    stream, keyed by the global chain index -- no host draw, no H2D copy, and
+    a shard of a run draws what the whole run draws for its chains.
+    """
+
+    def __init__(self, pdf, state, stepsize, rng=None):
         self.pdf = pdf
         self.state = state
         self.stepsize = stepsize
+        self.rng = rng
         self._n_moves = 0
         self._n_accepted_moves = 0
+        self.last_move_accepted = None
 
     @property
     def last_draw_stats(self):
@@ -92,41 +113,57 @@ class RWMCSampler(object):
             return n / float(self._n_moves)
         return 0.0
 
-    def sample(self):
+    def sample(self, change=None, u=None):
+        """One Metropolis move per chain.  ``change`` (``[C x K]``) and ``u``
+        (``[C]``) override the draws (tests, pre-generated pools)."""
         state = _native.require_device(self.state, 'the RWMC state')
-        E_old = -self.pdf.log_prob(coefficients=state)
-        s2 = state if state.dim() == 2 else state.reshape(1, -1)
+        s2 = (state if state.dim() == 2 else state.reshape(1, -1)).contiguous()
         C, K = s2.shape
         dev = s2.device
-        shape = (K,) if state.dim() == 1 else (C, K)
-        change = torch.from_numpy(np.random.uniform(
-            low=-self.stepsize, high=self.stepsize, size=shape)).to(dev)
-        proposal = state + change
-        E_new = -self.pdf.log_prob(coefficients=proposal)
-        u = torch.from_numpy(np.random.random(size=C)).to(dev)
+        lp_old = self.pdf.log_prob(coefficients=state)               # E_old = -lp_old
+        seed = off_c = off_u = coff = 0
+        if self.rng is not None and hasattr(self.rng, 'next_offset'):
+            # device draws: one stream position for the proposal, one for the test
+            seed, coff = self.rng.seed, int(getattr(self.rng, 'chain_offset', 0))
+            off_c = self.rng.next_offset() if change is None else 0
+            off_u = self.rng.next_offset() if u is None else 0
+        else:
+            if change is None:
+                shape = (K,) if state.dim() == 1 else (C, K)
+                change = torch.from_numpy(np.random.uniform(
+                    low=-self.stepsize, high=self.stepsize, size=shape)).to(dev)
+        if change is not None:
+            change = change.reshape(C, K).contiguous()
+        proposal = _native.rwmc_propose(s2, self.stepsize, change, seed, off_c, coff)
+        lp_new = self.pdf.log_prob(coefficients=proposal.view(state.shape))
+        if u is None and not (self.rng is not None and hasattr(self.rng, 'next_offset')):
+            u = torch.from_numpy(np.random.random(size=C)).to(dev)
         accepted = torch.empty(C, dtype=torch.uint8, device=dev)
         if not isinstance(self._n_accepted_moves, torch.Tensor):
             self._n_accepted_moves = torch.zeros(C, dtype=torch.int64, device=dev)
-        p2 = proposal if proposal.dim() == 2 else proposal.reshape(1, -1)
-        _native.accept_select(p2.contiguous(), s2.contiguous(),
-                              E_old.reshape(-1), E_new.reshape(-1), u, p2,
-                              accepted, self._n_accepted_moves)
-        self.state = p2.view(state.shape)
+        _native.rwmc_accept(proposal, s2, lp_old.reshape(-1).contiguous(),
+                            lp_new.reshape(-1).contiguous(), proposal, accepted,
+                            self._n_accepted_moves, u, seed, off_u, coff)
+        self.last_move_accepted = accepted.view(torch.bool)
+        self.state = proposal.view(state.shape)
         self._n_moves += 1
         return self.state
 
 
-def make_sampler(posterior, rwmc_stepsize, start_state):
+def make_sampler(posterior, rwmc_stepsize, start_state, rng=None):
     """The reference's factory (``:94-111``): RWMC for the coefficients,
-    conjugate Gamma for the precision, wrapped in a GibbsSampler."""
+    conjugate Gamma for the precision, wrapped in a GibbsSampler.  ``rng``
+    (not in the reference): a :class:`DeviceRNG` makes every draw of the sweep
+    a device draw (nothing crosses PCIe); default = the reference's global
+    ``np.random`` stream."""
     from binf_amd.samplers.gibbs import GibbsSampler
     coeffs = start_state.variables['coefficients']
     precision = start_state.variables['precision']
     coefficients_sampler = RWMCSampler(
         posterior.conditional_factory(precision=precision), coeffs,
-        rwmc_stepsize)
+        rwmc_stepsize, rng=rng)
     precision_sampler = GammaSampler(
-        posterior.conditional_factory(coefficients=coeffs), precision)
+        posterior.conditional_factory(coefficients=coeffs), precision, rng=rng)
     return GibbsSampler(posterior, start_state,
                         {'coefficients': coefficients_sampler,
                          'precision': precision_sampler})
@@ -144,9 +181,12 @@ def make_hmc_sampler(posterior, timestep, nsteps, start_state, **hmc_kwargs):
     coefficients_sampler = HMCSampler(
         posterior.conditional_factory(precision=precision), coeffs, timestep,
         nsteps, variable_name='coefficients', **hmc_kwargs)
+    # a device generator given for the HMC draws also serves the Gamma draw
+    # (GammaSampler: device gamma when an rng with .gamma is there)
+    rng = hmc_kwargs.get('rng')
     precision_sampler = GammaSampler(
         posterior.conditional_factory(coefficients=coeffs), precision,
-        gamma=gamma)
+        gamma=gamma, rng=rng if (gamma is None and hasattr(rng, 'gamma')) else None)
     return GibbsSampler(posterior, start_state,
                         {'coefficients': coefficients_sampler,
                          'precision': precision_sampler})

@@ -146,8 +146,8 @@ class HMCSampler(object):
         C, D = q0.shape
         dev = q0.device
         spec = self._fused_spec(name, D, C)          # once per call: walks the posterior
-        if p0 is None and u is None and self._fused_rng(name, D, C, spec):
-            # the draws are generated inside the sampling kernel
+        if p0 is None and u is None and self._fused_rng(name, D, spec):
+            # the draws come from the lane streams of the fused kernels
             if _native.gauss_persist_covers(D):
                 return self._sample_n_fused_rng(1)
             return self._sample_long_fused_rng(name, q0, shape)
@@ -211,10 +211,17 @@ class HMCSampler(object):
         C, D = q0.shape
         dev = q0.device
         nrec = n // thin
-        fused_rng = p0 is None and u is None and self._fused_rng(name, D, C) and \
-            _native.gauss_persist_covers(D)
         spec = self._fused_spec(name, D)
+        fused_rng = p0 is None and u is None and self._fused_rng(name, D, spec) and \
+            _native.gauss_persist_covers(D)
         persist = spec is not None and spec[0] == 'gauss' and _native.gauss_persist_covers(D)
+        if fused_rng and not self._draws_in_kernel(C, D):
+            # a small batch: the split kernel with the draws in HBM is the faster
+            # launch, so the SAME lane-stream draws are written out first (a seed
+            # identifies the draws whatever the batch size)
+            p0, u = _native.hmc_gauss_rng_draws(n, C, D, self.rng.seed, self.rng.next_offset(),
+                                                dev, chain_offset=self._chain_offset())
+            fused_rng = False
         if persist and not fused_rng and (p0 is None or u is None):
             # the draws of n sample() calls in the order those calls consume the
             # generator: normal, uniform, normal, uniform, ... (hmc.py:146,151)
@@ -283,7 +290,8 @@ class HMCSampler(object):
                                            self.nsteps, n, thin, k, x0, n_adapt,
                                            self.adaption_uprate, self.adaption_downrate,
                                            _MODES[self.mode], self.rng.seed,
-                                           self.rng.next_offset())
+                                           self.rng.next_offset(),
+                                           chain_offset=self._chain_offset())
         else:
             _native.hmc_sample_n_gauss(q0, p0.contiguous(), u.contiguous(), q_out,
                                        samples, accepted, self.n_accepted, eb, ea,
@@ -301,26 +309,32 @@ class HMCSampler(object):
         return samples if state.dim() == 2 else samples.reshape((nrec,) + tuple(shape))
 
     # -- fused tier ----------------------------------------------------------
-    def _fused_rng(self, name, D, C=None, spec=False):
-        """True if this sampler's draws are generated inside the sampling
-        kernel: a device generator that allows it, a Gaussian with a fused
-        kernel of that shape -- and a batch large enough for one wave per chain.
-        Up to 1024 chains of D = 768 / 1024 the library spreads a chain over 4
-        waves when the draws come from HBM (hmc_gauss_split.hip); that beats the
-        one-wave kernel with its own generator (512 chains: 4.0 vs 10.5 us per
-        transition, scripts/probe_small_batch_rng.py), so such batches take the
-        stand-alone generator kernels."""
+    def _fused_rng(self, name, D, spec=False):
+        """True if this sampler's draws are the lane streams of the fused
+        Gaussian kernels (csrc/xoshiro.hpp): a device generator that allows it and
+        a Gaussian with a fused kernel.  Depends on the PDF and D only, never on
+        the number of chains -- so a shard of a run draws what the whole run
+        draws for its chains."""
         if not getattr(self.rng, 'fused', False):
             return False
         if spec is False:
             spec = self._fused_spec(name, D)
-        if spec is None or spec[0] != 'gauss':
-            return False
-        if not _native.gauss_persist_covers(D):
-            return True                # long chains: hmc_gauss_big.hip draws its own as well
-        if getattr(self.rng, 'fused', False) == 'always' or C is None:
+        return spec is not None and spec[0] == 'gauss'
+
+    def _draws_in_kernel(self, C, D):
+        """Lane-stream draws: generated inside the sampling kernel (True) or
+        written out first by the draw kernel and read back (False)?  Same draws
+        either way; this only picks the faster launch.  Up to 1024 chains of
+        D = 768 / 1024 the library spreads a chain over 4 waves when the draws
+        come from HBM (hmc_gauss_split.hip); that beats the one-wave kernel with
+        its own generator (512 chains: 4.0 vs 10.5 us per transition,
+        scripts/probe_small_batch_rng.py)."""
+        if getattr(self.rng, 'fused', False) == 'always':
             return True
         return D > 1024 or _native.gauss_waves_per_chain(C, D) < 4
+
+    def _chain_offset(self):
+        return int(getattr(self.rng, 'chain_offset', 0))
 
     def _sample_long_fused_rng(self, name, q0, shape):
         """sample() for chains beyond the persistent kernel's reach with the
@@ -344,7 +358,8 @@ class HMCSampler(object):
                                          self._timestep, self._dt_chain, self.nsteps, k, x0,
                                          adapt, self.adaption_uprate, self.adaption_downrate,
                                          _MODES[self.mode], self.rng.seed,
-                                         self.rng.next_offset())
+                                         self.rng.next_offset(),
+                                         chain_offset=self._chain_offset())
         self.last_e_before, self.last_e_after = eb, ea
         self._last_move_accepted = accepted.view(torch.bool)
         self.counter += 1

@@ -30,26 +30,59 @@ class HostLegacyRNG(object):
 
 
 class DeviceRNG(object):
-    """Throughput source: draws generated in HBM by the library's Philox
-    kernels (``csrc/rng.hip``), so nothing crosses PCIe.  Deterministic in
-    (seed, call order), independent of launch geometry; NOT stream-compatible
-    with numpy."""
+    """Throughput source: draws generated on the device, so nothing crosses
+    PCIe.  NOT stream-compatible with numpy.
 
-    def __init__(self, seed=0, device='cuda', normal='ziggurat', fused=True):
+    What a chain draws is a function of ``(seed, call order, GLOBAL chain
+    index)`` only -- not of the batch size, the launch geometry, or how a run is
+    sharded over GPUs.  ``chain_offset`` is the global index of the first chain
+    this process owns (0 for an unsharded run; :meth:`for_shard` derives it from
+    ``binf_amd.dist.shard_chains``): a rank that owns chains ``[s, s + C)``
+    of a larger run draws exactly what the one-GPU run draws for those chains,
+    so an N-GPU run reproduces the 1-GPU run bit for bit.  Two ranks with the
+    same seed and the same ``chain_offset`` WOULD produce duplicate chains --
+    give every rank its shard's offset (or a different seed).
+
+    Two generators serve the draws:
+
+    * the stand-alone Philox4x32-10 kernels (``csrc/rng.hip``): element ``i`` of a
+      ``[C_total x D]`` normal draw is a function of its global flat index;
+    * the lane streams of the fused Gaussian HMC kernels (``csrc/xoshiro.hpp``,
+      ``fused=True``, the default): a sampler whose kernel can generate its own
+      draws (``HMCSampler`` on a Gaussian) asks for a stream position with
+      :meth:`next_offset` instead of for buffers.  Large batches generate the
+      draws inside the sampling kernel (the momentum never exists in HBM);
+      small batches, which run faster with a chain spread over several waves
+      (``csrc/hmc_gauss_split.hip``), get THE SAME draws written out by
+      ``binf_hmc_gauss_rng_draws_f64`` first.  Either way a seed identifies the
+      draws whatever the batch size.
+
+    ``fused=False`` uses the Philox kernels for everything; ``fused='always'``
+    generates in the sampling kernel whenever the shape is covered.  One
+    ``sample_n(n)`` launch takes ONE stream position where n ``sample()`` calls
+    take n: the two loops see different (equally valid) draws.
+    """
+
+    def __init__(self, seed=0, device='cuda', normal='ziggurat', fused=True, chain_offset=0):
         if normal not in ('ziggurat', 'box_muller'):
             raise ValueError("normal must be 'ziggurat' or 'box_muller'")
+        if int(chain_offset) < 0:
+            raise ValueError('chain_offset must be >= 0')
         self._normal_kind = 'normal_zig' if normal == 'ziggurat' else 'normal'
         self.seed = int(seed)
         self.offset = 0
+        self.chain_offset = int(chain_offset)
         self.device = torch.device(device)
-        # fused: a sampler whose kernel can generate its own draws (HMCSampler
-        # on a Gaussian, D <= 8192, more than 1024 chains) asks for a stream
-        # position with next_offset() instead of for buffers: the momentum
-        # never exists in HBM.  Which generator serves a sampler therefore
-        # depends on the batch shape; fused=False = always the stand-alone
-        # generator kernels (draws independent of the batch shape);
-        # fused='always' = the in-kernel generator whenever the shape is covered.
         self.fused = fused if fused == 'always' else bool(fused)
+
+    @classmethod
+    def for_shard(cls, seed, n_chains_total, rank=None, world_size=None, **kw):
+        """The generator of this rank's shard of ``n_chains_total`` chains
+        (``dist.shard_chains``): same seed on every rank, ``chain_offset`` = the
+        shard's first chain.  Returns ``(rng, start, count)``."""
+        from binf_amd.dist import shard_chains
+        start, count = shard_chains(n_chains_total, rank, world_size)
+        return cls(seed=seed, chain_offset=start, **kw), start, count
 
     def next_offset(self):
         """Reserve one launch worth of the in-kernel generator's stream."""
@@ -57,10 +90,18 @@ class DeviceRNG(object):
         self.offset += 1
         return o
 
+    def _elem_offset(self, shape):
+        # dim 0 is the chain axis: the window of this shard in the global array
+        per_chain = 1
+        for d in tuple(shape)[1:]:
+            per_chain *= int(d)
+        return self.chain_offset * per_chain
+
     def _fill(self, kind, dims, device, advance, **kw):
         from binf_amd import _native
         out = torch.empty(tuple(dims), dtype=torch.float64, device=device)
-        _native.rng_fill(kind, out, self.seed, self.offset, **kw)
+        _native.rng_fill(kind, out, self.seed, self.offset,
+                         elem_offset=self._elem_offset(dims), **kw)
         self.offset += advance
         return out
 
@@ -70,12 +111,14 @@ class DeviceRNG(object):
     def fill_normal(self, out):
         """normal() into a caller's contiguous buffer (same stream position rules)."""
         from binf_amd import _native
-        _native.rng_fill(self._normal_kind, out, self.seed, self.offset)
+        _native.rng_fill(self._normal_kind, out, self.seed, self.offset,
+                         elem_offset=self._elem_offset(out.shape))
         self.offset += 1
 
     def fill_uniform(self, out):
         from binf_amd import _native
-        _native.rng_fill('uniform', out, self.seed, self.offset)
+        _native.rng_fill('uniform', out, self.seed, self.offset,
+                         elem_offset=self._elem_offset(out.shape))
         self.offset += 1
 
     def uniform(self, n, device):

@@ -8,7 +8,9 @@ once.  Differences to the reference script, all deliberate:
   [n_chains x ...] device tensor);
 * the coefficients are sampled with HMC (50 leapfrog steps) instead of the
   random-walk sampler (pass --rwmc for the reference's own wiring);
-* draws come from the device generator unless --host-rng is given;
+* draws come from the device generator unless --host-rng is given (every rank
+  uses the SAME seed and its shard's chain offset, so the result does not depend
+  on how many GPUs the chains are spread over);
 * samples are recorded in an on-device, thinned SampleStore (burn-in and
   thinning as in example_script.py:41) and gathered once at the end; with
   torch.distributed initialised the chains are sharded over the ranks;
@@ -52,7 +54,7 @@ def main(argv=None):
         dist.init_process_group('nccl')
     rank, ws = world()
     dev = torch.device('cuda', torch.cuda.current_device())
-    _, C = shard_chains(args.chains, rank, ws)
+    start_chain, C = shard_chains(args.chains, rank, ws)
 
     # example_script.py:17-26
     np.random.seed(args.seed)
@@ -68,12 +70,12 @@ def main(argv=None):
         coefficients=torch.ones((C, 4), dtype=torch.float64, device=dev),
         precision=torch.ones(C, dtype=torch.float64, device=dev)))
     posterior = make_posterior(xses, ys, polynomial)
+    # one seed for the whole run; the streams are keyed by the GLOBAL chain index
+    rng = None if args.host_rng else DeviceRNG(args.seed, dev, chain_offset=start_chain)
     if args.rwmc:
-        gips = make_sampler(posterior, 0.1, start)
+        gips = make_sampler(posterior, 0.1, start, rng=rng)
     else:
-        rng = None if args.host_rng else DeviceRNG(args.seed + 1000 * rank, dev)
         gips = make_hmc_sampler(posterior, args.timestep, args.nsteps, start,
-                                gamma=None if rng is None else rng.gamma,
                                 **({} if rng is None else {'rng': rng}))
 
     n_keep = max(1, (args.iterations - args.burn_in + args.thin - 1) // args.thin)

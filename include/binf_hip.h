@@ -26,7 +26,13 @@
 extern "C" {
 #endif
 
-#define BINF_ABI_VERSION 1
+/* 2: every entry point that GENERATES draws takes the global index of its first
+ *    chain / element (chain_offset, elem_offset) so that a sharded run reproduces
+ *    the unsharded one bit for bit; new entry points for the RWMC subsampler, the
+ *    multi-sweep Gibbs launch, the Jacobian contraction and the term sum.
+ *    (1 -> 2 also covers the contract changes made late in ABI 1: the polynomial
+ *    gradient's workspace is mandatory, binf_hmc_sample_poly_f64 accepts N <= 1024.) */
+#define BINF_ABI_VERSION 2
 
 #define BINF_E_ARG        (-1)  /* null pointer / negative size / bad flag    */
 #define BINF_E_UNSUPPORTED (-2) /* shape outside what the kernels cover       */
@@ -152,6 +158,9 @@ int32_t binf_hmc_sample_gauss_big_f64(const double *q0, const double *p0,
  * xoshiro128++ stream per lane and (chain, 8192-chunk) for the momentum, one per
  * chain for the acceptance draw; keyed by (seed, offset), a caller advances
  * offset by one per call): binf_hmc_sample_gauss_big_f64 without p0 / u.
+ * chain_offset (>= 0) is the GLOBAL index of chain 0 of this call: the streams are
+ * keyed by global chain, so a rank that owns chains [s, s + C) of a larger run
+ * passes chain_offset = s and draws exactly what the unsharded call draws for them.
  * binf_hmc_gauss_big_rng_draws_f64 writes those draws out instead (p0_out [C*D],
  * u_out [C]); feeding them to binf_hmc_sample_gauss_big_f64 reproduces the fused
  * call bit for bit. */
@@ -163,11 +172,12 @@ int32_t binf_hmc_sample_gauss_big_rng_f64(const double *q0, double *q_out,
                                           double k, double x0, int32_t adapt,
                                           double uprate, double downrate,
                                           int32_t mode, uint64_t seed,
-                                          uint64_t offset, void *workspace,
+                                          uint64_t offset, int64_t chain_offset,
+                                          void *workspace,
                                           int64_t workspace_bytes, void *stream);
 int32_t binf_hmc_gauss_big_rng_draws_f64(double *p0_out, double *u_out, int64_t C,
                                          int64_t D, uint64_t seed, uint64_t offset,
-                                         void *stream);
+                                         int64_t chain_offset, void *stream);
 
 /* ------------------------------------------------------------------------
  * The same n transitions with the random draws generated INSIDE the kernel:
@@ -175,9 +185,12 @@ int32_t binf_hmc_gauss_big_rng_draws_f64(double *p0_out, double *u_out, int64_t 
  * q.shape) ... np.random.uniform() (binf/samplers/hmc.py:146,151), with no
  * momentum buffer in HBM.  Per-lane xoshiro128++ streams seeded from the Philox
  * block (lane's element set, offset) under `seed`, normals by a 1024-layer
- * ziggurat; deterministic in (seed, offset, C, D), independent of the launch
- * geometry, NOT numpy's MT19937 stream (parity runs inject host draws through
- * binf_hmc_sample_n_gauss_f64).  A caller advances `offset` by one per launch.
+ * ziggurat; chain c of the call draws the stream of GLOBAL chain chain_offset + c:
+ * deterministic in (seed, offset, global chain, D), independent of the launch
+ * geometry, of the batch size C and of how a run is sharded over GPUs (a rank that
+ * owns chains [s, s + C) passes chain_offset = s); NOT numpy's MT19937 stream
+ * (parity runs inject host draws through binf_hmc_sample_n_gauss_f64).  A caller
+ * advances `offset` by one per launch.
  * Arguments as binf_hmc_sample_n_gauss_f64 without p0 / u.
  * Supported: the shapes of binf_hmc_sample_n_gauss_f64 (D <= 8192, pairwise
  * tree height <= 6); otherwise BINF_E_UNSUPPORTED (use the stand-alone
@@ -192,15 +205,17 @@ int32_t binf_hmc_sample_n_gauss_rng_f64(const double *q0, double *q_out,
                                         double k, double x0, int32_t n_adapt,
                                         double uprate, double downrate,
                                         int32_t mode, uint64_t seed,
-                                        uint64_t offset, void *stream);
+                                        uint64_t offset, int64_t chain_offset,
+                                        void *stream);
 
-/* The draws binf_hmc_sample_n_gauss_rng_f64 consumes for (seed, offset, C, D, n),
+/* The draws binf_hmc_sample_n_gauss_rng_f64 consumes for (seed, offset, chain_offset, C, D, n),
  * written out instead of used: p0_out [n*C*D], u_out [n*C].  Feeding them to
  * binf_hmc_sample_n_gauss_f64 reproduces the fused call bit for bit -- the
  * handle by which the fused generator is tested and its stream inspected. */
 int32_t binf_hmc_gauss_rng_draws_f64(double *p0_out, double *u_out, int64_t C,
                                      int64_t D, int32_t n, uint64_t seed,
-                                     uint64_t offset, void *stream);
+                                     uint64_t offset, int64_t chain_offset,
+                                     void *stream);
 
 /* ------------------------------------------------------------------------
  * Generic per-step tier: the pieces of HMCSampler.sample() as separate
@@ -381,6 +396,41 @@ int32_t binf_gamma_precision_update_f64(const double *g, const double *lp_unit,
                                         void *stream);
 
 /* ------------------------------------------------------------------------
+ * Random-walk Metropolis subsampler, RWMCSampler.sample
+ * (binf/example/samplers.py:78-92), as two launches around the pdf's evaluation
+ * of the proposal.  Draws: supplied by the caller (parity with the reference's
+ * np.random stream) or, when the pointer is NULL, generated from the Philox
+ * stream of binf_rng_uniform_f64 under (seed, offset), keyed by GLOBAL index
+ * (chain_offset = global index of chain 0 of this call).
+ *
+ * binf_rwmc_propose_f64 (samplers.py:81-83):
+ *   proposal[c,k] = state[c,k] + change[c,k]
+ *   change == NULL: change[c,k] = -stepsize + (stepsize - -stepsize) * U, U =
+ *   element (chain_offset + c) * K + k of the uniform stream (seed, offset) --
+ *   np.random.uniform(low=-stepsize, high=stepsize) as legacy numpy forms it.
+ *   proposal may be exactly state (in place).
+ *
+ * binf_rwmc_accept_f64 (samplers.py:84-90):
+ *   acc[c] = u[c] < np.exp(-(E_new[c] - E_old[c])),  E = -log_prob: lp_old / lp_new
+ *   are the LOG-PROBABILITIES the pdf returned ([C]); numpy's exp, not csb's
+ *   clipped one (overflow -> inf accepts, NaN rejects).
+ *   u == NULL: u[c] = element chain_offset + c of the uniform stream (seed, offset).
+ *   state_out[c,:] = acc ? proposal[c,:] : state[c,:]   (exactly proposal, exactly
+ *   state, or disjoint);  accepted [C] or NULL;  n_accepted [C] or NULL, += acc
+ *   (samplers.py:88).
+ * ---------------------------------------------------------------------- */
+int32_t binf_rwmc_propose_f64(const double *state, const double *change,
+                              double *proposal, double stepsize, int64_t C,
+                              int64_t K, uint64_t seed, uint64_t offset,
+                              int64_t chain_offset, void *stream);
+int32_t binf_rwmc_accept_f64(const double *proposal, const double *state,
+                             const double *lp_old, const double *lp_new,
+                             const double *u, double *state_out,
+                             uint8_t *accepted, int64_t *n_accepted, int64_t C,
+                             int64_t K, uint64_t seed, uint64_t offset,
+                             int64_t chain_offset, void *stream);
+
+/* ------------------------------------------------------------------------
  * Pairwise-distance-restraint model (BASELINE config C5; build-defined, the
  * reference has no code for it -- it follows the reference's forward-model /
  * error-model plug-in shape, binf/model/forwardmodels.py:10-66).
@@ -438,16 +488,21 @@ int32_t binf_pairdist_leapfrog_f64(double *q, double *p, const double *ymat,
  * binf/example/samplers.py:47 when bit-parity with numpy's stream is not
  * required.  A caller advances `offset` by 1 per uniform / normal call and by
  * 128 per gamma call so that calls never reuse a counter.
+ * `i` is a GLOBAL element index: out[l] receives element elem_offset + l
+ * (elem_offset >= 0), so a rank filling its window of a larger logical array
+ * (chains [s, s + C) of a [C_total x D] draw: elem_offset = s * D, n = C * D) writes
+ * exactly what the unsharded call writes there.
  * ---------------------------------------------------------------------- */
 int32_t binf_rng_uniform_f64(double *out, int64_t n, uint64_t seed, uint64_t offset,
-                             void *stream);                 /* [0, 1), 53 bits  */
+                             int64_t elem_offset, void *stream);  /* [0, 1), 53 bits */
 int32_t binf_rng_normal_f64(double *out, int64_t n, uint64_t seed, uint64_t offset,
-                            void *stream);                  /* Box-Muller        */
+                            int64_t elem_offset, void *stream);   /* Box-Muller       */
 int32_t binf_rng_normal_zig_f64(double *out, int64_t n, uint64_t seed, uint64_t offset,
-                                void *stream);              /* 256-layer ziggurat;
-                                                               offset < 2^48     */
+                                int64_t elem_offset, void *stream);  /* 1024-layer
+                                                   ziggurat; offset < 2^48          */
 int32_t binf_rng_gamma_f64(double *out, int64_t n, double shape, uint64_t seed,
-                           uint64_t offset, void *stream);  /* Marsaglia-Tsang   */
+                           uint64_t offset, int64_t elem_offset,
+                           void *stream);                         /* Marsaglia-Tsang  */
 /* Host-side evaluation of the generator's block function (known-answer tests). */
 int32_t binf_rng_philox4x32_10(const uint32_t counter[4], const uint32_t key[2],
                                uint32_t out[4]);

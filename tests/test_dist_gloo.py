@@ -86,6 +86,27 @@ def _worker(rank, ws, port, n_total, n_dims, q):
         ok = ok and g2.shape == (2, n_total, n_dims) and torch.equal(g2[1], glob + 1000.0)
         ok = ok and torch.equal(pend_flags.wait(), (glob[:, 0] % 2 == 0).to(torch.uint8))
         ok = ok and st2.gather(n_total).shape == (3, n_total, n_dims)
+        # gather to ONE rank (dst): the others send and get None
+        for d in range(ws):
+            got = gather_chains(local, n_total, dst=d)
+            ok = ok and ((torch.equal(got, glob)) if rank == d else got is None)
+        pend = gather_chains(local, n_total, dst=0, async_op=True)
+        got = pend.wait()
+        ok = ok and (torch.equal(got, glob) if rank == 0 else got is None)
+        gd = st.gather(n_total, dst=1)
+        ok = ok and ((gd.shape == (3, n_total, n_dims) and torch.equal(gd[2], glob + 4000.0))
+                     if rank == 1 else gd is None)
+        # the device generator of this rank's shard: same seed, chain_offset = the
+        # shard's first GLOBAL chain (what makes an N-GPU run reproduce the 1-GPU run)
+        from binf_amd.samplers.rng import DeviceRNG
+        rng, s0, c0 = DeviceRNG.for_shard(17, n_total)
+        ok = ok and (s0, c0) == (start, count) and rng.chain_offset == start and rng.seed == 17
+        offs = [None] * ws
+        dist.all_gather_object(offs, (rng.chain_offset, count))
+        ok = ok and offs[0][0] == 0 and all(offs[r + 1][0] == offs[r][0] + offs[r][1]
+                                             for r in range(ws - 1))
+        ok = ok and offs[-1][0] + offs[-1][1] == n_total
+        ok = ok and rng._elem_offset((count, n_dims)) == start * n_dims
         # max-over-ranks timing reduction used by bench.py
         t = torch.tensor([1.0 + rank], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -220,7 +220,7 @@ def test_in_kernel_generator_stays_inside_its_buffers(device, D, C, n):
     for make in (Guarded(device), None):
         t = make if make is not None else (lambda a, dtype=torch.float64: plain(a, device, dtype))
         pd, ud = t(np.full((n, C, D), 77.0)), t(np.full((n, C), 77.0))
-        rc = lib.binf_hmc_gauss_rng_draws_f64(pd.data_ptr(), ud.data_ptr(), C, D, n, 5, 2, st)
+        rc = lib.binf_hmc_gauss_rng_draws_f64(pd.data_ptr(), ud.data_ptr(), C, D, n, 5, 2, 3, st)
         assert rc == 0
         tq, qo, smp = t(q0), t(np.zeros((C, D))), t(np.zeros((n, C, D)))
         acc = t(np.zeros((n, C), dtype=np.uint8), torch.uint8)
@@ -230,7 +230,7 @@ def test_in_kernel_generator_stays_inside_its_buffers(device, D, C, n):
         rc = lib.binf_hmc_sample_n_gauss_rng_f64(
             tq.data_ptr(), qo.data_ptr(), smp.data_ptr(), acc.data_ptr(), nacc.data_ptr(),
             eb.data_ptr(), ea.data_ptr(), 0.1, dtc.data_ptr(), C, D, 4, n, 1, 2.5, 0.3, n, 1.05,
-            0.95, _native.MODE_EXACT, 5, 2, st)
+            0.95, _native.MODE_EXACT, 5, 2, 3, st)
         assert rc == 0
         if make is not None:
             make.check()

@@ -214,7 +214,7 @@ def test_fused_generator_equals_sampling_from_its_own_dump(device, C, D, L, k, x
     dt = 0.9 / np.sqrt(k * max(D, 4))
     kw = dict(timestep_adaption_limit=4, variable_name='x', mode=mode, record_energies=True)
     a = HMCSampler(IsotropicGaussian(k, x0), q0, dt, L, rng=DeviceRNG(seed, device, fused='always'), **kw)
-    assert a._fused_rng('x', D, C)
+    assert a._fused_rng('x', D) and a._draws_in_kernel(C, D)
     rec_a = a.sample_n(n)                                    # offset 0
     rec_a2 = a.sample_n(2, thin=2)                           # offset 1
     p0, u = _native.hmc_gauss_rng_draws(n, C, D, seed, 0, device)
@@ -282,14 +282,15 @@ def test_fused_generator_limits_and_fallback(device):
         _native.hmc_gauss_rng_draws(1, 3, 9000, 0, 0, device)      # the persistent kernel's entry
     # longer chains draw inside the chunked kernels (test below)
     s = HMCSampler(IsotropicGaussian(), z, 0.02, 3, variable_name='x', rng=DeviceRNG(1, device))
-    assert s._fused_rng('x', 9000, 3)
+    assert s._fused_rng('x', 9000)
     assert s.sample_n(2).shape == (2, 3, 9000) and s.rng.offset == 2
     # few chains of D = 1024: a chain is spread over 4 waves with draws from HBM, which beats
-    # the one-wave kernel with its own generator -> stand-alone generator kernels
+    # the one-wave kernel with its own generator -> the SAME lane-stream draws, written out
+    # by the draw kernel first (the choice of launch never changes what a chain draws)
     for C, want in ((64, False), (1024, False), (1025, True), (2100, True), (5000, True)):
         s = HMCSampler(IsotropicGaussian(), torch.zeros((C, 1024), dtype=torch.float64, device=device),
                        0.02, 3, variable_name='x', rng=DeviceRNG(1, device))
-        assert s._fused_rng('x', 1024, C) is want, C
+        assert s._fused_rng('x', 1024) and s._draws_in_kernel(C, 1024) is want, C
     assert _native.gauss_waves_per_chain(512, 1024) == 4
     assert _native.gauss_waves_per_chain(2048, 1024) == 2
     assert _native.gauss_waves_per_chain(4096, 1024) == 1
@@ -316,7 +317,7 @@ def test_long_chain_generator_equals_sampling_from_its_own_dump(device, C, D, L,
               record_energies=True)
     a = HMCSampler(IsotropicGaussian(k, x0), q0, dt, L, rng=DeviceRNG(seed, device), **kw)
     b = HMCSampler(IsotropicGaussian(k, x0), q0, dt, L, **kw)
-    assert a._fused_rng('x', D, C) and not _native.gauss_persist_covers(D)
+    assert a._fused_rng('x', D) and not _native.gauss_persist_covers(D)
     for call in range(3):
         xa = a.sample()
         p0, u = _native.hmc_gauss_big_rng_draws(C, D, seed, call, device)
