@@ -104,12 +104,16 @@ def gibbs_run(device, C, sweeps, rng, coff=0, start=None):
         precision=torch.ones(C, dtype=torch.float64, device=device) if start is None else start[1]))
     gips = make_sampler(make_posterior(xs, ys, POLYVAL), 0.1, st, rng=rng)
     cs, ts = [], []
-    before = np.random.get_state()[1].copy()
+    def stream_pos():
+        # key words AND position: a few draws move only the position
+        st = np.random.get_state()
+        return (st[1].tobytes(), st[2], st[3], st[4])
+    before = stream_pos()
     for _ in range(sweeps):
         s = gips.sample()
         cs.append(s.variables['coefficients'].clone())
         ts.append(s.variables['precision'].clone())
-    gips.host_stream_untouched = np.array_equal(np.random.get_state()[1], before)
+    gips.host_stream_untouched = stream_pos() == before
     return torch.stack(cs), torch.stack(ts), gips
 
 
