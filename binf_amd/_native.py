@@ -15,6 +15,9 @@ LIB_PATH = os.environ.get('BINF_LIB_OVERRIDE') or \
 
 MODE_EXACT = 0
 MODE_FMA = 1
+MODE_LANE_PER_CHAIN = 16     # flag for hmc_sample_poly: one lane per chain (N <= 128)
+MOVE_HMC = 0
+MOVE_RWMC = 1
 
 E_ARG = -1
 E_UNSUPPORTED = -2
@@ -31,6 +34,7 @@ _vp = ctypes.c_void_p
 _i64 = ctypes.c_int64
 _i32 = ctypes.c_int32
 _f64 = ctypes.c_double
+_u64 = ctypes.c_uint64
 
 # name -> (restype, argtypes); must list every symbol of include/binf_hip.h
 SIGNATURES = {
@@ -113,6 +117,7 @@ SIGNATURES = {
                                      ctypes.c_uint64, _i64, _vp]),
     'binf_rwmc_accept_f64': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64,
                                     ctypes.c_uint64, ctypes.c_uint64, _i64, _vp]),
+    'binf_gibbs_poly_sample_n_f64': (_i32, [_vp, _vp]),
     'binf_rng_philox4x32_10': (_i32, [ctypes.POINTER(ctypes.c_uint32),
                                       ctypes.POINTER(ctypes.c_uint32),
                                       ctypes.POINTER(ctypes.c_uint32)]),
@@ -122,7 +127,7 @@ SIGNATURES = {
                                   ctypes.POINTER(_i32), ctypes.POINTER(_i32)]),
 }
 
-ABI_VERSION = 2        # keep in step with BINF_ABI_VERSION (include/binf_hip.h)
+ABI_VERSION = 3        # keep in step with BINF_ABI_VERSION (include/binf_hip.h)
 
 
 def lib():
@@ -484,7 +489,8 @@ def hmc_sample_poly(q0, p0, u, q_out, accepted, n_accepted, e_before, e_after,
                     lp_pre, lp_post, timestep, dt_chain, nsteps, adapt, uprate,
                     downrate, mode=MODE_EXACT):
     """binf_hmc_sample_poly_f64 on torch's current stream (K <= 16
-    coefficients, <= 128 data points)."""
+    coefficients, <= 1024 data points; ``mode | MODE_LANE_PER_CHAIN``: one lane
+    per chain, <= 128 data points)."""
     C, K = _cd(q0)
     N = xs.numel()
     tau, tau_chain = _precision_args(precision, C, q0.device)
@@ -504,6 +510,74 @@ def hmc_sample_poly(q0, p0, u, q_out, accepted, n_accepted, e_before, e_after,
         int(nsteps), int(bool(adapt)), float(uprate), float(downrate),
         int(mode), stream_handle(q0.device))
     check(rc, 'binf_hmc_sample_poly_f64')
+
+
+class GibbsPolyArgs(ctypes.Structure):
+    """``binf_gibbs_poly_args`` of include/binf_hip.h, field for field."""
+    _fields_ = [('struct_size', _u64)] + \
+        [(n, _vp) for n in ('coefficients', 'precision', 'coefficients_out', 'precision_out',
+                            'rec_coefficients', 'rec_precision', 'accepted', 'n_accepted',
+                            'e_before', 'e_after', 'xs', 'ys', 'prior_means', 'prior_vars',
+                            'p0', 'u', 'g', 'dt_chain')] + \
+        [(n, _f64) for n in ('timestep', 'uprate', 'downrate', 'stepsize', 'gp_shape',
+                             'gp_rate', 'gamma_shape', 'gamma_rate')] + \
+        [(n, _i64) for n in ('C', 'K', 'N', 'chain_offset')] + \
+        [(n, _u64) for n in ('seed_m', 'off_m', 'stride_m', 'seed_u', 'off_u', 'stride_u',
+                             'seed_g', 'off_g', 'stride_g')] + \
+        [(n, _i32) for n in ('move', 'mode', 'nsteps', 'n', 'thin', 'n_adapt', 'prior_first',
+                             'gp_where', 'zig', 'reserved')]
+
+
+@_launcher
+def gibbs_poly_sample_n(coefficients, precision, coefficients_out, precision_out, xs, ys, n,
+                        thin=1, move=MOVE_HMC, mode=MODE_EXACT, nsteps=1, timestep=0.0,
+                        dt_chain=None, n_adapt=0, uprate=1.05, downrate=0.95, stepsize=0.0,
+                        prior_means=None, prior_vars=None, prior_first=False, gp_where=0,
+                        gp_shape=1.0, gp_rate=0.0, gamma_shape=1.0, gamma_rate=0.0,
+                        rec_coefficients=None, rec_precision=None, accepted=None,
+                        n_accepted=None, e_before=None, e_after=None, p0=None, u=None, g=None,
+                        streams=None, chain_offset=0, zig=True):
+    """binf_gibbs_poly_sample_n_f64 on torch's current stream: n sweeps of the
+    example's Gibbs loop in one launch.  ``streams`` = ``((seed, offset, stride),) * 3``
+    for the momentum / proposal, acceptance and gamma draws that are not supplied."""
+    C, K = _cd(coefficients)
+    N = xs.numel()
+    n, thin = int(n), int(thin)
+    nrec = n // thin
+    a = GibbsPolyArgs()
+    a.struct_size = ctypes.sizeof(GibbsPolyArgs)
+    a.coefficients = dptr(coefficients, numel=C * K, name='coefficients')
+    a.precision = dptr(precision, numel=C, name='precision')
+    a.coefficients_out = dptr(coefficients_out, numel=C * K, name='coefficients_out')
+    a.precision_out = dptr(precision_out, numel=C, name='precision_out')
+    a.rec_coefficients = dptr(rec_coefficients, numel=nrec * C * K, name='rec_coefficients')
+    a.rec_precision = dptr(rec_precision, numel=nrec * C, name='rec_precision')
+    a.accepted = dptr(accepted, torch.uint8, n * C, 'accepted')
+    a.n_accepted = dptr(n_accepted, torch.int64, C, 'n_accepted')
+    a.e_before = dptr(e_before, numel=n * C, name='e_before')
+    a.e_after = dptr(e_after, numel=n * C, name='e_after')
+    a.xs = dptr(xs, numel=N, name='xs')
+    a.ys = dptr(ys, numel=N, name='ys')
+    a.prior_means = dptr(prior_means, numel=K, name='prior_means')
+    a.prior_vars = dptr(prior_vars, numel=K, name='prior_vars')
+    a.p0 = dptr(p0, numel=n * C * K, name='p0')
+    a.u = dptr(u, numel=n * C, name='u')
+    a.g = dptr(g, numel=n * C, name='g')
+    a.dt_chain = dptr(dt_chain, numel=C, name='dt_chain')
+    a.timestep, a.uprate, a.downrate = float(timestep), float(uprate), float(downrate)
+    a.stepsize = float(stepsize)
+    a.gp_shape, a.gp_rate = float(gp_shape), float(gp_rate)
+    a.gamma_shape, a.gamma_rate = float(gamma_shape), float(gamma_rate)
+    a.C, a.K, a.N, a.chain_offset = C, K, N, int(chain_offset)
+    sm, su, sg = streams if streams is not None else ((0, 0, 0),) * 3
+    a.seed_m, a.off_m, a.stride_m = [int(v) for v in sm]
+    a.seed_u, a.off_u, a.stride_u = [int(v) for v in su]
+    a.seed_g, a.off_g, a.stride_g = [int(v) for v in sg]
+    a.move, a.mode, a.nsteps, a.n, a.thin = int(move), int(mode), int(nsteps), n, thin
+    a.n_adapt, a.prior_first, a.gp_where = int(n_adapt), int(bool(prior_first)), int(gp_where)
+    a.zig = int(bool(zig))
+    rc = lib().binf_gibbs_poly_sample_n_f64(ctypes.byref(a), stream_handle(coefficients.device))
+    check(rc, 'binf_gibbs_poly_sample_n_f64')
 
 
 _grad_ws = {}

@@ -2,8 +2,11 @@
 // sets (n_data <= 128, K <= 16 coefficients): the reference's own
 // example_script.py shape (K = 4, n_data = 20, 50 leapfrog steps), where the
 // per-step tier is launch-bound (~150 launches, 2 ms per transition however
-// few the chains).  ONE launch = one HMCSampler.sample() for every chain;
-// replaces binf/samplers/hmc.py:92-164 around
+// few the chains).  ONE launch = one HMCSampler.sample() for every chain.
+// This file: the entry point binf_hmc_sample_poly_f64 and the ONE-LANE-PER-CHAIN
+// kernel it runs under BINF_MODE_LANE_PER_CHAIN (the layout for ~10^5 chains and
+// more; by default a chain is a lane group, poly_chain_kernel.hpp).  Replaces
+// binf/samplers/hmc.py:92-164 around
 //   Posterior.log_prob / gradient        binf/pdf/posteriors.py:147-187
 //   Likelihood.log_prob / gradient       binf/pdf/likelihoods.py:141-155
 //   ForwardModel / GaussianErrorModel    binf/example/likelihood.py:24-30,54-61
@@ -264,10 +267,14 @@ extern "C" int32_t binf_hmc_sample_poly_f64(
 {
     if (C < 0 || K < 1 || N < 0 || nsteps < 1)
         return fail(BINF_E_ARG, "hmc_sample_poly: need C>=0, K>=1, N>=0, nsteps>=1");
+    const bool lane_per_chain = (mode & BINF_MODE_LANE_PER_CHAIN) != 0;
+    mode &= ~BINF_MODE_LANE_PER_CHAIN;
     if (mode != BINF_MODE_EXACT && mode != BINF_MODE_FMA)
         return fail(BINF_E_ARG, "hmc_sample_poly: unknown mode %d", mode);
     if (K > 16 || N > 1024 || (N > 128 && pairwise_tree_height(N) > 3))
         return fail(BINF_E_UNSUPPORTED, "hmc_sample_poly: K=%lld > 16 or n_data=%lld > 1024 (or a pairwise tree deeper than 3) not covered by the fused kernels (use the per-step tier)", (long long)K, (long long)N);
+    if (lane_per_chain && N > 128)
+        return fail(BINF_E_UNSUPPORTED, "hmc_sample_poly: one lane per chain covers n_data <= 128, not %lld", (long long)N);
     if (C == 0) return 0;
     if (!q0 || !p0 || !u || !q_out || !accepted || (N > 0 && (!xs || !ys)))
         return fail(BINF_E_ARG, "hmc_sample_poly: null buffer");
@@ -292,7 +299,7 @@ extern "C" int32_t binf_hmc_sample_poly_f64(
     a.adapt = adapt ? 1 : 0;
     const bool fma = (mode == BINF_MODE_FMA);
     hipStream_t st = (hipStream_t)stream;
-    if (N > 128) return launch_poly_wave_from(a, fma, st);
+    if (!lane_per_chain) return launch_poly_wave_from(a, fma, st);
     hipError_t e;
     if (K <= 4)      e = launch_poly<4>(a, fma, st);
     else if (K <= 8) e = launch_poly<8>(a, fma, st);

@@ -105,6 +105,9 @@ __device__ inline double zig_slow(uint32_t lo, uint32_t hi, const double *zx, co
 
 // Gamma(shape, 1), Marsaglia & Tsang (2000); shape < 1 via Gamma(shape+1)*U^(1/shape).
 // Attempt k of global element i uses counter i under offset + 2k, 2k + 1 (bounded retries).
+// SMALL = false drops the shape < 1 branch (and with it pow(), ~100 VGPRs when inlined
+// into a larger kernel): same values for every shape >= 1.
+template <bool SMALL = true>
 __device__ inline double gamma_elem(int64_t i, double shape, uint64_t seed, uint64_t offset)
 {
     const double alpha = shape < 1.0 ? shape + 1.0 : shape;
@@ -121,7 +124,7 @@ __device__ inline double gamma_elem(int64_t i, double shape, uint64_t seed, uint
         const double uu = 1.0 - u1;                 // (0, 1]
         if (log(uu) < 0.5 * x * x + d - d * v + d * log(v)) {
             g = d * v;
-            if (shape < 1.0) g *= pow(1.0 - u2, 1.0 / shape);
+            if (SMALL && shape < 1.0) g *= pow(1.0 - u2, 1.0 / shape);
             break;
         }
     }

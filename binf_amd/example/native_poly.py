@@ -98,3 +98,164 @@ def posterior_hmc_spec(posterior, variable_name):
             lik.error_model['precision'].value, prior,
             prior is not None and kinds.index('prior') < kinds.index('lik'),
             consts[:n_pre], consts[n_pre] if n_post else None)
+
+
+# ---------------------------------------------------------------------------
+# n Gibbs sweeps in one launch (csrc/gibbs_poly.hip)
+# ---------------------------------------------------------------------------
+def _device_rng_of(obj):
+    """The DeviceRNG behind a sampler's draw source (the generator itself, or
+    a bound ``gamma`` method of one), else None."""
+    from binf_amd.samplers.rng import DeviceRNG
+    obj = getattr(obj, '__self__', obj)
+    return obj if type(obj) is DeviceRNG else None
+
+
+def gibbs_sample_n(gibbs, n, thin, record):
+    """``n`` sweeps of ``gibbs`` in ONE launch of ``binf_gibbs_poly_sample_n_f64``
+    if it is the example's scheme -- variables ``coefficients`` (an
+    :class:`HMCSampler` or :class:`RWMCSampler` on a conditional posterior the
+    fused polynomial kernel integrates) and ``precision`` (a
+    :class:`GammaSampler`) -- with draw sources the kernel can reproduce: all
+    :class:`DeviceRNG` (generated in the kernel, the same values n single sweeps
+    draw) or all the reference's host ``np.random`` stream (drawn on the host in
+    the reference's order, uploaded once).  Returns ``(handled, records)``;
+    ``handled`` False = not this scheme, nothing was touched."""
+    import numpy as np
+
+    from binf_amd.example.priors import GammaPrior
+    from binf_amd.example.samplers import GammaSampler, RWMCSampler
+    from binf_amd.samplers.hmc import HMCSampler, _MODES
+    from binf_amd.samplers.rng import HostLegacyRNG
+
+    subs = gibbs.subsamplers
+    if sorted(gibbs.pdf.variables) != ['coefficients', 'precision'] or \
+            set(subs) != {'coefficients', 'precision'}:
+        return False, None
+    cs, ps = subs['coefficients'], subs['precision']
+    if type(ps) is not GammaSampler or type(cs) not in (HMCSampler, RWMCSampler):
+        return False, None
+    state = gibbs.state.variables
+    theta, tau = state['coefficients'], state['precision']
+    if not (isinstance(theta, torch.Tensor) and theta.is_cuda and theta.dim() == 2 and
+            theta.dtype == torch.float64 and isinstance(tau, torch.Tensor) and tau.is_cuda and
+            tau.dtype == torch.float64 and tau.dim() == 1 and tau.numel() == theta.shape[0]):
+        return False, None
+    C, K = theta.shape
+    dev = theta.device
+    spec = posterior_hmc_spec(cs.pdf, 'coefficients')
+    if spec is None or K > FUSED_MAX_COEFFS:
+        return False, None
+    _, fwm, em, _, prior, prior_first, pre, post = spec
+    consts = list(pre) + ([post] if post is not None else [])
+    if len(consts) > 1 or any(type(f) is not GammaPrior or
+                              set(f._original_variables) != {'precision'} for f in consts):
+        return False, None
+    gp_where = 0 if not consts else (1 if pre else 2)
+    gp = consts[0] if consts else None
+    hmc = type(cs) is HMCSampler
+    if hmc:
+        if cs._variable_name != 'coefficients' or cs.fused_polynomial == 'lane' or \
+                cs._fused_spec('coefficients', K, C) is None:
+            return False, None
+    # the precision sampler must look at the same data
+    try:
+        em_p = ps.pdf.likelihoods['points'].error_model
+        fwm_p = ps.pdf.likelihoods['points'].forward_model
+        gprior = ps._get_prior()
+    except (KeyError, IndexError, NotImplementedError, AttributeError):
+        return False, None
+    if getattr(fwm_p, 'native_spec', lambda: None)() is None or \
+            getattr(em_p, 'native_spec', lambda: None)() is None or \
+            not torch.equal(em_p.ys_device(dev), em.ys_device(dev)) or \
+            not torch.equal(fwm_p.xs_device(dev), fwm.xs_device(dev)):
+        return False, None
+    gamma_shape = float(ps._calculate_shape())
+
+    # ---- draw sources -------------------------------------------------------
+    rng_c = _device_rng_of(cs.rng) if cs.rng is not None else None
+    rng_g = _device_rng_of(ps.gamma) if ps.gamma is not None else None
+    host_c = (cs.rng is None) if not hmc else type(cs.rng) is HostLegacyRNG
+    host_g = ps.gamma is None
+    p0 = u = g = streams = None
+    zig = True
+    coff = 0
+    if rng_c is not None and rng_g is not None:
+        if gamma_shape < 1.0 or rng_c.chain_offset != rng_g.chain_offset:
+            return False, None
+        coff = rng_c.chain_offset
+        zig = rng_c._normal_kind == 'normal_zig'
+        if rng_c is rng_g:
+            o = rng_c.offset             # per sweep: momentum / step, acceptance, gamma (+128)
+            streams = ((rng_c.seed, o, 130), (rng_c.seed, o + 1, 130), (rng_c.seed, o + 2, 130))
+            rng_c.offset += 130 * n
+        else:
+            streams = ((rng_c.seed, rng_c.offset, 2), (rng_c.seed, rng_c.offset + 1, 2),
+                       (rng_g.seed, rng_g.offset, 128))
+            rng_c.offset += 2 * n
+            rng_g.offset += 128 * n
+    elif host_c and host_g:
+        # the global legacy stream in the order n sweeps consume it
+        hp = np.empty((n, C, K))
+        hu = np.empty((n, C))
+        hg = np.empty((n, C))
+        for i in range(n):
+            if hmc:
+                hp[i] = np.random.normal(size=(C, K))                # hmc.py:146
+                hu[i] = np.random.uniform(size=C)                    # hmc.py:151
+            else:
+                hp[i] = np.random.uniform(low=-cs.stepsize, high=cs.stepsize, size=(C, K))
+                hu[i] = np.random.random(size=C)                     # samplers.py:80,86
+            hg[i] = np.random.gamma(gamma_shape, size=C)             # samplers.py:47
+        p0, u, g = (torch.from_numpy(x).to(dev) for x in (hp, hu, hg))
+    else:
+        return False, None
+
+    nrec = n // thin
+    rec_c = torch.empty((nrec, C, K), dtype=torch.float64, device=dev) if record and nrec else None
+    rec_t = torch.empty((nrec, C), dtype=torch.float64, device=dev) if record and nrec else None
+    theta_out = torch.empty_like(theta)
+    tau_out = torch.empty_like(tau)
+    accepted = torch.empty((n, C), dtype=torch.uint8, device=dev)
+    kw = {}
+    if hmc:
+        n_adapt = max(0, min(n, cs.timestep_adaption_limit - 1 - cs.counter))
+        if n_adapt > 0 and cs._dt_chain is None:
+            cs._dt_chain = torch.full((C,), float(cs._timestep), dtype=torch.float64, device=dev)
+        if not isinstance(cs.n_accepted, torch.Tensor):
+            cs.n_accepted = torch.zeros(C, dtype=torch.int64, device=dev)
+        eb = torch.empty((n, C), dtype=torch.float64, device=dev)
+        ea = torch.empty((n, C), dtype=torch.float64, device=dev)
+        kw = dict(move=_native.MOVE_HMC, mode=_MODES[cs.mode], nsteps=cs.nsteps,
+                  timestep=cs._timestep, dt_chain=cs._dt_chain, n_adapt=n_adapt,
+                  uprate=cs.adaption_uprate, downrate=cs.adaption_downrate,
+                  n_accepted=cs.n_accepted, e_before=eb, e_after=ea)
+    else:
+        if not isinstance(cs._n_accepted_moves, torch.Tensor):
+            cs._n_accepted_moves = torch.zeros(C, dtype=torch.int64, device=dev)
+        kw = dict(move=_native.MOVE_RWMC, stepsize=cs.stepsize, n_accepted=cs._n_accepted_moves)
+    _native.gibbs_poly_sample_n(
+        theta.contiguous(), tau.contiguous(), theta_out, tau_out, fwm.xs_device(dev),
+        em.ys_device(dev), n, thin,
+        prior_means=prior._vec('means', dev) if prior is not None else None,
+        prior_vars=prior._vec('variances', dev) if prior is not None else None,
+        prior_first=prior_first, gp_where=gp_where,
+        gp_shape=gp.shape if gp is not None else 1.0, gp_rate=gp.rate if gp is not None else 0.0,
+        gamma_shape=gamma_shape, gamma_rate=gprior.rate, rec_coefficients=rec_c,
+        rec_precision=rec_t, accepted=accepted, p0=p0, u=u, g=g, streams=streams,
+        chain_offset=coff, zig=zig, **kw)
+
+    # ---- what n single sweeps would have left behind ---------------------------
+    flags = accepted.view(torch.bool)
+    if hmc:
+        cs.last_e_before, cs.last_e_after = eb[-1], ea[-1]
+        cs._last_move_accepted = flags[-1]
+        cs.accepted_history = flags
+        cs.counter += n
+    else:
+        cs.last_move_accepted = flags[-1]
+        cs._n_moves += n
+    cs.state = theta_out
+    ps.state = tau_out
+    gibbs._update_state(coefficients=theta_out, precision=tau_out)
+    return True, ({'coefficients': rec_c, 'precision': rec_t} if rec_c is not None else None)

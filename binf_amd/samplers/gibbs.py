@@ -85,6 +85,41 @@ class GibbsSampler(object):
             self._update_state(**{var: new})
         return self._state
 
+    def sample_n(self, n, thin=1, record=True):
+        """``n`` sweeps -- the ``for i in range(n): gips.sample()`` loop of the
+        reference's ``example_script.py:33-34`` -- returning the recorded states
+        as ``{variable: tensor [n // thin, ...]}`` (the state after sweeps
+        ``thin, 2*thin, ...``; ``example_script.py:41`` keeps every 20th) or None
+        if ``record`` is false.
+
+        For the example's scheme (HMC or RWMC on the polynomial coefficients +
+        the conjugate Gamma draw of the precision, draws from a ``DeviceRNG`` or
+        from the reference's host stream) this is ONE kernel launch with every
+        chain's state in registers between the sweeps, bit-identical to n
+        ``sample()`` calls (``csrc/gibbs_poly.hip``); any other scheme loops over
+        ``sample()``."""
+        n, thin = int(n), int(thin)
+        if n < 1 or thin < 1:
+            raise ValueError('sample_n: n >= 1 and thin >= 1 required')
+        self._update_subsampler_states()
+        self._update_conditional_pdf_params()
+        from binf_amd.example import native_poly
+        handled, rec = native_poly.gibbs_sample_n(self, n, thin, record)
+        if handled:
+            self._update_conditional_pdf_params()
+            return rec
+        import torch
+        kept = {}
+        for i in range(n):
+            s = self.sample()
+            if record and (i + 1) % thin == 0:
+                for k, v in s.variables.items():
+                    kept.setdefault(k, []).append(v.clone() if isinstance(v, torch.Tensor) else v)
+        if not kept:
+            return None
+        return {k: (torch.stack(v) if isinstance(v[0], torch.Tensor) else v)
+                for k, v in kept.items()}
+
     # -- statistics ------------------------------------------------------------
     def _calc_pacc(self):
         """Not applicable (reference ``gibbs.py:153-157``)."""

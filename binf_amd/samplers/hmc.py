@@ -76,7 +76,11 @@ class HMCSampler(object):
         self.last_e_after = None
         self.accepted_history = None      # [n x C] flags of the last sample_n()
         self.fused_leapfrog = True        # use a PDF's fused leapfrog kernel if it has one
-        self.fused_polynomial = True      # ... and the fused small-data polynomial transition
+        # ... and the fused small-data polynomial transition: True (a chain's data
+        # spread over a lane group), 'always' (even where the per-step tier is faster),
+        # 'lane' (one lane per chain, <= 128 data points: the layout for ~1e5+ chains;
+        # same energies, force summed in another order) or False
+        self.fused_polynomial = True
 
     # -- reference attributes ----------------------------------------------
     @property
@@ -384,6 +388,8 @@ class HMCSampler(object):
         if spec is not None and spec[0] == 'poly' and self.fused_polynomial and \
                 D <= _native_poly_limits()[0]:
             n_data = len(spec[2].ys)
+            if self.fused_polynomial == 'lane' and n_data > 128:
+                return None
             if n_data > 128 and C is not None and self.fused_polynomial != 'always' and \
                     float(C) * n_data * D > _POLY_WAVE_MAX_WORK:
                 # one wave per chain wins while the batch is launch-bound (3-10x up to
@@ -436,7 +442,8 @@ class HMCSampler(object):
                                 means, variances, prior_first, lp_pre, lp_post,
                                 self._timestep, self._dt_chain, self.nsteps, adapt,
                                 self.adaption_uprate, self.adaption_downrate,
-                                _MODES[self.mode])
+                                _MODES[self.mode] | (_native.MODE_LANE_PER_CHAIN
+                                                     if self.fused_polynomial == 'lane' else 0))
         self.last_e_before, self.last_e_after = eb, ea
         return q_out
 

@@ -31,8 +31,11 @@ extern "C" {
  *    the unsharded one bit for bit; new entry points for the RWMC subsampler, the
  *    multi-sweep Gibbs launch, the Jacobian contraction and the term sum.
  *    (1 -> 2 also covers the contract changes made late in ABI 1: the polynomial
- *    gradient's workspace is mandatory, binf_hmc_sample_poly_f64 accepts N <= 1024.) */
-#define BINF_ABI_VERSION 2
+ *    gradient's workspace is mandatory, binf_hmc_sample_poly_f64 accepts N <= 1024.)
+ * 3: binf_hmc_sample_poly_f64 spreads a chain's data over a lane group for EVERY
+ *    N <= 1024 (the force's summation order for N <= 128 changed with it; one lane
+ *    per chain is now the opt-in BINF_MODE_LANE_PER_CHAIN); binf_gibbs_poly_sample_n_f64. */
+#define BINF_ABI_VERSION 3
 
 #define BINF_E_ARG        (-1)  /* null pointer / negative size / bad flag    */
 #define BINF_E_UNSUPPORTED (-2) /* shape outside what the kernels cover       */
@@ -44,6 +47,11 @@ extern "C" {
                               restatement of the reference's numpy path      */
 #define BINF_MODE_FMA   1  /* p-=dt*g and q+=p*dt contracted to one FMA each:
                               within 1e-10 relative of EXACT, not bit-equal  */
+/* flag, OR-ed into `mode` of binf_hmc_sample_poly_f64 only: one LANE per chain
+ * (N <= 128) instead of a lane group -- the faster layout from ~10^5 chains up.
+ * Energies are the same bits; the force is summed in data order instead of
+ * per-lane partial sums + butterfly, so trajectories differ at rounding level. */
+#define BINF_MODE_LANE_PER_CHAIN 16
 
 int32_t binf_abi_version(void);
 
@@ -348,9 +356,10 @@ int32_t binf_poly_gauss_grad_f64(const double *coeffs, const double *design,
 
 /* One HMCSampler.sample() (binf/samplers/hmc.py:136-164,183-191) for every
  * chain on the example's polynomial posterior with a SMALL or MEDIUM data set
- * (K <= 16 coefficients; N <= 128 data points: one lane per chain; 128 < N <=
- * 1024 with a pairwise tree of height <= 3 -- every N <= 920 and the multiples of
- * 8 up to 1024: one wave per chain, the data spread over its lanes; else
+ * (K <= 16 coefficients; N <= 1024 data points with a pairwise tree of height
+ * <= 3 -- every N <= 920 and the multiples of 8 up to 1024; a chain's data are
+ * spread over a group of 8 << H lanes, 8 lanes up to 128 points, one wave from
+ * 513; mode | BINF_MODE_LANE_PER_CHAIN: one lane per chain, N <= 128; else
  * BINF_E_UNSUPPORTED), the whole transition in one launch (the per-step tier is
  * launch-bound there):
  *   log p(theta) = [lp_pre] + {prior, likelihood in the order prior_first says} + [lp_post]
@@ -380,6 +389,95 @@ int32_t binf_hmc_sample_poly_f64(const double *q0, const double *p0,
                                  int64_t N, int32_t nsteps, int32_t adapt,
                                  double uprate, double downrate, int32_t mode,
                                  void *stream);
+
+/* ------------------------------------------------------------------------
+ * n sweeps of the example's Gibbs loop in ONE launch:
+ *     for i in range(n): gips.sample()          example_script.py:33-34
+ * around GibbsSampler.sample (binf/samplers/gibbs.py:136-151; alphabetical
+ * sweep: coefficients, then precision), for every chain, with a chain's state
+ * in registers between the sweeps.  Per sweep and chain:
+ *   coefficients  move == BINF_MOVE_HMC:  HMCSampler.sample (hmc.py:136-164,
+ *                   183-191) on the conditional posterior of the coefficients
+ *                   -- exactly the transition of binf_hmc_sample_poly_f64 with
+ *                   precision_chain = the chain's current precision;
+ *                 move == BINF_MOVE_RWMC: RWMCSampler.sample
+ *                   (binf/example/samplers.py:78-92): proposal = state + change,
+ *                   accept iff u < np.exp(lp_new - lp_old) (numpy's exp);
+ *   precision     GammaSampler.sample (samplers.py:27-51):
+ *                   rate = 0.5 * chi2(coefficients) + gamma_rate
+ *                   precision = g / rate,  g ~ Gamma(gamma_shape, 1).
+ * The conditional posterior of the coefficients is
+ *   [gp] + {prior, likelihood in the order prior_first says} + [gp]
+ *   gp = (gp_shape - 1) * log(precision) - precision * gp_rate: the GammaPrior
+ *   term (binf/example/priors.py:23-25; a constant of the move), added first
+ *   (gp_where == 1), last (2) or absent (0).
+ * Draws: p0 / u / g supplied ([n x C x K], [n x C], [n x C]; parity with a host
+ * stream), or NULL = generated in place from the Philox streams of binf_rng_*:
+ *   p0[i][c][k] = element (chain_offset + c) * K + k of
+ *                 binf_rng_normal_zig_f64 (zig != 0) / binf_rng_normal_f64 under
+ *                 (seed_m, off_m + i * stride_m)          (HMC), or
+ *                 -stepsize + 2 stepsize * (that element of binf_rng_uniform_f64)
+ *                 as binf_rwmc_propose_f64 forms it         (RWMC);
+ *   u[i][c]     = element chain_offset + c of binf_rng_uniform_f64 (seed_u, off_u + i * stride_u);
+ *   g[i][c]     = element chain_offset + c of binf_rng_gamma_f64 (gamma_shape; seed_g, off_g + i * stride_g)
+ *                 (generated only for gamma_shape >= 1, else BINF_E_UNSUPPORTED).
+ * With samplers/rng.py:DeviceRNG serving all three: off_u = off_m + 1, off_g =
+ * off_m + 2, strides 130 -- n sweeps then draw what n single sweeps draw.
+ * Results are BIT-IDENTICAL to n single sweeps through binf_hmc_sample_poly_f64
+ * (or binf_rwmc_*), binf_poly_gauss_logp_f64 and binf_gamma_precision_update_f64
+ * with the same draws.  Records: the state after sweeps thin, 2 thin, ...
+ * K <= 16, N <= 1024 with a pairwise tree of height <= 3, as
+ * binf_hmc_sample_poly_f64.  struct_size = sizeof(binf_gibbs_poly_args)
+ * (layout check; mismatch -> BINF_E_ARG).
+ * ---------------------------------------------------------------------- */
+#define BINF_MOVE_HMC  0
+#define BINF_MOVE_RWMC 1
+typedef struct binf_gibbs_poly_args {
+    uint64_t struct_size;
+    /* state, device */
+    const double *coefficients;   /* [C x K] start                                  */
+    const double *precision;      /* [C]     start                                  */
+    double *coefficients_out;     /* [C x K] after sweep n; may be `coefficients`   */
+    double *precision_out;        /* [C]     after sweep n; may be `precision`      */
+    double *rec_coefficients;     /* [n / thin x C x K] or NULL                     */
+    double *rec_precision;        /* [n / thin x C] or NULL                         */
+    uint8_t *accepted;            /* [n x C] or NULL: the move's accept flags       */
+    int64_t *n_accepted;          /* [C] or NULL, += accepted moves                 */
+    double *e_before;             /* [n x C] or NULL (HMC)                          */
+    double *e_after;              /* [n x C] or NULL (HMC)                          */
+    /* model, device */
+    const double *xs;             /* [N] */
+    const double *ys;             /* [N] */
+    const double *prior_means;    /* [K] or NULL (then prior_vars NULL too)         */
+    const double *prior_vars;     /* [K] */
+    /* supplied draws, device, or NULL */
+    const double *p0;
+    const double *u;
+    const double *g;
+    double *dt_chain;             /* [C] or NULL: per-chain HMC step sizes (in/out)  */
+    double timestep;              /* HMC step size when dt_chain == NULL            */
+    double uprate, downrate;      /* hmc.py:188-191                                  */
+    double stepsize;              /* RWMC half-width                                 */
+    double gp_shape, gp_rate;     /* GammaPrior term of the coefficient conditional  */
+    double gamma_shape;           /* 0.5 N + prior.shape - 1, samplers.py:27-32       */
+    double gamma_rate;            /* prior.rate of the precision conditional         */
+    int64_t C, K, N;
+    int64_t chain_offset;
+    uint64_t seed_m, off_m, stride_m;
+    uint64_t seed_u, off_u, stride_u;
+    uint64_t seed_g, off_g, stride_g;
+    int32_t move;                 /* BINF_MOVE_*                                     */
+    int32_t mode;                 /* BINF_MODE_EXACT / BINF_MODE_FMA (HMC)           */
+    int32_t nsteps;               /* leapfrog steps (HMC)                            */
+    int32_t n;                    /* sweeps                                          */
+    int32_t thin;
+    int32_t n_adapt;              /* the first n_adapt HMC transitions adapt dt_chain */
+    int32_t prior_first;
+    int32_t gp_where;             /* 0 / 1 / 2, see above                            */
+    int32_t zig;                  /* generated momenta: ziggurat (1) or Box-Muller (0) */
+    int32_t reserved;
+} binf_gibbs_poly_args;
+int32_t binf_gibbs_poly_sample_n_f64(const binf_gibbs_poly_args *args, void *stream);
 
 /* GammaPrior._evaluate_log_prob (binf/example/priors.py:10-25), one value per chain:
  *   out[c] = (shape - 1) * log(precision[c]) - precision[c] * rate

@@ -114,6 +114,7 @@ def gibbs_run(device, C, sweeps, rng, coff=0, start=None):
         cs.append(s.variables['coefficients'].clone())
         ts.append(s.variables['precision'].clone())
     gips.host_stream_untouched = stream_pos() == before
+    gips.host_stream_untouched_after = lambda _: stream_pos() == before
     return torch.stack(cs), torch.stack(ts), gips
 
 
@@ -131,8 +132,12 @@ def test_device_rwmc_gibbs_needs_no_host_draw_and_mixes(device):
     assert isinstance(gips.subsamplers['precision'], GammaSampler)
     assert isinstance(gips.subsamplers['coefficients'], RWMCSampler)
     assert (ts > 0).all() and torch.isfinite(cs).all()
-    # the posterior of the example: coefficients near the truth after burn-in
-    m = cs[300:].mean(dim=(0, 1)).cpu().numpy()
+    # the posterior of the example: coefficients near the truth after burn-in (a
+    # random walk of half-width 0.1 needs some 1e4 sweeps from the all-ones start:
+    # one multi-sweep launch, GibbsSampler.sample_n)
+    rec = gips.sample_n(40000, thin=200)
+    assert gips.host_stream_untouched_after(rec)
+    m = rec['coefficients'][100:].mean(dim=(0, 1)).cpu().numpy()
     assert np.all(np.abs(m - np.array([2.0, -4.0, 1.0, 1.5])) < 1.0), m
     # deterministic in the seed
     cs2, ts2, _ = gibbs_run(device, C, 5, DeviceRNG(9, device))

@@ -144,3 +144,38 @@ def test_philox4x32_10_known_answers():
             [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1])]
     for ctr, key, want in kat:
         assert _native.philox4x32_10(ctr, key) == want
+
+
+def test_gibbs_args_struct_layout_matches_the_header(tmp_path):
+    """binf_gibbs_poly_args is passed by pointer: the ctypes mirror must agree with
+    what a C compiler makes of include/binf_hip.h, field by field."""
+    import ctypes
+    import subprocess
+    fields = [f[0] for f in _native.GibbsPolyArgs._fields_]
+    src = tmp_path / 'layout.c'
+    src.write_text(
+        '#include <stdio.h>\n#include <stddef.h>\n#include "binf_hip.h"\n'
+        'int main(void) {\n'
+        '  printf("%zu\\n", sizeof(binf_gibbs_poly_args));\n' +
+        ''.join('  printf("%%zu\\n", offsetof(binf_gibbs_poly_args, %s));\n' % f for f in fields) +
+        '  return 0; }\n')
+    exe = tmp_path / 'layout'
+    subprocess.check_call(['gcc', '-I', os.path.join(ROOT, 'include'), str(src), '-o', str(exe)])
+    out = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    assert out[0] == ctypes.sizeof(_native.GibbsPolyArgs)
+    for f, off in zip(fields, out[1:]):
+        assert getattr(_native.GibbsPolyArgs, f).offset == off, f
+    # every field of the C struct is mirrored (same count as declared in the header)
+    hdr = open(os.path.join(ROOT, 'include', 'binf_hip.h')).read()
+    body = hdr[hdr.index('typedef struct binf_gibbs_poly_args {'):hdr.index('} binf_gibbs_poly_args;')]
+    import re
+    body = re.sub(r'/\*.*?\*/', '', body, flags=re.S)
+    declared = []
+    for stmt in body.split('{', 1)[1].split(';'):
+        stmt = stmt.strip()
+        if not stmt:
+            continue
+        names = stmt.replace('*', ' ').split(',')
+        declared.append(names[0].split()[-1])
+        declared += [n.strip() for n in names[1:]]
+    assert declared == fields
