@@ -83,4 +83,33 @@ __device__ inline double shfl_f64(double v, int src)
     return __shfl(v, src, 64);
 }
 
+// The same moves through the DPP path of the VALU (a few cycles; __shfl is a
+// ds_bpermute pair through the LDS crossbar, ~100 cycles of latency each way).
+template <int CTRL>
+__device__ inline double dpp_f64(double v)
+{
+    // every control used below reads a valid lane for every lane (all rows and banks
+    // enabled), so no lane keeps an old value: bound_ctrl lets the move write a fresh
+    // register instead of copying the source first (the copy sat on the critical path)
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ inline double xor1_f64(double v) { return dpp_f64<0xB1>(v); }    // quad_perm [1,0,3,2]
+__device__ inline double xor2_f64(double v) { return dpp_f64<0x4E>(v); }    // quad_perm [2,3,0,1]
+__device__ inline double xor8_f64(double v) { return dpp_f64<0x128>(v); }   // row_ror:8 (rows of 16)
+// lane i <- lane 7 - i of its aligned group of 8 (row_half_mirror): the partner sits in
+// the OTHER quad, which is all the third level of an 8-lane sum tree needs once the four
+// lanes of a quad hold the same value -- then the same bits as an xor-4 exchange
+__device__ inline double other_quad_f64(double v) { return dpp_f64<0x141>(v); }
+
+// all-reduce sum over aligned groups of 8 lanes in the order
+// ((v0+v1)+(v2+v3))+((v4+v5)+(v6+v7)); every lane ends with the same bits
+__device__ inline double sum8_f64(double r)
+{
+    r = r + xor1_f64(r);
+    r = r + xor2_f64(r);
+    return r + other_quad_f64(r);
+}
+
 }  // namespace binf

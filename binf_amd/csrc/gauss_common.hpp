@@ -109,11 +109,8 @@ __device__ inline double chain_sum_finish(const LaneSum &s, int T, int rem,
                                           int lane, int H, int leafdepth,
                                           double *xch = nullptr, int wib = 0)
 {
-    double r = s.r;
     // ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7))
-    r = r + shfl_xor_f64(r, 1);
-    r = r + shfl_xor_f64(r, 2);
-    r = r + shfl_xor_f64(r, 4);
+    const double r = sum8_f64(s.r);
     double res = r;
     if (!REGULAR) {
         // n < 8: no accumulators, numpy starts from -0.0 and adds in order
@@ -129,7 +126,7 @@ __device__ inline double chain_sum_finish(const LaneSum &s, int T, int rem,
     // join the leaves: level l combines the two depth-(H-l) subtrees
     const int hin = (LW > 0) ? 3 : H;
     for (int l = 0; l < hin; ++l) {
-        const double o = shfl_xor_f64(res, 8 << l);
+        const double o = (l == 0) ? xor8_f64(res) : shfl_xor_f64(res, 8 << l);
         const double n = res + o;
         res = (leafdepth >= H - l) ? n : res;
     }

@@ -63,9 +63,7 @@ constexpr uint64_t BIG_U_STREAM = 1ull << 62;
 template <bool REG>
 __device__ inline double leaf_finish(double r, double tail, int T, int rem, int lane)
 {
-    r = r + shfl_xor_f64(r, 1);
-    r = r + shfl_xor_f64(r, 2);
-    r = r + shfl_xor_f64(r, 4);
+    r = sum8_f64(r);
     if (REG) return r;                       // 128 elements: no tail
     double res = (T > 0) ? r : -0.0;
     const int leafbase = lane & ~7;

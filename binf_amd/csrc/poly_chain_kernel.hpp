@@ -37,6 +37,7 @@
 #pragma once
 #include "gauss_common.hpp"
 #include "philox_draws.hpp"
+#include <type_traits>
 
 namespace binf {
 
@@ -182,16 +183,45 @@ __global__ void __launch_bounds__(256) poly_chain_kernel(const PolyChainArgs a)
     double dt = a.dt_chain ? a.dt_chain[c] : a.timestep;
 
     // np.sum((polyval(xs, theta) - ys)**2): Horner, zero-padded above K-1 (exact no-ops)
+    // A lane's data points are visited in rounds t = 0, 1, ... (point 8 t + j of its leaf).
+    // With one wave per SIMD or less -- a few thousand chains -- every dependent FP64
+    // operation costs its full latency, so the rounds run FOUR AT A TIME with their Horner
+    // chains interleaved; rounds 0..3 live in registers (20 data points are 3 rounds),
+    // later ones come from LDS.  Rounds past a lane's data hold x = y = 0 and contribute
+    // exact zeros / are masked, so the grouping changes no bit.
+    double xr[4], yr[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        xr[t] = sx[t][slot];
+        yr[t] = sy[t][slot];
+    }
+    const int groups = (TC + 3) >> 2;
     auto chi2_of = [&]() {
         LaneSum s = {0.0, 0.0};
-#pragma unroll 2
-        for (int t = 0; t < TC; ++t) {
-            const double x = sx[t][slot];
-            double v = th[KMAX - 1] + x * 0.0;
+        auto four = [&](const double (&x)[4], const double (&y)[4], int t0) {
+            double v[4];
 #pragma unroll
-            for (int k = KMAX - 2; k >= 0; --k) v = th[k] + v * x;
-            const double d = v - sy[t][slot];
-            lane_sum_add<false>(s, d * d, t, T);
+            for (int u = 0; u < 4; ++u) v[u] = th[KMAX - 1] + x[u] * 0.0;
+#pragma unroll
+            for (int k = KMAX - 2; k >= 0; --k) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = th[k] + v[u] * x[u];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const double d = v[u] - y[u];
+                lane_sum_add<false>(s, d * d, t0 + u, T);
+            }
+        };
+        four(xr, yr, 0);
+        for (int gi = 1; gi < groups; ++gi) {
+            double x[4], y[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                x[u] = sx[4 * gi + u][slot];
+                y[u] = sy[4 * gi + u][slot];
+            }
+            four(x, y, 4 * gi);
         }
         return 1.0 * chain_sum_finish<false, 0>(s, T, rem, lane, H, Lf.depth);
     };
@@ -226,31 +256,73 @@ __global__ void __launch_bounds__(256) poly_chain_kernel(const PolyChainArgs a)
         return 0.5 * np_sum_k<KMAX>(sq, K);
     };
     // force = tau * sum_n (polyval(x_n) - y_n) x_n^k             likelihoods.py:148-155
+    // R rounds at a time, their Horner chains interleaved.  m[u] = tau for a data point the
+    // lane owns and counts, 0 for a round past its data (x = y = 0 there) or on a redundant
+    // path of a ragged tree: (v - y) * m is the residual times tau, or an exact zero.
+    auto force_rounds = [&](auto rc, const double *x, const double *y, const double *m) {
+        constexpr int R = decltype(rc)::value;
+        double v[R], r[R], pw[R];
+#pragma unroll
+        for (int u = 0; u < R; ++u) v[u] = th[KMAX - 1];
+#pragma unroll
+        for (int k = KMAX - 2; k >= 0; --k) {
+#pragma unroll
+            for (int u = 0; u < R; ++u) v[u] = __builtin_fma(v[u], x[u], th[k]);
+        }
+#pragma unroll
+        for (int u = 0; u < R; ++u) {
+            r[u] = (v[u] - y[u]) * m[u];
+            pw[u] = 1.0;
+        }
+        // every g[k] receives its terms in the order t = 0, 1, 2, ...
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+#pragma unroll
+            for (int u = 0; u < R; ++u) {
+                g[k] = __builtin_fma(pw[u], r[u], g[k]);
+                if (k + 1 < KMAX) pw[u] = pw[u] * x[u];
+            }
+        }
+    };
+    double mr[4];                      // the multipliers of rounds 0..3 under the current tau
     auto force = [&]() {
 #pragma unroll
         for (int k = 0; k < KMAX; ++k) g[k] = 0.0;
-#pragma unroll 2
-        for (int t = 0; t < TC; ++t) {
-            const double x = sx[t][slot];
-            double v = th[KMAX - 1];
+        if (TC <= 2) {
+            force_rounds(std::integral_constant<int, 2>(), xr, yr, mr);
+        } else if (TC == 3) {
+            force_rounds(std::integral_constant<int, 3>(), xr, yr, mr);
+        } else {
+            force_rounds(std::integral_constant<int, 4>(), xr, yr, mr);
+            for (int gi = 1; gi < groups; ++gi) {
+                double x[4], y[4], m[4];
 #pragma unroll
-            for (int k = KMAX - 2; k >= 0; --k) v = __builtin_fma(v, x, th[k]);
-            // rows past the lane's data hold x = y = 0 with theta_0 as "residual": masked
-            const double r = (8 * t + j < n) ? (v - sy[t][slot]) * tau * fcanon : 0.0;
-            double pw = 1.0;
-#pragma unroll
-            for (int k = 0; k < KMAX; ++k) {
-                g[k] = __builtin_fma(pw, r, g[k]);
-                pw = pw * x;
+                for (int u = 0; u < 4; ++u) {
+                    x[u] = sx[4 * gi + u][slot];
+                    y[u] = sy[4 * gi + u][slot];
+                    m[u] = (8 * (4 * gi + u) + j < n) ? tau * fcanon : 0.0;
+                }
+                force_rounds(std::integral_constant<int, 4>(), x, y, m);
             }
         }
-        // all-reduce over the chain's lanes; padded coefficients stay exactly zero
+        // all-reduce over the chain's lanes, level by level for all coefficients at once
+        // (independent chains for the pipeline); padded coefficients stay exactly zero
 #pragma unroll
-        for (int k = 0; k < KMAX; ++k) {
-            double s = g[k];
-            for (int m = 1; m < (1 << lg); m <<= 1) s = s + shfl_xor_f64(s, m);
-            g[k] = (k < K) ? s : 0.0;
+        for (int k = 0; k < KMAX; ++k) g[k] = g[k] + xor1_f64(g[k]);
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) g[k] = g[k] + xor2_f64(g[k]);
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) g[k] = g[k] + other_quad_f64(g[k]);
+        if (lg > 3) {
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) g[k] = g[k] + xor8_f64(g[k]);
+            for (int m = 16; m < (1 << lg); m <<= 1) {
+#pragma unroll
+                for (int k = 0; k < KMAX; ++k) g[k] = g[k] + shfl_xor_f64(g[k], m);
+            }
         }
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) g[k] = (k < K) ? g[k] : 0.0;
     };
     // K draws of a chain from a paired Philox stream: lane (slot & 7) of the chain computes
     // block (e0 >> 1) + (slot & 7) -- global elements 2b, 2b + 1 -- and the chain's lanes
@@ -319,21 +391,20 @@ __global__ void __launch_bounds__(256) poly_chain_kernel(const PolyChainArgs a)
         if (MOVE == POLY_MOVE_HMC) {
             e_before = -log_prob(chi2, logZ, have_pre, cpre, have_post, cpost) + kinetic();  // hmc.py:148
             const double hdt = 0.5 * dt;
-            force();                                                      // hmc.py:116
 #pragma unroll
-            for (int k = 0; k < KMAX; ++k) p[k] = kick<FMA>(p[k], hdt, g[k]);
-            for (int l = 0; l < a.nsteps - 1; ++l) {                      // hmc.py:118-120
-#pragma unroll
-                for (int k = 0; k < KMAX; ++k) th[k] = drift<FMA>(th[k], p[k], dt);
+            for (int u = 0; u < 4; ++u) mr[u] = (8 * u + j < n) ? tau * fcanon : 0.0;
+            // hmc.py:116-123 as ONE loop around the force: half kick, (nsteps - 1) x [drift,
+            // kick], drift, half kick
+            for (int l = 0; l <= a.nsteps; ++l) {
                 force();
+                const double kdt = (l == 0 || l == a.nsteps) ? hdt : dt;
 #pragma unroll
-                for (int k = 0; k < KMAX; ++k) p[k] = kick<FMA>(p[k], dt, g[k]);
+                for (int k = 0; k < KMAX; ++k) p[k] = kick<FMA>(p[k], kdt, g[k]);
+                if (l < a.nsteps) {
+#pragma unroll
+                    for (int k = 0; k < KMAX; ++k) th[k] = drift<FMA>(th[k], p[k], dt);
+                }
             }
-#pragma unroll
-            for (int k = 0; k < KMAX; ++k) th[k] = drift<FMA>(th[k], p[k], dt);   // hmc.py:122-123
-            force();
-#pragma unroll
-            for (int k = 0; k < KMAX; ++k) p[k] = kick<FMA>(p[k], hdt, g[k]);
             chi2_new = chi2_of();
             e_after = -log_prob(chi2_new, logZ, have_pre, cpre, have_post, cpost) + kinetic();  // hmc.py:150
             double x = -(e_after - e_before);                            // hmc.py:151

@@ -24,9 +24,7 @@ __device__ inline double leaf_sum_f(const F &f, int off, int n, int lane,
         r = f(off + j);
         for (int t = 1; t < T; ++t) r = r + f(off + 8 * t + j);
     }
-    r = r + shfl_xor_f64(r, 1);
-    r = r + shfl_xor_f64(r, 2);
-    r = r + shfl_xor_f64(r, 4);
+    r = sum8_f64(r);
     double res = (T > 0) ? r : -0.0;
     double tail = 0.0;
     if (active && j < rem) tail = f(off + 8 * T + j);
@@ -89,7 +87,7 @@ row_reduce_wave_kernel(const ARGS args, const RowGeom g, double *out)
     const auto f = FM::make(args, row);
     double res = leaf_sum_f(f, L.off, L.len, lane, true);
     for (int l = 0; l < H; ++l) {
-        const double o = shfl_xor_f64(res, 8 << l);
+        const double o = (l == 0) ? xor8_f64(res) : shfl_xor_f64(res, 8 << l);
         const double s = res + o;
         res = (L.depth >= H - l) ? s : res;
     }

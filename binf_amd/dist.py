@@ -153,6 +153,18 @@ class SampleStore(object):
         self.n_kept += 1
         return True
 
+    def extend(self, block, n_sweeps=None):
+        """Append a block of already thinned draws ``[m, C_local, D]`` -- what
+        ``GibbsSampler.sample_n`` / ``HMCSampler.sample_n`` return -- that stands
+        for ``n_sweeps`` calls of ``record`` (default ``m * thin``)."""
+        m = int(block.shape[0])
+        if self.n_kept + m > self.buffer.shape[0]:
+            raise IndexError('SampleStore is full (%d + %d draws)' % (self.n_kept, m))
+        self.buffer[self.n_kept:self.n_kept + m].copy_(
+            block.reshape((m,) + tuple(self.buffer.shape[1:])))
+        self.n_kept += m
+        self.n_seen += m * self.thin if n_sweeps is None else int(n_sweeps)
+
     def local(self):
         return self.buffer[:self.n_kept]
 

@@ -14,6 +14,9 @@ once.  Differences to the reference script, all deliberate:
 * samples are recorded in an on-device, thinned SampleStore (burn-in and
   thinning as in example_script.py:41) and gathered once at the end; with
   torch.distributed initialised the chains are sharded over the ranks;
+* the sweeps run `--per-launch` at a time in one kernel launch
+  (GibbsSampler.sample_n, bit-identical to that many gips.sample() calls;
+  --per-launch 1 is the reference's loop, one sample() per iteration);
 * no plotting (out of scope); a posterior summary is printed instead.
 
   python examples/polynomial_fit.py --chains 4096 --iterations 3000
@@ -46,6 +49,8 @@ def main(argv=None):
     ap.add_argument('--rwmc', action='store_true', help="the reference's RWMC + Gamma wiring")
     ap.add_argument('--host-rng', action='store_true', help='np.random draws (parity mode, slow)')
     ap.add_argument('--seed', type=int, default=0)
+    ap.add_argument('--per-launch', type=int, default=500,
+                    help='sweeps per kernel launch (1: one gips.sample() per iteration)')
     args = ap.parse_args(argv)
 
     if 'RANK' in os.environ and int(os.environ.get('WORLD_SIZE', '1')) > 1:
@@ -81,15 +86,44 @@ def main(argv=None):
     n_keep = max(1, (args.iterations - args.burn_in + args.thin - 1) // args.thin)
     store_c = SampleStore(n_keep, C, 4, thin=args.thin, burn_in=args.burn_in, device=dev)
     store_p = SampleStore(n_keep, C, 1, thin=args.thin, burn_in=args.burn_in, device=dev)
-    for i in range(args.iterations):
-        state = gips.sample()
-        store_c.record(state.variables['coefficients'])
-        store_p.record(state.variables['precision'])
-        if rank == 0 and i % 500 == 0 and i > 0:
+    def report(i):
+        if rank == 0:
             print('#### Gibbs sampling step {} ####'.format(i))
             stats = gips.last_draw_stats['coefficients']
             acc = stats.acceptance_rate if args.rwmc else stats.accepted.double()
             print('coefficient sampler acceptance: {:.3f}'.format(float(acc.mean())))
+
+    if args.per_launch <= 1:
+        for i in range(args.iterations):
+            state = gips.sample()
+            store_c.record(state.variables['coefficients'])
+            store_p.record(state.variables['precision'])
+            if i % 500 == 0 and i > 0:
+                report(i)
+    else:
+        # the same sweeps, many per launch: burn-in unrecorded, then the draw the
+        # store keeps first (sweep burn_in + 1), then blocks of whole thinning periods
+        done = 0
+        while done < min(args.burn_in, args.iterations):
+            m = min(args.per_launch, min(args.burn_in, args.iterations) - done)
+            gips.sample_n(m, record=False)
+            done += m
+            store_c.n_seen = store_p.n_seen = done
+            report(done)
+        if done < args.iterations:
+            state = gips.sample()
+            store_c.record(state.variables['coefficients'])
+            store_p.record(state.variables['precision'])
+            done += 1
+        block = max(args.thin, args.per_launch // args.thin * args.thin)
+        while done < args.iterations:
+            m = min(block, args.iterations - done)
+            rec = gips.sample_n(m, thin=args.thin)
+            if rec is not None:
+                store_c.extend(rec['coefficients'], n_sweeps=m)
+                store_p.extend(rec['precision'].unsqueeze(-1), n_sweeps=m)
+            done += m
+            report(done)
 
     coeffs = store_c.gather(args.chains)           # [n_kept, chains, 4] on every rank
     prec = store_p.gather(args.chains)

@@ -125,6 +125,10 @@ def test_device_rwmc_gibbs_needs_no_host_draw_and_mixes(device):
     C, sweeps = 512, 400
     cs, ts, gips = gibbs_run(device, C, sweeps, DeviceRNG(9, device))
     assert gips.host_stream_untouched
+    # a random walk of half-width 0.1 needs some 1e4 sweeps from the all-ones start:
+    # one multi-sweep launch (GibbsSampler.sample_n), still without a host draw
+    rec = gips.sample_n(40000, thin=200)
+    assert gips.host_stream_untouched_after(rec)
     _, _, host = gibbs_run(device, 2, 2, None)
     assert not host.host_stream_untouched            # the parity mode does consume np.random
     rate = gips.last_draw_stats['coefficients'].acceptance_rate
@@ -132,11 +136,7 @@ def test_device_rwmc_gibbs_needs_no_host_draw_and_mixes(device):
     assert isinstance(gips.subsamplers['precision'], GammaSampler)
     assert isinstance(gips.subsamplers['coefficients'], RWMCSampler)
     assert (ts > 0).all() and torch.isfinite(cs).all()
-    # the posterior of the example: coefficients near the truth after burn-in (a
-    # random walk of half-width 0.1 needs some 1e4 sweeps from the all-ones start:
-    # one multi-sweep launch, GibbsSampler.sample_n)
-    rec = gips.sample_n(40000, thin=200)
-    assert gips.host_stream_untouched_after(rec)
+    # the posterior of the example: coefficients near the truth after burn-in
     m = rec['coefficients'][100:].mean(dim=(0, 1)).cpu().numpy()
     assert np.all(np.abs(m - np.array([2.0, -4.0, 1.0, 1.5])) < 1.0), m
     # deterministic in the seed
