@@ -76,6 +76,12 @@ def parse(argv=None):
                     help='with --fuse > 1: record every thin-th state')
     ap.add_argument('--draw-buffers', type=int, default=3,
                     help='draw buffers [fuse, C, D] cycled through (>= 2)')
+    ap.add_argument('--survey-draws', type=int, default=1,
+                    help='draw buffers generated on the host with the SURVEY.md 8(d) seeds '
+                         '(the rest: torch.randn on the device)')
+    ap.add_argument('--sustain-ms', type=float, default=1000.0,
+                    help='after the timed steps: the same launches for this long, reported as '
+                         'value_sustained (0 = skip)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-other-mode', action='store_true',
                     help='skip the short extra measurement in the other arithmetic mode')
@@ -244,6 +250,32 @@ def pmc_traffic_live(args):
     return nbytes, src
 
 
+def kernel_stats_live():
+    """rocprofv3 --kernel-trace --stats over scripts/bench_extra.py --roofline-child
+    (the C3 / C5 / C1 kernels the sub-results price) -> ({kernel: (calls, avg ns)}, text)."""
+    rocprof = shutil.which('rocprofv3') or '/opt/rocm/bin/rocprofv3'
+    if not os.path.exists(rocprof):
+        return None, 'rocprofv3 not found'
+    tmp = tempfile.mkdtemp(prefix='binf_kt_', dir='/tmp')
+    cmd = [rocprof, '--kernel-trace', '--stats', '--output-format', 'csv', '-d', tmp, '--',
+           sys.executable, os.path.join(ROOT, 'scripts', 'bench_extra.py'), '--roofline-child']
+    try:
+        try:
+            r = subprocess.run(cmd, cwd='/tmp', env=dict(os.environ, TMPDIR='/tmp'),
+                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=240)
+        except subprocess.TimeoutExpired:
+            return None, 'rocprofv3 --kernel-trace child timed out'
+        if r.returncode != 0:
+            return None, 'rocprofv3 --kernel-trace child failed (rc %d)' % r.returncode
+        stats = {}
+        for f in glob.glob(os.path.join(tmp, '**', '*kernel_stats.csv'), recursive=True):
+            for row in csv.DictReader(open(f)):
+                stats[row['Name']] = (int(row['Calls']), float(row['AverageNs']))
+        return (stats, 'ok') if stats else (None, 'no kernel_stats.csv in the rocprofv3 output')
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def pmc_traffic_committed(C, D, L, F, thin, mode):
     for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_traffic.json')),
                        reverse=True):
@@ -319,6 +351,12 @@ def main():
             live_traffic, live_src = pmc_traffic_live(args)
             if live_traffic is not None:
                 live_src += '; %.0f s' % (time.perf_counter() - t_p)
+    kstats, kstats_src = None, 'not attempted'
+    if world == 1 and not args.pmc_child and not args.no_pmc and not args.no_extra:
+        if under_profiler():
+            kstats_src = 'this process itself runs under a profiler'
+        else:
+            kstats, kstats_src = kernel_stats_live()
 
     if not torch.cuda.is_available():
         sys.exit('bench.py needs a GPU (binf_amd has no CPU path)')
@@ -344,15 +382,31 @@ def main():
     from binf_amd.pdf import IsotropicGaussian
     from binf_amd.samplers.hmc import HMCSampler
 
-    # synthetic inputs, resident in HBM before the timed region
+    # synthetic inputs, resident in HBM before the timed region.  q0 and the FIRST draw
+    # buffer follow SURVEY.md 8(d) literally -- q0 = RandomState(1234), call i draws
+    # p0 = RandomState(1000 + i).standard_normal((C, D)), u = RandomState(2000 + i).uniform(C)
+    # (rank r adds 100000 r to every seed) -- generated on the host before the timed
+    # region; the other buffers are filled on the device (host generation of a buffer
+    # takes ~6 s).  --survey-draws 0: all buffers on the device.
     q0 = torch.from_numpy(
-        np.random.RandomState(1234 + rank).standard_normal((C, D))).to(dev)
+        np.random.RandomState(1234 + 100000 * rank).standard_normal((C, D))).to(dev)
     gen = torch.Generator(device=dev)
     gen.manual_seed(1000 + rank)
-    p_bufs = [torch.randn((F, C, D), dtype=torch.float64, device=dev, generator=gen)
-              for _ in range(NB)]
-    u_bufs = [torch.rand((F, C), dtype=torch.float64, device=dev, generator=gen)
-              for _ in range(NB)]
+    p_bufs, u_bufs = [], []
+    n_survey = min(NB, max(0, args.survey_draws)) if not args.pmc_child else 0
+    for b in range(NB):
+        if b < n_survey:
+            pb = torch.empty((F, C, D), dtype=torch.float64, device=dev)
+            ub = torch.empty((F, C), dtype=torch.float64, device=dev)
+            for i in range(F):
+                call = b * F + i + 100000 * rank
+                pb[i].copy_(torch.from_numpy(np.random.RandomState(1000 + call).standard_normal((C, D))))
+                ub[i].copy_(torch.from_numpy(np.random.RandomState(2000 + call).uniform(size=C)))
+        else:
+            pb = torch.randn((F, C, D), dtype=torch.float64, device=dev, generator=gen)
+            ub = torch.rand((F, C), dtype=torch.float64, device=dev, generator=gen)
+        p_bufs.append(pb)
+        u_bufs.append(ub)
     nrec = F // thin
     # record buffers (every thin-th state of a step), preallocated: two, used in turn
     rec_bufs = [torch.empty((nrec, C, D), dtype=torch.float64, device=dev)
@@ -422,10 +476,30 @@ def main():
     ev1.record()
     barrier()
     elapsed = time.perf_counter() - t0
+    my_elapsed = elapsed
     dev_ms = ev0.elapsed_time(ev1)
     per_launch_us = None
     if evs is not None:
         per_launch_us = sorted(evs[i].elapsed_time(evs[i + 1]) * 1e3 for i in range(K))
+
+    # the same launches for >= --sustain-ms more (device time, HIP events): the figure a long
+    # run sees, next to the K timed steps
+    sustained = None
+    if args.sustain_ms > 0:
+        s0 = torch.cuda.Event(enable_timing=True)
+        s1 = torch.cuda.Event(enable_timing=True)
+        n_sus, first = 0, n_settle + W + K
+        t_s = time.perf_counter()
+        s0.record()
+        while (time.perf_counter() - t_s) * 1e3 < args.sustain_ms:
+            run(sampler, first + n_sus, 8)
+            n_sus += 8
+            torch.cuda.synchronize()
+        s1.record()
+        torch.cuda.synchronize()
+        sus_ms = s0.elapsed_time(s1)
+        sustained = {'launches': n_sus, 'ms': sus_ms,
+                     'value_per_gpu': C * L * F * n_sus / (sus_ms * 1e-3)}
 
     acc_rate = float(sampler.acceptance_rate.mean())
     gather_ms = None
@@ -466,6 +540,22 @@ def main():
             gather_chains(state)
         barrier()
         gather_ms = (time.perf_counter() - t1) / 5 * 1e3
+        # gather to rank 0 only (what writing the samples out needs)
+        gather_chains(state, dst=0)
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(5):
+            gather_chains(state, dst=0)
+        barrier()
+        gather_dst0_ms = (time.perf_counter() - t1) / 5 * 1e3
+        # what every rank saw: the line is self-checking for the driver's first SCALE run
+        mine = {'rank': rank, 'world_size_seen': dist.get_world_size(), 'backend': dist.get_backend(),
+                'device': '%s:%d' % (torch.cuda.get_device_name(dev_index), dev_index),
+                'elapsed_s': my_elapsed, 'dev_ms': dev_ms,
+                'chain_offset': int(rank) * C,
+                'sustained_value': None if sustained is None else sustained['value_per_gpu']}
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
 
     if rank == 0:
         transitions = K * F
@@ -497,7 +587,7 @@ def main():
         roof = {'bound': 'hbm', 'achieved': achieved,
                 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                 'frac': achieved / HBM_PEAK_GBS,
-                'frac_of_measured_copy_ceiling': achieved / HBM_COPY_GBS,
+                'hbm_frac_moved_of_copy_ceiling': moved_bytes_launch / launch_s / 1e9 / HBM_COPY_GBS,
                 'traffic': traffic, 'traffic_source': traffic_src,
                 'hbm_frac_measured': (traffic / launch_s / 1e9 / HBM_PEAK_GBS)
                 if traffic is not None else None,
@@ -540,9 +630,12 @@ def main():
             'config': {'workload': 'C2: %d-d isotropic Gaussian (k=1, x0=0), '
                                    '%d chains/GPU, %d leapfrog steps, dt=%g, '
                                    'fused HMC transition, mode=%s; 1 step = 1 launch = %d '
-                                   'transition(s) (sample() calls), %s state recorded'
+                                   'transition(s) (sample() calls), %s state recorded; q0 and '
+                                   'draw buffer(s) 0..%d from the SURVEY.md 8(d) seeds (host), '
+                                   'the other %d filled by torch.randn on the device'
                                    % (D, C, L, dt, args.mode, F,
-                                      'every' if thin == 1 else 'every %d.' % thin),
+                                      'every' if thin == 1 else 'every %d.' % thin,
+                                      n_survey - 1, NB - n_survey),
                        'chains_per_gpu': C, 'n_dims': D, 'leapfrog_steps': L,
                        'transitions_per_step': F,
                        'parallelism': 'chains sharded x%d, no data-path '
@@ -559,6 +652,16 @@ def main():
         }
         if gather_ms is not None:
             res['sample_gather_ms'] = gather_ms
+            res['sample_gather_to_rank0_ms'] = gather_dst0_ms
+            res['sample_gather_bytes_per_rank'] = C * D * 8
+            res['ranks'] = per_rank
+        if sustained is not None:
+            res['value_sustained'] = sustained['value_per_gpu'] * world if world == 1 else \
+                sum(r['sustained_value'] for r in per_rank)
+            res['sustained'] = {'launches': sustained['launches'], 'ms': sustained['ms'],
+                                'what': 'the same launches for >= %g ms right after the timed steps '
+                                        '(device time, HIP events; rank 0 shown, value_sustained sums '
+                                        'the ranks)' % args.sustain_ms}
         if other is not None:
             res['other_mode'] = other
         if world == 1 and not args.no_extra:
@@ -567,7 +670,8 @@ def main():
             torch.cuda.empty_cache()
             try:
                 from scripts import bench_extra
-                res['extra'] = bench_extra.run_all(dev)
+                res['extra'] = bench_extra.run_all(dev, kstats)
+                res['extra']['roofline_kernel_trace'] = kstats_src
             except Exception as e:              # sub-results never break the headline
                 res['extra'] = {'error': '%s: %s' % (type(e).__name__, e)}
         if world == 1 and not args.no_cpu_baseline:

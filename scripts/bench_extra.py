@@ -197,10 +197,109 @@ def c2_strong_scaling_shares(dev, D=1024, L=20, F=64):
     return out
 
 
-def run_all(dev):
+# ---------------------------------------------------------------------------
+# Roofline blocks of the sub-results: the kernel's average duration comes from
+# rocprofv3 --kernel-trace --stats over a child run of `roofline_child` (started
+# by bench.py before it touches the GPU), so every frac can be recomputed from
+# the kernel_stats rows carried in the block.
+# ---------------------------------------------------------------------------
+ROOFLINE_KERNELS = {'C3': 'poly_grad_mfma_kernel', 'C5': 'pairdist_leapfrog_sym_kernel',
+                    'C1_gibbs': 'poly_chain_kernel<4, false, true, 0>'}
+C3_SHAPE = dict(C=8192, K=33, N=16384)
+C5_SHAPE = dict(C=256, n=256, L=20)
+C1_SHAPE = dict(C=4096, K=4, N=20, L=50, sweeps=200)
+
+
+def roofline_child():
+    """The kernels the roofline blocks price, launched back to back after a settle
+    phase each (run under rocprofv3 --kernel-trace --stats)."""
+    import time
+    from binf_amd import _native
+    from binf_amd.example.distance import make_distance_likelihood
+    from binf_amd.example.likelihood import POLYVAL, ForwardModel
+    dev = torch.device('cuda:0')
+
+    def settled(fn, n, settle_s=0.3):
+        t = time.perf_counter()
+        while time.perf_counter() - t < settle_s:
+            fn()
+            torch.cuda.synchronize()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+    # C3 gradient
+    C, K, N = C3_SHAPE['C'], C3_SHAPE['K'], C3_SHAPE['N']
+    xs = np.linspace(-1, 1, N)
+    ys = POLYVAL(xs, np.random.RandomState(7).standard_normal(K)) + \
+        np.random.RandomState(9).standard_normal(N) / np.sqrt(2.5)
+    q0 = torch.from_numpy(np.random.RandomState(8).standard_normal((C, K))).to(dev)
+    A = ForwardModel(xs, POLYVAL).design_matrix(K, dev)
+    ty = torch.from_numpy(ys).to(dev)
+    settled(lambda: _native.poly_gauss_grad(q0, A, ty, 2.5), 40)
+    # C5 fused leapfrog
+    C, n, L = C5_SHAPE['C'], C5_SHAPE['n'], C5_SHAPE['L']
+    rs = np.random.RandomState(0)
+    truth = rs.standard_normal((n, 3)) * 2.0
+    I, J = np.triu_indices(n, 1)
+    d = np.sqrt(np.sum((truth[I] - truth[J]) ** 2, axis=1))
+    lik = make_distance_likelihood(np.abs(d + 0.05 * rs.standard_normal(len(d))), n)
+    x = torch.from_numpy(truth.reshape(-1)[None, :] + 0.1 * rs.standard_normal((C, 3 * n))).to(dev)
+    ymat = lik.error_model.ymat_device(dev)
+    q, p = x.clone(), torch.zeros_like(x)
+    settled(lambda: _native.pairdist_leapfrog(q, p, ymat, 4.0, (0.05, 0.0), True, 1e-5, None, L), 60)
+    # C1 shape: the multi-sweep Gibbs launch
+    gips = _c1_gibbs(dev, C1_SHAPE['C'])
+    settled(lambda: gips.sample_n(C1_SHAPE['sweeps'], record=False), 6, settle_s=0.2)
+
+
+def _c1_gibbs(dev, C, L=50):
+    from binf_amd.example.misc import make_posterior
+    from binf_amd.example.samplers import make_hmc_sampler
+    from binf_amd.samplers import BinfState
+    from binf_amd.samplers.rng import DeviceRNG
+    np.random.seed(0)
+    xs = np.linspace(-2, 2, 20)
+    poly = np.polynomial.polynomial.polyval
+    ys = np.random.normal(loc=poly(xs, np.array([2.0, -4.0, 1.0, 1.5])), scale=1.0 / np.sqrt(2.5))
+    st = BinfState(dict(coefficients=torch.ones((C, 4), dtype=torch.float64, device=dev),
+                        precision=torch.ones(C, dtype=torch.float64, device=dev)))
+    return make_hmc_sampler(make_posterior(xs, ys, poly), 0.02, L, st, rng=DeviceRNG(0, dev))
+
+
+def c1_gibbs(dev, C=4096, L=50, sweeps=200):
+    """C1's shape (example_script.py: K = 4, 20 data points) batched: Gibbs-within-HMC,
+    `sweeps` sweeps per launch (GibbsSampler.sample_n) against one sample() per sweep."""
+    g1, g2 = _c1_gibbs(dev, C, L), _c1_gibbs(dev, C, L)
+    t_loop = _timed(g1.sample, 100, warm=10)
+    t_n = _timed(lambda: g2.sample_n(sweeps, record=False), 4, warm=1) / sweeps
+    return {'workload': 'C1 shape batched: Gibbs-within-HMC, polynomial K=4, N=20, %d chains, L=%d' % (C, L),
+            'sweep_us_one_sample_per_launch': t_loop * 1e6,
+            'sweep_us_%d_sweeps_per_launch' % sweeps: t_n * 1e6,
+            'chain_leapfrog_steps_per_s': C * L / t_n}
+
+
+def _roofline(kstats, key, bound, work, peak, unit, what):
+    """kstats: {kernel name: (calls, average ns)} from rocprofv3's kernel_stats.csv."""
+    if not kstats:
+        return None
+    rows = {k: v for k, v in kstats.items() if ROOFLINE_KERNELS[key] in k}
+    if not rows:
+        return None
+    name, (calls, avg_ns) = max(rows.items(), key=lambda kv: kv[1][0])
+    achieved = work / (avg_ns * 1e-9) / 1e12
+    return {'bound': bound, 'achieved': achieved, 'peak': peak, 'unit': unit,
+            'frac': achieved / peak, 'traffic': None, 'kernel': name,
+            'rocprof_avg_us': avg_ns * 1e-3, 'rocprof_calls': calls,
+            'algorithmic_work_per_launch': work, 'work_is': what,
+            'source': 'rocprofv3 --kernel-trace --stats of scripts/bench_extra.py --roofline-child, '
+                      'run by bench.py in this invocation'}
+
+
+def run_all(dev, kstats=None):
     res = {}
     for name, fn in (('C3', c3_polynomial), ('C4', c4_gibbs), ('C5', c5_distance),
                      ('C5_2048_chains', lambda d: c5_distance(d, C=2048)),
+                     ('C1_gibbs', c1_gibbs),
                      ('C2_device_rng', c2_device_rng),
                      ('C2_strong_scaling_shares', c2_strong_scaling_shares)):
         try:
@@ -208,6 +307,31 @@ def run_all(dev):
         except Exception as e:                    # one failing sub-result does not hide the others
             res[name] = {'error': '%s: %s' % (type(e).__name__, e)}
         torch.cuda.empty_cache()
+    s3, s5, s1 = C3_SHAPE, C5_SHAPE, C1_SHAPE
+    blocks = {
+        'C3': _roofline(kstats, 'C3', 'mfma', 4.0 * s3['K'] * s3['N'] * s3['C'], MFMA_F64_PEAK_TFLOPS,
+                        'TFLOP/s', 'SURVEY 8(d): 4 K N flops per chain and gradient x %d chains '
+                        '(one launch = one gradient of every chain)' % s3['C']),
+        'C5': _roofline(kstats, 'C5', 'valu',
+                        24.0 * 0.5 * s5['C'] * s5['n'] * (s5['n'] - 1) * (s5['L'] + 1),
+                        VALU_PEAK_LANEOPS / 1e12, 'T lane-op/s',
+                        '24 VALU instructions per unordered pair (ISA count, DESIGN.md 4.4) x '
+                        'n (n - 1) / 2 pairs x %d chains x (L + 1) = %d force evaluations of one '
+                        'fused leapfrog launch; peak = 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz'
+                        % (s5['C'], s5['L'] + 1)),
+        # 13 lane-operations per data point and force evaluation (Horner K - 1, residual 2,
+        # K accumulates + K - 1 powers) -- the arithmetic of the model, not the butterflies
+        'C1_gibbs': _roofline(kstats, 'C1_gibbs', 'valu',
+                              13.0 * s1['N'] * (s1['L'] + 1) * s1['C'] * s1['sweeps'],
+                              VALU_PEAK_LANEOPS / 1e12, 'T lane-op/s',
+                              '13 FP64 lane-operations per data point and force evaluation x 20 '
+                              'points x (L + 1) = 51 evaluations x %d chains x %d sweeps per launch '
+                              '(latency-bound at this batch: 512 waves for 1024 SIMDs)'
+                              % (s1['C'], s1['sweeps'])),
+    }
+    for k, b in blocks.items():
+        if b is not None and k in res and 'error' not in res[k]:
+            res[k]['roofline'] = b
     return res
 
 
@@ -216,4 +340,7 @@ if __name__ == '__main__':
     import os
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    print(json.dumps(run_all(torch.device('cuda:0'))))
+    if '--roofline-child' in sys.argv:
+        roofline_child()
+    else:
+        print(json.dumps(run_all(torch.device('cuda:0'))))
