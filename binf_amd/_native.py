@@ -118,6 +118,8 @@ SIGNATURES = {
     'binf_rwmc_accept_f64': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64,
                                     ctypes.c_uint64, ctypes.c_uint64, _i64, _vp]),
     'binf_gibbs_poly_sample_n_f64': (_i32, [_vp, _vp]),
+    'binf_jacobian_contract_f64': (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _i32, _vp]),
+    'binf_sum_terms_f64': (_i32, [_vp, _vp, _i32, _vp, _i64, _vp]),
     'binf_rng_philox4x32_10': (_i32, [ctypes.POINTER(ctypes.c_uint32),
                                       ctypes.POINTER(ctypes.c_uint32),
                                       ctypes.POINTER(ctypes.c_uint32)]),
@@ -578,6 +580,55 @@ def gibbs_poly_sample_n(coefficients, precision, coefficients_out, precision_out
     a.zig = int(bool(zig))
     rc = lib().binf_gibbs_poly_sample_n_f64(ctypes.byref(a), stream_handle(coefficients.device))
     check(rc, 'binf_gibbs_poly_sample_n_f64')
+
+
+@_launcher
+def jacobian_contract(jacobian, emgrad):
+    """``dfm.dot(emgrad)`` of ``Likelihood._evaluate_gradient``, batched:
+    ``jacobian`` ``[K x N]`` (shared) or ``[C x K x N]``, ``emgrad`` ``[C x N]`` or
+    ``[N]`` (one chain) -> ``[C x K]`` / ``[K]``."""
+    one = emgrad.dim() == 1
+    r = emgrad.reshape(1, -1) if one else emgrad
+    C, N = r.shape
+    batched = jacobian.dim() == 3
+    K = jacobian.shape[-2]
+    if jacobian.shape[-1] != N or (batched and jacobian.shape[0] != C):
+        raise ValueError('jacobi matrix %s does not fit the error-model gradient %s'
+                         % (tuple(jacobian.shape), tuple(emgrad.shape)))
+    out = torch.empty((C, K), dtype=torch.float64, device=r.device)
+    rc = lib().binf_jacobian_contract_f64(
+        dptr(jacobian, numel=(C if batched else 1) * K * N, name='jacobi matrix'),
+        dptr(r, numel=C * N, name='error-model gradient'), dptr(out), C, K, N, int(batched),
+        stream_handle(r.device))
+    check(rc, 'binf_jacobian_contract_f64')
+    return out.reshape(-1) if one else out
+
+
+@_launcher
+def sum_terms(terms):
+    """``((t0 + t1) + t2) + ...`` in one launch; a term is a device tensor (all of
+    one shape) or a Python / numpy scalar."""
+    tens = [t for t in terms if isinstance(t, torch.Tensor) and t.dim() > 0]
+    if not tens:
+        raise TypeError('sum_terms: no device tensor among the terms')
+    ref = tens[0]
+    n = ref.numel()
+    T = len(terms)
+    ptrs = (_vp * T)()
+    scal = (_f64 * T)()
+    for i, t in enumerate(terms):
+        if isinstance(t, torch.Tensor) and t.dim() > 0:
+            if t.shape != ref.shape:
+                raise ValueError('sum_terms: term shapes differ (%s, %s)'
+                                 % (tuple(t.shape), tuple(ref.shape)))
+            ptrs[i] = dptr(t, numel=n, name='term %d' % i)
+        else:
+            ptrs[i] = None
+            scal[i] = float(t)
+    out = torch.empty_like(ref)
+    rc = lib().binf_sum_terms_f64(ptrs, scal, T, dptr(out), n, stream_handle(ref.device))
+    check(rc, 'binf_sum_terms_f64')
+    return out
 
 
 _grad_ws = {}

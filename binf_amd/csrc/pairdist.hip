@@ -19,6 +19,7 @@
 // Each has a force-only kernel and a fused leapfrog (the whole _leapfrog() of
 // binf/samplers/hmc.py:92-125 in one launch) that are bit-identical to each other.
 #include <stdlib.h>
+#include <atomic>
 #include "rowsum.hpp"
 
 namespace binf {
@@ -709,12 +710,14 @@ static int lanes_per_bead(int64_t C) { return C < 1024 ? 4 : 1; }
 // development aid: BINF_PD_SYM=0 sends n <= 256 to the one-sided kernels as well
 static bool sym_enabled()
 {
-    static int on = -1;
-    if (on < 0) {
+    static std::atomic<int> on(-1);
+    int v = on.load(std::memory_order_relaxed);
+    if (v < 0) {
         const char *e = getenv("BINF_PD_SYM");
-        on = (e && e[0] == '0') ? 0 : 1;
+        v = (e && e[0] == '0') ? 0 : 1;
+        on.store(v, std::memory_order_relaxed);
     }
-    return on != 0;
+    return v != 0;
 }
 
 // workgroups of the n <= 256 kernels: as many as the chip holds at a time (16 waves per
@@ -722,12 +725,16 @@ static bool sym_enabled()
 // share of the chains
 static unsigned sym_grid(int64_t C, int nblk)
 {
-    static int cus = 0;
+    // CU count of the CURRENT device (the wrappers make the stream's device current),
+    // cached per device id; atomics make the first calls of several threads harmless
+    static std::atomic<int> cu_cache[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    int cus = cu_cache[dev].load(std::memory_order_relaxed);
     if (cus <= 0) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess ||
-            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
             cus = 256;
+        cu_cache[dev].store(cus, std::memory_order_relaxed);
     }
     const int64_t slots = (int64_t)cus * (nblk == 1 ? 16 : (nblk == 2 ? 4 : 1));
     return (unsigned)(C < slots ? C : slots);

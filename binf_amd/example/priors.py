@@ -25,12 +25,13 @@ class GammaPrior(AbstractPrior):
         self._set_original_variables()
 
     def _evaluate_log_prob(self, precision):
-        if isinstance(precision, torch.Tensor) and precision.is_cuda and \
-                precision.dtype == torch.float64 and precision.is_contiguous():
-            # one launch instead of four torch ops, the same roundings
-            return _native.gamma_logp(precision, self.shape, self.rate)
-        log = torch.log if isinstance(precision, torch.Tensor) else np.log
-        return (self.shape - 1.0) * log(precision) - precision * self.rate
+        if isinstance(precision, torch.Tensor):
+            # per-chain precisions: one launch, the roundings of the expression below
+            _native.require_device(precision, 'precision')
+            return _native.gamma_logp(precision.to(torch.float64).contiguous(),
+                                      self.shape, self.rate)
+        # one precision for all chains (a Python / numpy scalar): host arithmetic
+        return (self.shape - 1.0) * np.log(precision) - precision * self.rate
 
     def clone(self):
         # Reference quirk Q6, kept: the copy is built with (shape, shape), so

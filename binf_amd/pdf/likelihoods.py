@@ -9,8 +9,8 @@ Jacobian laid out ``[n_params x n_data]`` (reference ``:148-155``; pinned by
 Dispatch: when forward and error model both advertise a native implementation
 that the HIP library can fuse (``native_spec``), log-prob and gradient run in
 one fused kernel and the ``[C x n_data]`` mock data never reaches HBM;
-otherwise the models are called as written and the contraction is a plain
-batched product.
+otherwise the models are called as written and the contraction is the
+library's generic kernel (``binf_jacobian_contract_f64``).
 """
 from binf_amd.pdf import AbstractBinfPDF
 
@@ -144,17 +144,20 @@ class Likelihood(AbstractBinfPDF):
 
 
 def contract_jacobian(dfm, emgrad):
-    """``dfm.dot(emgrad)`` of the reference, batched: ``dfm`` is
-    ``[n_params x n_data]`` or ``[C x n_params x n_data]``, ``emgrad`` is
-    ``[n_data]`` or ``[C x n_data]``."""
+    """``dfm.dot(emgrad)`` of the reference (``:155``), batched: ``dfm`` is
+    ``[n_params x n_data]`` (shared by all chains) or ``[C x n_params x n_data]``,
+    ``emgrad`` is ``[n_data]`` or ``[C x n_data]``.  Device tensors go through
+    ``binf_jacobian_contract_f64`` (f64 MFMA tiles for a shared Jacobian, streamed
+    row products for per-chain ones; fixed summation order); numpy values -- the
+    host mirror of the reference's own unit tests -- through ``ndarray.dot``.
+    There is no torch fallback: CPU tensors are refused."""
     try:
         import torch
     except ImportError:  # pragma: no cover
         torch = None
-    if torch is not None and isinstance(emgrad, torch.Tensor):
-        if emgrad.dim() == 1:
-            return dfm @ emgrad
-        if dfm.dim() == 2:
-            return emgrad @ dfm.transpose(0, 1)
-        return torch.bmm(dfm, emgrad.unsqueeze(-1)).squeeze(-1)
+    if torch is not None and (isinstance(emgrad, torch.Tensor) or isinstance(dfm, torch.Tensor)):
+        from binf_amd import _native
+        _native.require_device(emgrad, 'the error-model gradient')
+        _native.require_device(dfm, 'the jacobi matrix')
+        return _native.jacobian_contract(dfm.contiguous(), emgrad.contiguous())
     return dfm.dot(emgrad)

@@ -17,6 +17,33 @@ part of the energy but not of the force.
 from binf_amd.pdf import AbstractBinfPDF
 
 
+def _sum_in_order(terms):
+    """``((t0 + t1) + t2) + ...``: per-chain device tensors in ONE launch of
+    ``binf_sum_terms_f64`` (Python-float terms ride along as scalars); host values
+    (the reference's own unit-test cases) with Python's ``+``."""
+    if len(terms) == 1:
+        return terms[0]
+    try:
+        import torch
+    except ImportError:  # pragma: no cover
+        torch = None
+    if torch is not None and any(isinstance(t, torch.Tensor) and t.is_cuda and t.dim() > 0
+                                 for t in terms):
+        from binf_amd import _native
+        if len(terms) <= 16 and all(
+                (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float64 and
+                 t.is_contiguous()) or not isinstance(t, torch.Tensor) or t.dim() == 0
+                for t in terms):
+            shapes = set(tuple(t.shape) for t in terms if isinstance(t, torch.Tensor) and t.dim() > 0)
+            if len(shapes) == 1:
+                return _native.sum_terms([t if (isinstance(t, torch.Tensor) and t.dim() > 0)
+                                          else float(t) for t in terms])
+    total = terms[0]
+    for t in terms[1:]:
+        total = total + t
+    return total
+
+
 class Posterior(AbstractBinfPDF):
 
     def __init__(self, likelihoods, priors, name='the one and only posterior'):
@@ -81,20 +108,15 @@ class Posterior(AbstractBinfPDF):
 
     def _evaluate_log_prob(self, **model_parameters):
         # numpy.sum over a short list = sequential adds (reference :147-151)
-        terms = self._evaluate_components(**model_parameters)
-        total = terms[0]
-        for t in terms[1:]:
-            total = total + t
-        return total
+        return _sum_in_order(self._evaluate_components(**model_parameters))
 
     def _evaluate_gradient(self, **variables):
-        total = None
+        grads = []
         for f in self._ordered_components():
             if len(f.variables) > 0 and len(f.differentiable_variables) > 0:
-                g = f.gradient(**{x: variables[x] for x in variables
-                                  if x in f.variables})
-                total = g if total is None else total + g
-        if total is None:
+                grads.append(f.gradient(**{x: variables[x] for x in variables
+                                           if x in f.variables}))
+        if not grads:
             # no differentiable component: the reference returns its zero
             # vector, one entry per element of the differentiable variables
             # passed in (reference :177-180)
@@ -102,7 +124,7 @@ class Posterior(AbstractBinfPDF):
             return numpy.zeros(sum(len(variables[v]) if hasattr(variables[v], '__len__')
                                    else 1 for v in variables
                                    if v in self.differentiable_variables))
-        return total
+        return _sum_in_order(grads)
 
     # -- copies --------------------------------------------------------------
     def clone(self):

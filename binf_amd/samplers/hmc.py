@@ -427,10 +427,10 @@ class HMCSampler(object):
             if not isinstance(v, torch.Tensor):
                 return torch.full((C,), float(v), dtype=torch.float64, device=dev)
             return v.to(device=dev, dtype=torch.float64).reshape(-1).expand(C).contiguous()
-        lp_pre = None
-        for f in pre:                      # numpy.sum of a short list: left to right
-            t = const_term(f)
-            lp_pre = t if lp_pre is None else lp_pre + t
+        # numpy.sum of a short list: left to right (one launch for two and more terms)
+        pre_terms = [const_term(f) for f in pre]
+        lp_pre = None if not pre_terms else \
+            (pre_terms[0] if len(pre_terms) == 1 else _native.sum_terms(pre_terms))
         lp_post = const_term(post) if post is not None else None
         means = prior._vec('means', dev) if prior is not None else None
         variances = prior._vec('variances', dev) if prior is not None else None

@@ -34,7 +34,8 @@ extern "C" {
  *    gradient's workspace is mandatory, binf_hmc_sample_poly_f64 accepts N <= 1024.)
  * 3: binf_hmc_sample_poly_f64 spreads a chain's data over a lane group for EVERY
  *    N <= 1024 (the force's summation order for N <= 128 changed with it; one lane
- *    per chain is now the opt-in BINF_MODE_LANE_PER_CHAIN); binf_gibbs_poly_sample_n_f64. */
+ *    per chain is now the opt-in BINF_MODE_LANE_PER_CHAIN); binf_gibbs_poly_sample_n_f64,
+ *    binf_jacobian_contract_f64, binf_sum_terms_f64. */
 #define BINF_ABI_VERSION 3
 
 #define BINF_E_ARG        (-1)  /* null pointer / negative size / bad flag    */
@@ -389,6 +390,34 @@ int32_t binf_hmc_sample_poly_f64(const double *q0, const double *p0,
                                  int64_t N, int32_t nsteps, int32_t adapt,
                                  double uprate, double downrate, int32_t mode,
                                  void *stream);
+
+/* ------------------------------------------------------------------------
+ * The generic chain-rule contraction of the Likelihood plug-in surface,
+ * Likelihood._evaluate_gradient (binf/pdf/likelihoods.py:148-155):
+ *     return dfm.dot(emgrad)
+ * for any forward model without a fused kernel of its own.
+ *   batched == 0: jacobian [K x N], shared by all chains (linear forward models;
+ *                 forwardmodels.py:23-28) -- two-operand f64 MFMA tiles;
+ *   batched != 0: jacobian [C x K x N], one per chain -- streamed row products.
+ *   emgrad [C x N] (error_model.gradient(mock_data=...), likelihoods.py:152-153),
+ *   out [C x K]:  out[c,k] = sum_n jacobian[(c,) k, n] * emgrad[c, n].
+ * The reference's BLAS summation order is not reproducible; this contraction is
+ * held to 1e-10 * sum_n |J||r| (tests/poly_bounds.py).  Its own order depends on
+ * (K, N) only: deterministic, and the same for any number of chains.
+ * ---------------------------------------------------------------------- */
+int32_t binf_jacobian_contract_f64(const double *jacobian, const double *emgrad,
+                                   double *out, int64_t C, int64_t K, int64_t N,
+                                   int32_t batched, void *stream);
+
+/* out[i] = ((t_0[i] + t_1[i]) + t_2[i]) + ... : the Posterior's sums over its
+ * components, Posterior._evaluate_log_prob (numpy.sum of a short list: sequential,
+ * binf/pdf/posteriors.py:147-151) and _evaluate_gradient (posteriors.py:173-187),
+ * in ONE launch and in the order given (the build's order: sorted component
+ * name).  terms: HOST array of n_terms (<= 16) device vectors of n elements; a
+ * NULL entry t stands for the host scalar scalars[t] (a component whose log-prob
+ * is a Python float).  out may be one of the terms. */
+int32_t binf_sum_terms_f64(const double *const *terms, const double *scalars,
+                           int32_t n_terms, double *out, int64_t n, void *stream);
 
 /* ------------------------------------------------------------------------
  * n sweeps of the example's Gibbs loop in ONE launch:
