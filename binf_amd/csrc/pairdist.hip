@@ -321,17 +321,34 @@ __global__ void __launch_bounds__(256 * LANES) pairdist_leapfrog_kernel(const Pa
     const int qt = (LANES == 4) ? (threadIdx.x & 3) : 0;              // quarter of the j-range
     const int slot = (LANES == 4) ? (threadIdx.x >> 2) : threadIdx.x;  // bead inside a tile of 256
 
-    // the four lanes of a bead hold identical copies of its position / momentum
-    double q[NB][3], p[NB][3];
+    // the four lanes of a bead hold identical copies of its position / momentum.  Four
+    // tiles of beads with four lanes each (769 .. 1024 beads, a 1024-thread workgroup:
+    // 128 VGPRs) do not fit q AND p in registers -- 28 bytes per lane went to scratch --
+    // so there the momentum lives in LDS behind the positions: every lane of a bead
+    // writes the same value to the same slot and reads it back itself.
+    constexpr bool PLDS = (NB == 4 && LANES == 4);
+    double *sp = sx + 3 * n;                     // [n_beads][3], PLDS only
+    double q[NB][3], p[PLDS ? 1 : NB][3];
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
         const int i = slot + 256 * b;
 #pragma unroll
         for (int ax = 0; ax < 3; ++ax) {
             q[b][ax] = (i < n) ? qc[3 * i + ax] : 0.0;
-            p[b][ax] = (i < n) ? pc[3 * i + ax] : 0.0;
+            const double pv = (i < n) ? pc[3 * i + ax] : 0.0;
+            if (PLDS) { if (i < n) sp[3 * i + ax] = pv; }
+            else p[b][ax] = pv;
         }
     }
+    auto get_p = [&](int b, int ax) -> double {
+        const int i = slot + 256 * b;
+        return PLDS ? ((i < n) ? sp[3 * i + ax] : 0.0) : p[PLDS ? 0 : b][ax];
+    };
+    auto set_p = [&](int b, int ax, double v) {
+        const int i = slot + 256 * b;
+        if (PLDS) { if (i < n) sp[3 * i + ax] = v; }
+        else p[PLDS ? 0 : b][ax] = v;
+    };
     auto publish = [&]() {
         __syncthreads();
 #pragma unroll
@@ -368,7 +385,8 @@ __global__ void __launch_bounds__(256 * LANES) pairdist_leapfrog_kernel(const Pa
                     const double gp = a.prior_k * (q[b][ax] - a.prior_x0);
                     g = a.prior_first ? gp + gl : gl + gp;
                 }
-                p[b][ax] = FMA ? __builtin_fma(-step, g, p[b][ax]) : p[b][ax] - step * g;
+                const double pv = get_p(b, ax);
+                set_p(b, ax, FMA ? __builtin_fma(-step, g, pv) : pv - step * g);
             }
         }
     };
@@ -377,7 +395,10 @@ __global__ void __launch_bounds__(256 * LANES) pairdist_leapfrog_kernel(const Pa
         for (int b = 0; b < NB; ++b)
 #pragma unroll
             for (int ax = 0; ax < 3; ++ax)
-                q[b][ax] = FMA ? __builtin_fma(p[b][ax], dt, q[b][ax]) : q[b][ax] + p[b][ax] * dt;
+            {
+                const double pv = get_p(b, ax);
+                q[b][ax] = FMA ? __builtin_fma(pv, dt, q[b][ax]) : q[b][ax] + pv * dt;
+            }
     };
 
     publish();
@@ -398,7 +419,7 @@ __global__ void __launch_bounds__(256 * LANES) pairdist_leapfrog_kernel(const Pa
 #pragma unroll
             for (int ax = 0; ax < 3; ++ax) {
                 qc[3 * i + ax] = q[b][ax];
-                pc[3 * i + ax] = p[b][ax];
+                pc[3 * i + ax] = get_p(b, ax);
             }
         }
     }
@@ -876,12 +897,13 @@ extern "C" int32_t binf_pairdist_leapfrog_f64(double *q, double *p, const double
     a.tau = precision; a.timestep = timestep; a.prior_k = prior_k; a.prior_x0 = prior_x0;
     a.has_prior = has_prior ? 1 : 0; a.prior_first = prior_first ? 1 : 0;
     a.nsteps = nsteps; a.n_beads = (int32_t)n_beads; a.n_chains = C;
-    const size_t lds = (size_t)n_beads * 3 * sizeof(double);
     dim3 grid((unsigned)C);
     hipStream_t st = (hipStream_t)stream;
     const bool fma = mode == BINF_MODE_FMA;
     const int nb = (int)((n_beads + 255) / 256);
     const bool four = lanes_per_bead(C) == 4;
+    // positions; four tiles x four lanes keep the momentum there as well
+    const size_t lds = (size_t)n_beads * 3 * sizeof(double) * ((nb >= 4 && four) ? 2 : 1);
     if (n_beads >= SYM_MIN_BEADS && n_beads <= SYM_MAX_BEADS && sym_enabled()) {
         const int nblk = (int)((n_beads + 63) / 64);
         if (nblk == 1)      launch_leapfrog_sym<1>(a, fma, st);

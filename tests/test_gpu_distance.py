@@ -119,7 +119,8 @@ def test_c5_size_properties(device):
 
 
 @pytest.mark.parametrize('n,C,L,dt,with_prior', [(8, 12, 10, 0.02, True), (256, 5, 6, 0.002, True),
-                                                 (300, 3, 3, 0.002, False), (700, 2, 2, 0.001, True)])
+                                                 (300, 3, 3, 0.002, False), (700, 2, 2, 0.001, True),
+                                                 (1000, 2, 2, 0.0005, True), (770, 1030, 1, 0.0005, False)])
 def test_fused_leapfrog_is_bit_identical_to_the_per_step_tier(device, n, C, L, dt, with_prior):
     ys, x = synth(n, C, 5 * n)
     rs = np.random.RandomState(n + 1)

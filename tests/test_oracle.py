@@ -153,7 +153,7 @@ def test_polynomial_gibbs_golden_is_what_the_restatement_gives(name):
         assert 0 < g['accepted'].mean() < 1
 
 
-@pytest.mark.parametrize('name', ['dist_n12', 'dist_n40', 'dist_n100'])
+@pytest.mark.parametrize('name', ['dist_n12', 'dist_n40', 'dist_n100', 'dist_n256', 'dist_n300'])
 def test_distance_golden_is_what_the_restatement_gives(name):
     from oracle import gen_golden as G
     g = load_golden(golden_files(name)[0])
