@@ -103,6 +103,34 @@ __device__ inline double xor8_f64(double v) { return dpp_f64<0x128>(v); }   // r
 // lanes of a quad hold the same value -- then the same bits as an xor-4 exchange
 __device__ inline double other_quad_f64(double v) { return dpp_f64<0x141>(v); }
 
+// xor-16 / xor-32 partners through the gfx950 lane-swap instructions (VALU; the
+// ds_bpermute pair they replace waits ~100 cycles for the LDS crossbar):
+//   v_permlane16_swap vdst, src: odd rows (of 16 lanes) of vdst <-> even rows of src
+//   v_permlane32_swap vdst, src: lanes 32..63 of vdst <-> lanes 0..31 of src
+// with vdst = src = v, one result holds the even / lower copies and the other the
+// odd / upper ones; a lane picks the one that carries its partner's value.
+__device__ inline double xor16_f64(double v, int lane)
+{
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    const bool odd = (lane >> 4) & 1;
+    return __hiloint2double(odd ? (int)b[0] : (int)b[1], odd ? (int)a[0] : (int)a[1]);
+}
+__device__ inline double xor32_f64(double v, int lane)
+{
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    const bool up = lane >= 32;
+    return __hiloint2double(up ? (int)b[0] : (int)b[1], up ? (int)a[0] : (int)a[1]);
+}
+// partner lane ^ (8 << l), l = 0, 1, 2 (the leaf-tree levels inside a wave)
+__device__ inline double xor_level_f64(double v, int l, int lane)
+{
+    return l == 0 ? xor8_f64(v) : (l == 1 ? xor16_f64(v, lane) : xor32_f64(v, lane));
+}
+
 // all-reduce sum over aligned groups of 8 lanes in the order
 // ((v0+v1)+(v2+v3))+((v4+v5)+(v6+v7)); every lane ends with the same bits
 __device__ inline double sum8_f64(double r)

@@ -126,7 +126,7 @@ __device__ inline double chain_sum_finish(const LaneSum &s, int T, int rem,
     // join the leaves: level l combines the two depth-(H-l) subtrees
     const int hin = (LW > 0) ? 3 : H;
     for (int l = 0; l < hin; ++l) {
-        const double o = (l == 0) ? xor8_f64(res) : shfl_xor_f64(res, 8 << l);
+        const double o = xor_level_f64(res, l, lane);
         const double n = res + o;
         res = (leafdepth >= H - l) ? n : res;
     }

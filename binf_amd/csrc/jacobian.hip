@@ -114,8 +114,8 @@ jac_batched_kernel(const double *__restrict__ r, const double *__restrict__ J,
             double s = s0 + s1;
             s = sum8_f64(s);
             s = s + xor8_f64(s);
-            s = s + shfl_xor_f64(s, 16);
-            s = s + shfl_xor_f64(s, 32);
+            s = s + xor16_f64(s, lane);
+            s = s + xor32_f64(s, lane);
             if (lane == 0) out[c * K + k] = s;
         }
     }

@@ -316,9 +316,13 @@ __global__ void __launch_bounds__(256) poly_chain_kernel(const PolyChainArgs a)
         if (lg > 3) {
 #pragma unroll
             for (int k = 0; k < KMAX; ++k) g[k] = g[k] + xor8_f64(g[k]);
-            for (int m = 16; m < (1 << lg); m <<= 1) {
+            if (lg > 4) {
 #pragma unroll
-                for (int k = 0; k < KMAX; ++k) g[k] = g[k] + shfl_xor_f64(g[k], m);
+                for (int k = 0; k < KMAX; ++k) g[k] = g[k] + xor16_f64(g[k], lane);
+            }
+            if (lg > 5) {
+#pragma unroll
+                for (int k = 0; k < KMAX; ++k) g[k] = g[k] + xor32_f64(g[k], lane);
             }
         }
 #pragma unroll

@@ -87,7 +87,7 @@ row_reduce_wave_kernel(const ARGS args, const RowGeom g, double *out)
     const auto f = FM::make(args, row);
     double res = leaf_sum_f(f, L.off, L.len, lane, true);
     for (int l = 0; l < H; ++l) {
-        const double o = (l == 0) ? xor8_f64(res) : shfl_xor_f64(res, 8 << l);
+        const double o = xor_level_f64(res, l, lane);
         const double s = res + o;
         res = (L.depth >= H - l) ? s : res;
     }
