@@ -96,6 +96,9 @@ SIGNATURES = {
     'binf_poly_gauss_grad_f64': (_i32, [_vp, _vp, _vp, _f64, _vp, _vp, _vp,
                                         _i64, _i64, _i64, _i64, _vp]),
     'binf_gamma_precision_update_f64': (_i32, [_vp, _vp, _f64, _vp, _i64, _vp]),
+    'binf_poly_leapfrog_workspace_bytes': (_i64, [_i64, _i64, _i64]),
+    'binf_poly_leapfrog_f64': (_i32, [_vp, _vp, _vp, _vp, _f64, _vp, _vp, _i64, _i64, _i64, _i64,
+                                      _f64, _vp, _i32, _i32, _vp]),
     'binf_pairdist_gauss_logp_f64': (_i32, [_vp, _vp, _vp, _vp, _f64, _vp, _vp, _i64,
                                             _i64, _i64, _vp]),
     'binf_pairdist_forward_f64': (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i64,
@@ -664,6 +667,32 @@ def poly_gauss_grad(coeffs, design, ys, precision):
         ws.data_ptr() if ws is not None else None, need, C, K, N, st)
     check(rc, 'binf_poly_gauss_grad_f64')
     return out
+
+
+@_launcher
+def poly_leapfrog(q, p, design, ys, precision, timestep, dt_chain, nsteps, mode=MODE_EXACT):
+    """binf_poly_leapfrog_f64: the whole ``_leapfrog`` under the polynomial
+    likelihood's force, in place on ``q`` and ``p`` (``[C x K]``)."""
+    C, K = _cd(q)
+    N = ys.numel()
+    if design.shape != (K, N):
+        raise ValueError('design matrix must be [%d x %d], got %s' % (K, N, tuple(design.shape)))
+    tau, tau_chain = _precision_args(precision, C, q.device)
+    need = lib().binf_poly_leapfrog_workspace_bytes(C, K, N)
+    st = stream_handle(q.device)
+    key = (q.device, st, 'leap', need)
+    ws = _grad_ws.get(key)
+    if ws is None:
+        ws = torch.empty(max(1, need // 8), dtype=torch.float64, device=q.device)
+        while len(_grad_ws) >= 4:
+            _grad_ws.pop(next(iter(_grad_ws)))
+        _grad_ws[key] = ws
+    rc = lib().binf_poly_leapfrog_f64(
+        dptr(q, numel=C * K, name='q'), dptr(p, numel=C * K, name='p'),
+        dptr(design, numel=K * N, name='design'), dptr(ys, numel=N, name='ys'), tau,
+        dptr(tau_chain, numel=C, name='precision'), ws.data_ptr(), need, C, K, N,
+        float(timestep), dptr(dt_chain, numel=C, name='dt_chain'), int(nsteps), int(mode), st)
+    check(rc, 'binf_poly_leapfrog_f64')
 
 
 @_launcher

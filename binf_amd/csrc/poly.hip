@@ -323,6 +323,31 @@ __global__ void split_reduce_kernel(const double *part, double *out, int64_t n,
     out[j] = s;
 }
 
+// The same sum, followed by the kick it feeds and the drift that follows the kick:
+// g = part[0][j] + part[1][j] + ...;  p[j] -= step * g;  q[j] += p[j] * dt
+// (hmc.py:116 + 119, 120 + 119 / 122, or 123 alone) -- one launch instead of
+// split_reduce_kernel + kick (+ drift) of the per-step tier, the same roundings.
+// leap: 1 half kick + drift, 2 kick + drift, 3 half kick.
+template <bool FMA>
+__global__ void __launch_bounds__(256)
+split_reduce_kick_drift_kernel(const double *part, double *q, double *p, const double *dt_chain,
+                               double timestep, int64_t n, int32_t K, int32_t ns, int32_t leap)
+{
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    double g = part[j];
+    for (int k = 1; k < ns; ++k) g = g + part[(int64_t)k * n + j];
+    const double d = dt_chain ? dt_chain[j / K] : timestep;
+    const double step = (leap == 2) ? d : 0.5 * d;          // "0.5 * timestep" first
+    const double pv = p[j];
+    const double pn = FMA ? __builtin_fma(-step, g, pv) : pv - step * g;
+    p[j] = pn;
+    if (leap != 3) {
+        const double qv = q[j];
+        q[j] = FMA ? __builtin_fma(pn, d, qv) : qv + pn * d;
+    }
+}
+
 static int grad_ct(int64_t C)
 {
     // two 16-chain tiles per wave once there are enough chains to fill the chip
@@ -489,6 +514,25 @@ extern "C" int32_t binf_gamma_logp_f64(const double *precision, double shape, do
     return 0;
 }
 
+static hipError_t grad_dispatch(const GradArgs &a, int64_t K, int ct, dim3 grid, hipStream_t st)
+{
+    hipError_t e;
+    if (K <= 4)       e = grad_launch<1, 1, 0>(a, ct, grid, st);
+    else if (K <= 8)  e = grad_launch<2, 1, 0>(a, ct, grid, st);
+    else if (K <= 16) e = grad_launch<4, 1, 0>(a, ct, grid, st);
+    else if (K == 17) e = grad_launch<4, 1, 1>(a, ct, grid, st);
+    else if (K == 18) e = grad_launch<4, 1, 2>(a, ct, grid, st);
+    else if (K <= 32) e = grad_launch<8, 2, 0>(a, ct, grid, st);
+    else if (K == 33) e = grad_launch<8, 2, 1>(a, ct, grid, st);
+    else if (K == 34) e = grad_launch<8, 2, 2>(a, ct, grid, st);
+    else if (K <= 36) e = grad_launch<9, 3, 0>(a, ct, grid, st);
+    else if (K <= 48) e = grad_launch<12, 3, 0>(a, ct, grid, st);
+    else if (K == 49) e = grad_launch<12, 3, 1>(a, ct, grid, st);
+    else if (K == 50) e = grad_launch<12, 3, 2>(a, ct, grid, st);
+    else              e = grad_launch<16, 4, 0>(a, ct, grid, st);
+    return e;
+}
+
 extern "C" int64_t binf_poly_gauss_grad_workspace_bytes(int64_t C, int64_t K, int64_t N)
 {
     if (C <= 0 || K <= 0 || N <= 0) return 0;
@@ -531,19 +575,7 @@ extern "C" int32_t binf_poly_gauss_grad_f64(const double *coeffs, const double *
     dim3 grid((unsigned)((C + 64 * ct - 1) / (64 * ct)), (unsigned)ns);
     hipStream_t st = (hipStream_t)stream;
     hipError_t e;
-    if (K <= 4)       e = grad_launch<1, 1, 0>(a, ct, grid, st);
-    else if (K <= 8)  e = grad_launch<2, 1, 0>(a, ct, grid, st);
-    else if (K <= 16) e = grad_launch<4, 1, 0>(a, ct, grid, st);
-    else if (K == 17) e = grad_launch<4, 1, 1>(a, ct, grid, st);
-    else if (K == 18) e = grad_launch<4, 1, 2>(a, ct, grid, st);
-    else if (K <= 32) e = grad_launch<8, 2, 0>(a, ct, grid, st);
-    else if (K == 33) e = grad_launch<8, 2, 1>(a, ct, grid, st);
-    else if (K == 34) e = grad_launch<8, 2, 2>(a, ct, grid, st);
-    else if (K <= 36) e = grad_launch<9, 3, 0>(a, ct, grid, st);
-    else if (K <= 48) e = grad_launch<12, 3, 0>(a, ct, grid, st);
-    else if (K == 49) e = grad_launch<12, 3, 1>(a, ct, grid, st);
-    else if (K == 50) e = grad_launch<12, 3, 2>(a, ct, grid, st);
-    else              e = grad_launch<16, 4, 0>(a, ct, grid, st);
+    e = grad_dispatch(a, K, ct, grid, st);
     if (e != hipSuccess) return hip_fail(e, "poly_gauss_grad launch");
     if (ns > 1) {
         const int64_t n = C * K;
@@ -551,6 +583,63 @@ extern "C" int32_t binf_poly_gauss_grad_f64(const double *coeffs, const double *
             (const double *)workspace, out, n, ns);
         e = hipGetLastError();
         if (e != hipSuccess) return hip_fail(e, "poly_gauss_grad reduce launch");
+    }
+    return 0;
+}
+
+extern "C" int64_t binf_poly_leapfrog_workspace_bytes(int64_t C, int64_t K, int64_t N)
+{
+    if (C <= 0 || K <= 0 || N <= 0) return 0;
+    return (int64_t)grad_splits(C, N) * C * K * (int64_t)sizeof(double);
+}
+
+extern "C" int32_t binf_poly_leapfrog_f64(double *q, double *p, const double *design,
+                                          const double *ys, double precision,
+                                          const double *precision_chain, void *workspace,
+                                          int64_t workspace_bytes, int64_t C, int64_t K,
+                                          int64_t N, double timestep, const double *dt_chain,
+                                          int32_t nsteps, int32_t mode, void *stream)
+{
+    int32_t rc = check_poly("poly_leapfrog", C, K, N);
+    if (rc) return rc;
+    if (nsteps < 1) return fail(BINF_E_ARG, "poly_leapfrog: nsteps >= 1 required");
+    if (mode != BINF_MODE_EXACT && mode != BINF_MODE_FMA)
+        return fail(BINF_E_ARG, "poly_leapfrog: unknown mode %d", mode);
+    if (C == 0) return 0;
+    if (N < 1) return fail(BINF_E_UNSUPPORTED, "poly_leapfrog: no data points");
+    if (!q || !p || !design || !ys) return fail(BINF_E_ARG, "poly_leapfrog: null buffer");
+    const int64_t need = binf_poly_leapfrog_workspace_bytes(C, K, N);
+    if (!workspace || workspace_bytes < need)
+        return fail(BINF_E_ARG, "poly_leapfrog: needs %lld bytes of workspace "
+                    "(binf_poly_leapfrog_workspace_bytes), got %lld",
+                    (long long)need, (long long)workspace_bytes);
+    const int ns = grad_splits(C, N);
+    const int ntiles = (int)((N + 15) / 16);
+    const int ct = grad_ct(C);
+    GradArgs a;
+    a.theta = q; a.A = design; a.ys = ys; a.tau_chain = precision_chain; a.tau = precision;
+    a.C = C; a.K = (int32_t)K; a.N = (int32_t)N;
+    a.tiles_per_split = (ntiles + ns - 1) / ns;
+    if (a.tiles_per_split < 1) a.tiles_per_split = 1;
+    a.part = (double *)workspace;
+    dim3 grid((unsigned)((C + 64 * ct - 1) / (64 * ct)), (unsigned)ns);
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t n = C * K;
+    const dim3 rgrid((unsigned)((n + 255) / 256));
+    // hmc.py:116-123: half kick, (nsteps - 1) x [drift, kick], drift, half kick -- per
+    // gradient one MFMA launch and one launch for partial sums + kick + drift
+    for (int l = 0; l <= nsteps; ++l) {
+        const int leap = (l == 0) ? 1 : (l == nsteps ? 3 : 2);
+        hipError_t e = grad_dispatch(a, K, ct, grid, st);
+        if (e != hipSuccess) return hip_fail(e, "poly_leapfrog gradient launch");
+        if (mode == BINF_MODE_FMA)
+            split_reduce_kick_drift_kernel<true><<<rgrid, 256, 0, st>>>(
+                (const double *)workspace, q, p, dt_chain, timestep, n, (int32_t)K, ns, leap);
+        else
+            split_reduce_kick_drift_kernel<false><<<rgrid, 256, 0, st>>>(
+                (const double *)workspace, q, p, dt_chain, timestep, n, (int32_t)K, ns, leap);
+        e = hipGetLastError();
+        if (e != hipSuccess) return hip_fail(e, "poly_leapfrog kick launch");
     }
     return 0;
 }

@@ -149,6 +149,28 @@ class Posterior(AbstractBinfPDF):
         from binf_amd.example import native_poly
         return native_poly.posterior_hmc_spec(self, variable_name)
 
+    def _native_poly_leapfrog_spec(self, variable_name):
+        """``('poly', forward_model, error_model, precision)`` if the force on
+        ``variable_name`` is exactly ONE polynomial + Gaussian-error likelihood with
+        its precision fixed (every other component has no differentiable variable,
+        quirk Q4) -- the example's conditional posterior of the coefficients: the
+        whole ``_leapfrog`` then runs as ``binf_poly_leapfrog_f64``."""
+        from binf_amd.pdf.likelihoods import Likelihood
+        if variable_name != 'coefficients':
+            return None
+        lik = None
+        for f in self._ordered_components():
+            if not (len(f.variables) > 0 and len(f.differentiable_variables) > 0):
+                continue
+            if lik is not None or not isinstance(f, Likelihood) or f._native_pair() is None or \
+                    set(f.variables) != {variable_name} or \
+                    'precision' not in f.error_model.parameters:
+                return None
+            lik = f
+        if lik is None:
+            return None
+        return ('poly', lik.forward_model, lik.error_model, lik.error_model['precision'].value)
+
     def native_leapfrog_spec(self, variable_name):
         """Descriptor of a fused leapfrog kernel that integrates
         ``variable_name`` under THIS posterior's force, or None.
@@ -161,6 +183,9 @@ class Posterior(AbstractBinfPDF):
         class's sorted-component-name order."""
         from binf_amd.pdf import IsotropicGaussian
         from binf_amd.pdf.likelihoods import Likelihood
+        poly = self._native_poly_leapfrog_spec(variable_name)
+        if poly is not None:
+            return poly
         lik = prior = None
         order = []
         for f in self._ordered_components():

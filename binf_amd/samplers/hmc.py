@@ -475,6 +475,13 @@ class HMCSampler(object):
             _native.pairdist_leapfrog(q2, p2, em.ymat_device(q2.device), precision,
                                       prior, prior_first, dt, dtc, nsteps, mode)
             return q, p
+        if leap is not None and leap[0] == 'poly' and q2.is_cuda and q2.shape[1] <= 64:
+            # gradient, partial-sum reduction, kick and drift of every step in one launch
+            # each (bit-identical to the loop below)
+            _, fwm, em, precision = leap
+            _native.poly_leapfrog(q2, p2, fwm.design_matrix(q2.shape[1], q2.device),
+                                  em.ys_device(q2.device), precision, dt, dtc, nsteps, mode)
+            return q, p
         # half kick, drift, (nsteps - 1) x [gradient, kick + next drift], half kick:
         # the reference's sequence (hmc.py:116-123) with every interior kick
         # and the drift that follows it in one pass over memory

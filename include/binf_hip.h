@@ -35,7 +35,7 @@ extern "C" {
  * 3: binf_hmc_sample_poly_f64 spreads a chain's data over a lane group for EVERY
  *    N <= 1024 (the force's summation order for N <= 128 changed with it; one lane
  *    per chain is now the opt-in BINF_MODE_LANE_PER_CHAIN); binf_gibbs_poly_sample_n_f64,
- *    binf_jacobian_contract_f64, binf_sum_terms_f64. */
+ *    binf_jacobian_contract_f64, binf_sum_terms_f64, binf_poly_leapfrog_f64. */
 #define BINF_ABI_VERSION 3
 
 #define BINF_E_ARG        (-1)  /* null pointer / negative size / bad flag    */
@@ -354,6 +354,30 @@ int32_t binf_poly_gauss_grad_f64(const double *coeffs, const double *design,
                                  const double *precision_chain, double *out,
                                  void *workspace, int64_t workspace_bytes,
                                  int64_t C, int64_t K, int64_t N, void *stream);
+
+/* HMCSampler._leapfrog (binf/samplers/hmc.py:92-125) under the force of the
+ * polynomial + Gaussian likelihood alone (the example's conditional posterior of
+ * the coefficients: its priors are not differentiable, posteriors.py:183), IN
+ * PLACE on q = coefficients [C x K] and p [C x K]: per gradient call one launch of
+ * the MFMA gradient kernel of binf_poly_gauss_grad_f64 (partial sums over the
+ * data splits) and ONE launch that adds the partial sums in split order and
+ * applies the kick (hmc.py:116,120,123) and the drift that follows it (:119,122)
+ * -- 2 (nsteps + 1) launches from one call instead of ~3 per step through the
+ * class stack.  BIT-IDENTICAL to the per-step sequence binf_poly_gauss_grad_f64,
+ * binf_leapfrog_kick_f64 (half), binf_leapfrog_drift_f64,
+ * binf_leapfrog_kick_drift_f64 ... on the same batch.  (Combining a chain tile
+ * inside the gradient launch -- last workgroup, agent-scope release / acquire --
+ * was built and measured: 68-130 us per step slower, a tile's 16 x 34 KB of
+ * partial sums are too much for one workgroup to read.)  workspace: caller-owned
+ * device scratch of binf_poly_leapfrog_workspace_bytes(C, K, N) bytes
+ * (mandatory).  timestep / dt_chain, mode as elsewhere. */
+int64_t binf_poly_leapfrog_workspace_bytes(int64_t C, int64_t K, int64_t N);
+int32_t binf_poly_leapfrog_f64(double *q, double *p, const double *design,
+                               const double *ys, double precision,
+                               const double *precision_chain, void *workspace,
+                               int64_t workspace_bytes, int64_t C, int64_t K,
+                               int64_t N, double timestep, const double *dt_chain,
+                               int32_t nsteps, int32_t mode, void *stream);
 
 /* One HMCSampler.sample() (binf/samplers/hmc.py:136-164,183-191) for every
  * chain on the example's polynomial posterior with a SMALL or MEDIUM data set

@@ -23,6 +23,7 @@ from binf_amd.example.samplers import (GammaSampler, RWMCSampler,
                                        make_hmc_sampler, make_sampler)
 from binf_amd.samplers import BinfState
 from binf_amd.samplers.hmc import HMCSampler
+from binf_amd.pdf.posteriors import Posterior
 import poly_bounds as PB
 from conftest import golden_files, load_golden
 from oracle import ref_example as RE
@@ -819,3 +820,67 @@ def test_gamma_prior_log_prob_kernel_equals_the_expression(device):
             assert np.allclose(got.cpu().numpy(), want, rtol=0, atol=4e-16 * np.maximum(1.0, np.abs(want)).max() * 8)
             pr = GammaPrior(shape, rate)
             assert torch.equal(pr.log_prob(precision=t), got)
+
+
+@pytest.mark.parametrize('K,N,C,L,mode,per_chain', [
+    (4, 20, 5, 3, 'exact', False), (33, 1000, 20, 4, 'exact', True), (33, 16384, 130, 2, 'exact', False),
+    (8, 300, 2100, 3, 'fma', True), (17, 50, 3, 1, 'exact', False), (64, 129, 70, 2, 'fma', False),
+    (33, 4096, 2050, 2, 'exact', True)])
+def test_fused_polynomial_leapfrog_is_bit_identical_to_the_per_step_tier(device, K, N, C, L, mode,
+                                                                         per_chain):
+    """binf_poly_leapfrog_f64 (gradient + partial-sum reduction + kick + drift per
+    launch, the last workgroup of a chain tile combining it) against the per-step
+    sequence of launches it replaces: the same bits in q and p, whatever workgroup
+    happened to come last."""
+    xs, ys, theta = synth(K, N, C, K + N, xlim=1.0)
+    lik = make_likelihood(xs, ys, POLYVAL)
+    post = Posterior({lik.name: lik}, {'precision_prior': GammaPrior(1.0, 0.2),
+                                       'coefficients_prior': GaussianPrior(np.zeros(K), np.ones(K) * 5)})
+    rs = np.random.RandomState(C)
+    taus = dev_t(rs.uniform(1.0, 4.0, size=C), device)
+    cond = post.conditional_factory(precision=taus)
+    spec = cond.native_leapfrog_spec('coefficients')
+    assert spec is not None and spec[0] == 'poly'
+    assert cond.native_leapfrog_spec('precision') is None
+    dt = 1e-3 / K
+    dts = dev_t(dt * rs.uniform(0.5, 1.5, size=C), device) if per_chain else dt
+    p0 = rs.standard_normal((C, K))
+    outs = []
+    for fused in (True, False, True):
+        s = HMCSampler(cond, dev_t(theta, device), dt, L, variable_name='coefficients', mode=mode)
+        s.fused_leapfrog = fused
+        s.fused_polynomial = False
+        q, p = dev_t(theta, device), dev_t(p0, device)
+        s._leapfrog(q, p, dts, L)
+        outs.append((q, p))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert torch.equal(outs[0][0], outs[2][0]) and torch.equal(outs[0][1], outs[2][1])
+    assert not torch.equal(outs[0][0], dev_t(theta, device))
+    # ... and a whole sample() through it equals the per-step one
+    res = []
+    for fused in (True, False):
+        s = HMCSampler(cond, dev_t(theta, device), dt, L, variable_name='coefficients', mode=mode,
+                       record_energies=True)
+        s.fused_leapfrog = fused
+        s.fused_polynomial = False
+        x = s.sample(p0=dev_t(p0, device), u=dev_t(rs.uniform(size=C) * 0 + 0.5, device))
+        res.append((x, s.last_e_after, s.last_move_accepted))
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+
+
+def test_fused_polynomial_leapfrog_argument_checks(device):
+    C, K, N = 8, 4, 20
+    q = torch.zeros((C, K), dtype=torch.float64, device=device)
+    A = torch.ones((K, N), dtype=torch.float64, device=device)
+    y = torch.zeros(N, dtype=torch.float64, device=device)
+    with pytest.raises(ValueError):
+        _native.poly_leapfrog(q, q.clone(), A, y, 1.0, 0.1, None, 0)
+    with pytest.raises(ValueError):
+        _native.poly_leapfrog(q, q.clone(), A[:, :5].contiguous(), y, 1.0, 0.1, None, 2)
+    need = _native.lib().binf_poly_leapfrog_workspace_bytes(C, K, N)
+    assert need > 0
+    rc = _native.lib().binf_poly_leapfrog_f64(q.data_ptr(), q.clone().data_ptr(), A.data_ptr(),
+                                              y.data_ptr(), 1.0, None, None, 0, C, K, N, 0.1, None, 2,
+                                              0, None)
+    assert rc == _native.E_ARG and 'workspace' in _native.last_error()
