@@ -21,19 +21,37 @@ __device__ inline double leaf_sum_f(const F &f, int off, int n, int lane,
     const int rem = (n >= 8) ? (n & 7) : n;
     double r = 0.0;
     if (active && T > 0) {
-        r = f(off + j);
-        for (int t = 1; t < T; ++t) r = r + f(off + 8 * t + j);
+        // eight element values at a time: their loads (and the gathers behind them) are
+        // in flight together, then they are added in order -- one value per round trip
+        // left a lane waiting for memory 16 times per leaf
+        int t = 0;
+        for (; t + 8 <= T; t += 8) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = f(off + 8 * (t + u) + j);
+            r = (t == 0) ? v[0] : r + v[0];
+#pragma unroll
+            for (int u = 1; u < 8; ++u) r = r + v[u];
+        }
+        for (; t < T; ++t) {
+            const double v = f(off + 8 * t + j);
+            r = (t == 0) ? v : r + v;
+        }
     }
     r = sum8_f64(r);
     double res = (T > 0) ? r : -0.0;
-    double tail = 0.0;
-    if (active && j < rem) tail = f(off + 8 * T + j);
-    const int leafbase = lane & ~7;
+    // the leaf's tail elements (n not a multiple of 8), in order; skipped when no leaf
+    // of this wave has one
+    if (__any(rem != 0)) {
+        double tail = 0.0;
+        if (active && j < rem) tail = f(off + 8 * T + j);
+        const int leafbase = lane & ~7;
 #pragma unroll
-    for (int i = 0; i < 7; ++i) {
-        const double v = shfl_f64(tail, leafbase + i);
-        const double s = res + v;
-        res = (i < rem) ? s : res;
+        for (int i = 0; i < 7; ++i) {
+            const double v = shfl_f64(tail, leafbase + i);
+            const double s = res + v;
+            res = (i < rem) ? s : res;
+        }
     }
     return res;
 }
