@@ -151,11 +151,13 @@ def test_leapfrog_spec_rejects_unsupported_structures(device):
     ys, x = synth(8, 2, 1)
     # precision still free -> no fused leapfrog
     assert make_post(ys, 8).native_leapfrog_spec('coordinates') is None
-    # a polynomial posterior has none either
+    # a polynomial posterior has its own (binf_poly_leapfrog_f64), never the pair-distance one
     from binf_amd.example.misc import make_posterior
     from binf_amd.example.likelihood import POLYVAL
     post = make_posterior(np.linspace(-1, 1, 5), np.zeros(5), POLYVAL)
-    assert post.conditional_factory(precision=1.0).native_leapfrog_spec('coefficients') is None
+    spec = post.conditional_factory(precision=1.0).native_leapfrog_spec('coefficients')
+    assert spec is not None and spec[0] == 'poly'
+    assert post.native_leapfrog_spec('coefficients') is None          # precision still free
 
 
 @pytest.mark.parametrize('n', [24, 40, 64, 100, 150, 200, 256, 300])
