@@ -57,6 +57,14 @@ SIGNATURES = {
                                                  _i64, _i64, _i32, _f64, _f64, _i32,
                                                  _f64, _f64, _i32, ctypes.c_uint64,
                                                  ctypes.c_uint64, _i64, _vp, _i64, _vp]),
+    'binf_hmc_sample_n_gauss_big_workspace_bytes': (_i64, [_i64, _i64]),
+    'binf_hmc_sample_n_gauss_big_f64': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                               _f64, _vp, _i64, _i64, _i32, _i32, _i32, _f64,
+                                               _f64, _i32, _f64, _f64, _i32, _vp, _i64, _vp]),
+    'binf_hmc_sample_n_gauss_big_rng_f64': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _f64, _vp,
+                                                   _i64, _i64, _i32, _i32, _i32, _f64, _f64,
+                                                   _i32, _f64, _f64, _i32, _u64, _u64, _i64,
+                                                   _vp, _i64, _vp]),
     'binf_hmc_gauss_big_rng_draws_f64': (_i32, [_vp, _vp, _i64, _i64, ctypes.c_uint64,
                                                 ctypes.c_uint64, _i64, _vp]),
     'binf_hmc_sample_n_gauss_rng_f64': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp,
@@ -793,6 +801,46 @@ def hmc_sample_gauss_big_rng(q0, q_out, accepted, n_accepted, e_before, e_after,
         int(seed) & (2 ** 64 - 1), int(offset) & (2 ** 64 - 1), int(chain_offset), dptr(ws),
         nbytes, stream_handle(q0.device))
     check(rc, 'binf_hmc_sample_gauss_big_rng_f64')
+
+
+_big_n_ws = {}
+
+
+@_launcher
+def hmc_sample_n_gauss_big(q0, p0, u, q_out, samples, accepted, n_accepted, e_before, e_after,
+                           timestep, dt_chain, nsteps, n, thin, k, x0, n_adapt, uprate, downrate,
+                           mode=MODE_EXACT, rng=None):
+    """binf_hmc_sample_n_gauss_big_f64 (draws supplied: ``p0`` [n, C, D], ``u``
+    [n, C]) or, with ``rng = (seed, offset, chain_offset)``, its _rng form."""
+    C, D = _cd(q0)
+    n, thin = int(n), int(thin)
+    nrec = n // thin
+    need = lib().binf_hmc_sample_n_gauss_big_workspace_bytes(C, D)
+    st = stream_handle(q0.device)
+    key = (q0.device, st, need)
+    ws = _big_n_ws.get(key)
+    if ws is None:
+        ws = torch.empty(need // 8, dtype=torch.float64, device=q0.device)
+        _big_n_ws.clear()                      # one long-chain scratch at a time
+        _big_n_ws[key] = ws
+    common = (dptr(samples, numel=nrec * C * D, name='samples'),
+              dptr(accepted, torch.uint8, n * C, 'accepted'),
+              dptr(n_accepted, torch.int64, C, 'n_accepted'),
+              dptr(e_before, numel=n * C, name='e_before'), dptr(e_after, numel=n * C, name='e_after'),
+              float(timestep), dptr(dt_chain, numel=C, name='dt_chain'), C, D, int(nsteps), n, thin,
+              float(k), float(x0), int(n_adapt), float(uprate), float(downrate), int(mode))
+    if rng is None:
+        rc = lib().binf_hmc_sample_n_gauss_big_f64(
+            dptr(q0, numel=C * D, name='q0'), dptr(p0, numel=n * C * D, name='p0'),
+            dptr(u, numel=n * C, name='u'), dptr(q_out, numel=C * D, name='q_out'), *common,
+            ws.data_ptr(), need, st)
+        check(rc, 'binf_hmc_sample_n_gauss_big_f64')
+    else:
+        seed, offset, coff = rng
+        rc = lib().binf_hmc_sample_n_gauss_big_rng_f64(
+            dptr(q0, numel=C * D, name='q0'), dptr(q_out, numel=C * D, name='q_out'), *common,
+            int(seed) & (2 ** 64 - 1), int(offset) & (2 ** 64 - 1), int(coff), ws.data_ptr(), need, st)
+        check(rc, 'binf_hmc_sample_n_gauss_big_rng_f64')
 
 
 def hmc_gauss_big_rng_draws(C, D, seed, offset, device, chain_offset=0):

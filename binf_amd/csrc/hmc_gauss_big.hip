@@ -502,3 +502,104 @@ extern "C" int32_t binf_hmc_gauss_big_rng_draws_f64(double *p0_out, double *u_ou
                                  BINF_MODE_EXACT, nullptr, seed, offset, chain_offset, p0_out, u_out,
                                  (hipStream_t)stream);
 }
+
+// ---------------------------------------------------------------------------
+// n transitions from one call: the `for i in range(n): sampler.sample()` loop of
+// example_script.py:33-34 for long chains.  The trajectory kernel moves its 24 D
+// bytes per chain as fast per byte as the persistent kernel of hmc_gauss.hip moves
+// its 16 D (measured: 0.22 vs 0.245 ps/B), so there is no persistent variant to
+// gain from for chains that do not fit a workgroup's registers; what a loop of
+// single calls DOES waste is the copy of every recorded state (torch.stack: +16 D)
+// and the host between the launches.  Here transition s writes its proposal
+// straight into the record slot (or into one of two scratch states), rejected
+// chains are restored from the state the transition read, and the next transition
+// reads what this one wrote: 3 launches and 24 D bytes per transition, recorded
+// or not.  Bit-identical to n single calls (the same kernels).
+// ---------------------------------------------------------------------------
+extern "C" int64_t binf_hmc_sample_n_gauss_big_workspace_bytes(int64_t C, int64_t D)
+{
+    if (C <= 0 || D <= 0) return 0;
+    return binf_hmc_sample_gauss_big_workspace_bytes(C, D) + C * D * (int64_t)sizeof(double);
+}
+
+template <int RNG>
+static int32_t big_run_n(const char *what, const double *q0, const double *p0, const double *u,
+                         double *q_out, double *samples, uint8_t *accepted, int64_t *n_accepted,
+                         double *e_before, double *e_after, double timestep, double *dt_chain,
+                         int64_t C, int64_t D, int32_t nsteps, int32_t n, int32_t thin, double k,
+                         double x0, int32_t n_adapt, double uprate, double downrate, int32_t mode,
+                         void *workspace, int64_t workspace_bytes, uint64_t seed, uint64_t offset,
+                         int64_t chain_offset, hipStream_t st)
+{
+    if (n < 1 || thin < 1 || n_adapt < 0) return fail(BINF_E_ARG, "%s: need n>=1, thin>=1, n_adapt>=0", what);
+    if (int32_t rc = big_check(what, q0, p0, q_out, accepted, dt_chain, C, D, nsteps, n_adapt > 0,
+                               mode, workspace, workspace_bytes)) return rc;
+    if (C == 0) return 0;
+    if (workspace_bytes < binf_hmc_sample_n_gauss_big_workspace_bytes(C, D))
+        return fail(BINF_E_ARG, "%s: needs %lld bytes of workspace, got %lld", what,
+                    (long long)binf_hmc_sample_n_gauss_big_workspace_bytes(C, D), (long long)workspace_bytes);
+    const int64_t CD = C * D;
+    double *scratch = (double *)((char *)workspace + binf_hmc_sample_gauss_big_workspace_bytes(C, D));
+    // unrecorded transitions alternate between q_out and the scratch state so that
+    // the LAST unrecorded one of a run lands in q_out
+    int n_unrec = 0;
+    for (int s = 0; s < n; ++s)
+        if (!(samples && (s + 1) % thin == 0)) ++n_unrec;
+    int unrec_seen = 0;
+    const double *in = q0;
+    double *out = nullptr;
+    for (int s = 0; s < n; ++s) {
+        const bool rec = samples && (s + 1) % thin == 0;
+        if (rec) {
+            out = samples + (int64_t)((s + 1) / thin - 1) * CD;
+        } else {
+            // the k-th unrecorded transition from the end writes q_out iff k is odd
+            out = ((n_unrec - unrec_seen) & 1) ? q_out : scratch;
+            ++unrec_seen;
+        }
+        const int32_t rc = big_run<RNG>(
+            what, in, p0 ? p0 + (int64_t)s * CD : nullptr, u ? u + (int64_t)s * C : nullptr, out,
+            accepted + (int64_t)s * C, n_accepted, e_before ? e_before + (int64_t)s * C : nullptr,
+            e_after ? e_after + (int64_t)s * C : nullptr, timestep, dt_chain, C, D, nsteps, k, x0,
+            s < n_adapt ? 1 : 0, uprate, downrate, mode, workspace, seed, offset + (uint64_t)s,
+            chain_offset, nullptr, nullptr, st);
+        if (rc) return rc;
+        in = out;
+    }
+    if (out != q_out) {
+        const hipError_t e = hipMemcpyAsync(q_out, out, (size_t)CD * sizeof(double),
+                                            hipMemcpyDeviceToDevice, st);
+        if (e != hipSuccess) return hip_fail(e, "final state copy");
+    }
+    return 0;
+}
+
+extern "C" int32_t binf_hmc_sample_n_gauss_big_f64(
+    const double *q0, const double *p0, const double *u, double *q_out, double *samples,
+    uint8_t *accepted, int64_t *n_accepted, double *e_before, double *e_after, double timestep,
+    double *dt_chain, int64_t C, int64_t D, int32_t nsteps, int32_t n, int32_t thin, double k,
+    double x0, int32_t n_adapt, double uprate, double downrate, int32_t mode, void *workspace,
+    int64_t workspace_bytes, void *stream)
+{
+    const char *what = "hmc_sample_n_gauss_big";
+    if (C > 0 && D >= 1 && nsteps >= 1 && (!p0 || !u)) return fail(BINF_E_ARG, "%s: null buffer", what);
+    return big_run_n<BIG_RNG_HBM>(what, q0, p0, u, q_out, samples, accepted, n_accepted, e_before,
+                                  e_after, timestep, dt_chain, C, D, nsteps, n, thin, k, x0, n_adapt,
+                                  uprate, downrate, mode, workspace, workspace_bytes, 0, 0, 0,
+                                  (hipStream_t)stream);
+}
+
+extern "C" int32_t binf_hmc_sample_n_gauss_big_rng_f64(
+    const double *q0, double *q_out, double *samples, uint8_t *accepted, int64_t *n_accepted,
+    double *e_before, double *e_after, double timestep, double *dt_chain, int64_t C, int64_t D,
+    int32_t nsteps, int32_t n, int32_t thin, double k, double x0, int32_t n_adapt, double uprate,
+    double downrate, int32_t mode, uint64_t seed, uint64_t offset, int64_t chain_offset,
+    void *workspace, int64_t workspace_bytes, void *stream)
+{
+    const char *what = "hmc_sample_n_gauss_big_rng";
+    if (chain_offset < 0) return fail(BINF_E_ARG, "%s: chain_offset < 0", what);
+    return big_run_n<BIG_RNG_FUSED>(what, q0, nullptr, nullptr, q_out, samples, accepted, n_accepted,
+                                    e_before, e_after, timestep, dt_chain, C, D, nsteps, n, thin, k,
+                                    x0, n_adapt, uprate, downrate, mode, workspace, workspace_bytes,
+                                    seed, offset, chain_offset, (hipStream_t)stream);
+}

@@ -249,6 +249,8 @@ class HMCSampler(object):
                     not out.is_contiguous() or out.numel() != nrec * C * D:
                 raise ValueError('sample_n: out must be a contiguous fp64 [%d, %d, %d] '
                                  'tensor on %s' % (nrec, C, D, dev))
+        if not persist and spec is not None and spec[0] == 'gauss':
+            return self._sample_n_long(spec, n, thin, p0, u, record, out, q0, shape, nrec)
         if not persist:
             # no persistent kernel for this PDF / shape: n single calls (each draws for
             # itself when no draws were supplied)
@@ -369,6 +371,82 @@ class HMCSampler(object):
         self.counter += 1
         self.state = q_out.view(shape)
         return self.state
+
+    def _sample_n_long(self, spec, n, thin, p0, u, record, out, q0, shape, nrec):
+        """sample_n for chains beyond the persistent kernel's reach
+        (csrc/hmc_gauss_big.hip): n transitions from one call, every recorded
+        state written where it is kept; the draws are supplied, generated in the
+        kernels (a generator with lane streams: exactly the draws of n sample()
+        calls) or drawn a block of transitions at a time."""
+        _, k, x0 = spec
+        C, D = q0.shape
+        dev = q0.device
+        n_adapt = max(0, min(n, self.timestep_adaption_limit - 1 - self.counter))
+        if n_adapt > 0 and self._dt_chain is None:
+            self._dt_chain = torch.full((C,), float(self._timestep), dtype=torch.float64, device=dev)
+        if not isinstance(self.n_accepted, torch.Tensor):
+            self.n_accepted = torch.zeros(C, dtype=torch.int64, device=dev)
+        samples = None
+        if record and nrec > 0:
+            samples = out.view(nrec, C, D) if out is not None else \
+                torch.empty((nrec, C, D), dtype=torch.float64, device=dev)
+        accepted = torch.empty((n, C), dtype=torch.uint8, device=dev)
+        eb = ea = None
+        if self.record_energies:
+            eb = torch.empty((n, C), dtype=torch.float64, device=dev)
+            ea = torch.empty((n, C), dtype=torch.float64, device=dev)
+        q_out = torch.empty_like(q0)
+        args = (self._timestep, self._dt_chain, self.nsteps)
+        tail = (k, x0, n_adapt, self.adaption_uprate, self.adaption_downrate, _MODES[self.mode])
+        if p0 is None and u is None and self._fused_rng(self._variable_name, D, spec):
+            off = self.rng.offset
+            self.rng.offset += n                    # n sample() calls take n stream positions
+            _native.hmc_sample_n_gauss_big(q0, None, None, q_out, samples, accepted, self.n_accepted,
+                                           eb, ea, *args, n, thin, *tail,
+                                           rng=(self.rng.seed, off, self._chain_offset()))
+        elif p0 is not None and u is not None:
+            _native.hmc_sample_n_gauss_big(q0, p0.reshape(n, C, D).contiguous(),
+                                           u.reshape(n, C).contiguous(), q_out, samples, accepted,
+                                           self.n_accepted, eb, ea, *args, n, thin, *tail)
+        else:
+            # draws from the sampler's generator, a block of transitions at a time (<= 1 GiB
+            # of momenta), in the order n sample() calls consume it: normal, uniform, ...
+            block = max(1, min(n, (1 << 27) // max(1, C * D)))
+            if samples is not None:
+                block = max(thin, block // thin * thin)
+            done, cur = 0, q0
+            while done < n:
+                m = min(block, n - done)
+                dp = p0[done:done + m] if p0 is not None else \
+                    torch.empty((m, C, D), dtype=torch.float64, device=dev)
+                du = u[done:done + m] if u is not None else \
+                    torch.empty((m, C), dtype=torch.float64, device=dev)
+                for i in range(m):
+                    if p0 is None:
+                        _fill(self.rng, 'normal', dp[i])
+                    if u is None:
+                        _fill(self.rng, 'uniform', du[i])
+                nxt = torch.empty_like(q0)
+                r0, r1 = done // thin, (done + m) // thin
+                _native.hmc_sample_n_gauss_big(
+                    cur, dp.contiguous(), du.contiguous(), nxt,
+                    samples[r0:r1] if samples is not None and r1 > r0 else None,
+                    accepted[done:done + m], self.n_accepted,
+                    eb[done:done + m] if eb is not None else None,
+                    ea[done:done + m] if ea is not None else None, *args, m, thin, k, x0,
+                    max(0, min(m, n_adapt - done)), self.adaption_uprate, self.adaption_downrate,
+                    _MODES[self.mode])
+                cur = nxt
+                done += m
+            q_out = cur
+        self.last_e_before, self.last_e_after = eb, ea
+        self._last_move_accepted = accepted[-1].view(torch.bool)
+        self.accepted_history = accepted.view(torch.bool)
+        self.counter += n
+        self.state = q_out.view(shape)
+        if samples is None:
+            return None
+        return samples if len(shape) == 2 else samples.reshape((nrec,) + tuple(shape))
 
     def _sample_n_fused_rng(self, n):
         """sample() with in-kernel draws: one transition, the new state."""

@@ -163,6 +163,47 @@ int32_t binf_hmc_sample_gauss_big_f64(const double *q0, const double *p0,
                                       int32_t mode, void *workspace,
                                       int64_t workspace_bytes, void *stream);
 
+/* n consecutive long-chain transitions from one call: the loop
+ * `for i in range(n): sampler.sample()` (example_script.py:33-34) for chains of
+ * any length.  Transition s writes its proposal straight into its record slot
+ * samples[(s + 1) / thin - 1] (or into q_out / a scratch state when it is not
+ * recorded), rejected chains are restored from the state the transition read,
+ * and transition s + 1 reads what s wrote: 3 launches and 24 D bytes per chain
+ * and transition, recorded or not (a loop of single calls copies every recorded
+ * state once more).  BIT-IDENTICAL to n calls of binf_hmc_sample_gauss_big_f64
+ * (the same kernels).  p0 [n x C x D], u [n x C], accepted / e_before / e_after
+ * [n x C], samples [n / thin x C x D] or NULL; the first n_adapt transitions adapt
+ * dt_chain.  workspace: binf_hmc_sample_n_gauss_big_workspace_bytes(C, D) bytes
+ * (chunk sums + one [C x D] scratch state).  q_out holds the state after
+ * transition n.  The _rng form generates the draws in the kernels, transition s
+ * under (seed, offset + s): exactly the draws of n calls of
+ * binf_hmc_sample_gauss_big_rng_f64 with offsets offset, offset + 1, ...
+ * (No persistent kernel: the trajectory kernel moves its 24 D bytes as fast per
+ * byte as the persistent kernel of binf_hmc_sample_n_gauss_f64 moves its 16 D;
+ * chains longer than a workgroup's registers stream through HBM either way.) */
+int64_t binf_hmc_sample_n_gauss_big_workspace_bytes(int64_t C, int64_t D);
+int32_t binf_hmc_sample_n_gauss_big_f64(const double *q0, const double *p0,
+                                        const double *u, double *q_out, double *samples,
+                                        uint8_t *accepted, int64_t *n_accepted,
+                                        double *e_before, double *e_after,
+                                        double timestep, double *dt_chain, int64_t C,
+                                        int64_t D, int32_t nsteps, int32_t n,
+                                        int32_t thin, double k, double x0,
+                                        int32_t n_adapt, double uprate, double downrate,
+                                        int32_t mode, void *workspace,
+                                        int64_t workspace_bytes, void *stream);
+int32_t binf_hmc_sample_n_gauss_big_rng_f64(const double *q0, double *q_out,
+                                            double *samples, uint8_t *accepted,
+                                            int64_t *n_accepted, double *e_before,
+                                            double *e_after, double timestep,
+                                            double *dt_chain, int64_t C, int64_t D,
+                                            int32_t nsteps, int32_t n, int32_t thin,
+                                            double k, double x0, int32_t n_adapt,
+                                            double uprate, double downrate, int32_t mode,
+                                            uint64_t seed, uint64_t offset,
+                                            int64_t chain_offset, void *workspace,
+                                            int64_t workspace_bytes, void *stream);
+
 /* The long-chain transition with its draws generated inside the kernels (one
  * xoshiro128++ stream per lane and (chain, 8192-chunk) for the momentum, one per
  * chain for the acceptance draw; keyed by (seed, offset), a caller advances

@@ -31,3 +31,31 @@ for name, rng in (('supplied', None), ('device_rng', DeviceRNG(0, dev))):
     del s, q0, p0
     torch.cuda.empty_cache()
 print(json.dumps(out))
+
+# n transitions from one call (binf_hmc_sample_n_gauss_big_*), every state recorded,
+# against the loop of sample() calls + stacking the states
+n = 8
+for name, mk in (('loop_of_sample_calls', False), ('one_call_sample_n', True)):
+    q0 = torch.randn((C, D), dtype=torch.float64, device=dev)
+    s = HMCSampler(IsotropicGaussian(), q0, 0.01, L, variable_name='x', rng=DeviceRNG(0, dev))
+    buf = torch.empty((n, C, D), dtype=torch.float64, device=dev)
+
+    def run():
+        if mk:
+            s.sample_n(n, out=buf)
+        else:
+            for i in range(n):
+                buf[i].copy_(s.sample())
+    run()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    t = e0.elapsed_time(e1) * 1e-3 / (5 * n)
+    out[name] = {'ms_per_recorded_transition': t * 1e3, 'algorithmic_TBps': (24.0 * D + 25) * C / t / 1e12}
+    del s, q0, buf
+    torch.cuda.empty_cache()
+print(json.dumps(out))

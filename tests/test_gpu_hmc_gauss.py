@@ -10,6 +10,7 @@ import torch
 from binf_amd import _native
 from binf_amd.pdf import IsotropicGaussian
 from binf_amd.samplers.hmc import HMCSampler
+from binf_amd.samplers.rng import DeviceRNG
 from conftest import golden_files, load_golden
 from oracle import c_oracle
 from oracle import ref_numpy as R
@@ -734,3 +735,78 @@ def test_private_helpers_of_the_reference_surface(device):
     s._adapt_timestep()
     want = np.where(acc, 0.3 * 1.05, 0.3 * 0.95)
     assert np.array_equal(s.timestep.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize('D,C,n,thin,adapt', [(8193, 3, 5, 2, False), (16384, 2, 4, 2, True),
+                                              (20000, 2, 3, 1, False), (40000, 1, 4, 3, True),
+                                              (12000, 5, 6, 4, False)])
+def test_long_chains_sample_n_one_call_vs_oracle_and_single_calls(device, D, C, n, thin, adapt):
+    """binf_hmc_sample_n_gauss_big_f64 (n long-chain transitions from one call, every
+    recorded state written where it is kept) against the C restatement, transition
+    by transition, and against n single sample() calls: states, flags, energies,
+    adapted step sizes bit for bit; q_out ends up right whether the last transition
+    is recorded or not."""
+    assert not fused_covers(D)
+    L, dt = 3, 0.02
+    rs = np.random.RandomState(D + n)
+    q0 = rs.standard_normal((C, D))
+    p0 = rs.standard_normal((n, C, D))
+    u = rs.uniform(size=(n, C))
+    if adapt:
+        u[0, ::2] = 0.999999
+        p0[0, ::2] *= 3.0
+    lim = 4 if adapt else 0
+    a = HMCSampler(IsotropicGaussian(), dev_t(q0, device), dt, L, variable_name='x',
+                   timestep_adaption_limit=lim, record_energies=True)
+    rec = a.sample_n(n, thin=thin, p0=dev_t(p0, device), u=dev_t(u, device))
+    b = HMCSampler(IsotropicGaussian(), dev_t(q0, device), dt, L, variable_name='x',
+                   timestep_adaption_limit=lim, record_energies=True)
+    dts = np.full(C, dt)
+    q = q0
+    for i in range(n):
+        want = c_oracle.hmc_sample_gauss(q, p0[i], u[i], dts if adapt else dt, L, nthreads=4)
+        x = b.sample(p0=dev_t(p0[i], device), u=dev_t(u[i], device))
+        assert np.array_equal(x.cpu().numpy(), want['q_out']), i
+        if (i + 1) % thin == 0:
+            assert torch.equal(rec[(i + 1) // thin - 1], x), i
+        assert np.array_equal(a.accepted_history[i].cpu().numpy(), want['accepted'].astype(bool)), i
+        assert np.array_equal(a.last_e_before[i].cpu().numpy(), want['e_before']), i
+        assert np.array_equal(a.last_e_after[i].cpu().numpy(), want['e_after']), i
+        if adapt and i + 1 < lim:
+            dts = np.where(want['accepted'].astype(bool), dts * 1.05, dts * 0.95)
+        q = want['q_out']
+    assert rec.shape == (n // thin, C, D)
+    assert torch.equal(a.state, b.state) and a.counter == b.counter == n
+    assert torch.equal(a.n_accepted, b.n_accepted)
+    if adapt:
+        assert np.array_equal(a.timestep.cpu().numpy(), dts) and torch.equal(a.timestep, b.timestep)
+    # nothing recorded: the state still arrives
+    c = HMCSampler(IsotropicGaussian(), dev_t(q0, device), dt, L, variable_name='x',
+                   timestep_adaption_limit=lim)
+    assert c.sample_n(n, p0=dev_t(p0, device), u=dev_t(u, device), record=False) is None
+    assert torch.equal(c.state, b.state)
+    # into a caller's record buffer
+    buf = torch.empty((n // thin, C, D), dtype=torch.float64, device=device)
+    d = HMCSampler(IsotropicGaussian(), dev_t(q0, device), dt, L, variable_name='x',
+                   timestep_adaption_limit=lim)
+    r2 = d.sample_n(n, thin=thin, p0=dev_t(p0, device), u=dev_t(u, device), out=buf)
+    assert r2.data_ptr() == buf.data_ptr() and torch.equal(buf, rec)
+
+
+@pytest.mark.parametrize('fused', [True, False])
+def test_long_chains_sample_n_draws_what_n_sample_calls_draw(device, fused):
+    """With a device generator the one-call loop takes the stream positions n
+    sample() calls take: lane streams in the kernels (fused) or the stand-alone
+    Philox fills a block of transitions at a time -- identical chains either way."""
+    D, C, n, L = 9000, 3, 5, 2
+    q0 = np.random.RandomState(3).standard_normal((C, D))
+    a = HMCSampler(IsotropicGaussian(2.0, 0.1), dev_t(q0, device), 0.01, L, variable_name='x',
+                   rng=DeviceRNG(11, device, fused=fused), record_energies=True)
+    b = HMCSampler(IsotropicGaussian(2.0, 0.1), dev_t(q0, device), 0.01, L, variable_name='x',
+                   rng=DeviceRNG(11, device, fused=fused), record_energies=True)
+    rec = a.sample_n(n, thin=2)
+    xs = [b.sample().clone() for _ in range(n)]
+    assert torch.equal(rec[0], xs[1]) and torch.equal(rec[1], xs[3])
+    assert torch.equal(a.state, xs[-1]) and a.rng.offset == b.rng.offset
+    assert torch.equal(a.last_e_after[-1], b.last_e_after)
+    assert bool(a.accepted_history.any())
