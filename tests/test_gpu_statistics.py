@@ -132,3 +132,45 @@ def test_example_custom_pdf_samples_both_wells(device):
     assert 0.5 < float(s.acceptance_rate.mean()) <= 1.0
     assert abs(float((x > 0).double().mean()) - 0.5) < 0.02
     assert 0.8 < float(x.abs().mean()) < 1.1
+
+
+def test_gibbs_launches_with_two_different_moves_agree_on_the_posterior(device):
+    """The multi-sweep Gibbs launch (csrc/gibbs_poly.hip) with its two coefficient
+    moves -- HMC and the reference's random walk -- shares only the energy code:
+    trajectories, proposals, accept rules (clipped exp vs np.exp) and draw streams
+    differ.  Both must sample the SAME joint posterior of the example; and given the
+    sampled coefficients, the precision draws must follow their conjugate Gamma
+    (mean = shape / rate), which does not involve either move."""
+    from binf_amd.example.misc import make_posterior
+    from binf_amd.example.samplers import make_hmc_sampler, make_sampler
+    from binf_amd.samplers import BinfState
+    np.random.seed(0)
+    xs = np.linspace(-2, 2, 20)
+    ys = np.random.normal(loc=POLYVAL(xs, np.array([2.0, -4.0, 1.0, 1.5])), scale=1.0 / np.sqrt(2.5))
+    C = 1024
+
+    def start():
+        return BinfState(dict(coefficients=torch.ones((C, 4), dtype=torch.float64, device=device),
+                              precision=torch.ones(C, dtype=torch.float64, device=device)))
+    hmc = make_hmc_sampler(make_posterior(xs, ys, POLYVAL), 0.02, 50, start(), rng=DeviceRNG(1, device))
+    rw = make_sampler(make_posterior(xs, ys, POLYVAL), 0.1, start(), rng=DeviceRNG(2, device))
+    hmc.sample_n(300, record=False)                    # burn-in
+    rw.sample_n(30000, record=False)
+    a = hmc.sample_n(400, thin=20)                     # 20 kept sweeps x 1024 chains
+    b = rw.sample_n(40000, thin=2000)
+    for key in ('coefficients', 'precision'):
+        xa = a[key].reshape(-1, a[key].shape[-1] if key == 'coefficients' else 1).cpu().numpy()
+        xb = b[key].reshape(-1, xa.shape[1]).cpu().numpy()
+        # chains are independent; kept sweeps of a chain are nearly so: use C as the
+        # effective sample size of each mean (conservative)
+        se = np.sqrt(xa.var(axis=0) / C + xb.var(axis=0) / C)
+        assert np.all(np.abs(xa.mean(axis=0) - xb.mean(axis=0)) < 6 * se), (key, xa.mean(0), xb.mean(0), se)
+        assert np.all(np.abs(np.log(xa.std(axis=0) / xb.std(axis=0))) < 0.15), key
+    # conjugate identity, per kept state of the HMC run: tau ~ Gamma(shape, rate(theta)) with
+    # shape = 0.5 n + alpha - 1 = 10, rate = 0.5 chi^2(theta) + 1 (the conditional's rate, Q6)
+    th = a['coefficients'].reshape(-1, 4).cpu().numpy()
+    tau = a['precision'].reshape(-1).cpu().numpy()
+    rate = 0.5 * np.sum((POLYVAL(xs, th.T) - ys[None, :]) ** 2, axis=1) + 1.0
+    z = tau * rate                                     # ~ Gamma(10, 1): mean 10, variance 10
+    assert abs(z.mean() - 10.0) < 6 * np.sqrt(10.0 / len(z))
+    assert abs(z.var() - 10.0) < 6 * 10.0 * np.sqrt(2.0 / len(z) + 0.6 / len(z))
