@@ -538,7 +538,7 @@ class GibbsPolyArgs(ctypes.Structure):
         [(n, _u64) for n in ('seed_m', 'off_m', 'stride_m', 'seed_u', 'off_u', 'stride_u',
                              'seed_g', 'off_g', 'stride_g')] + \
         [(n, _i32) for n in ('move', 'mode', 'nsteps', 'n', 'thin', 'n_adapt', 'prior_first',
-                             'gp_where', 'zig', 'reserved')]
+                             'gp_where', 'zig', 'keep_precision')]
 
 
 @_launcher
@@ -549,7 +549,7 @@ def gibbs_poly_sample_n(coefficients, precision, coefficients_out, precision_out
                         gp_shape=1.0, gp_rate=0.0, gamma_shape=1.0, gamma_rate=0.0,
                         rec_coefficients=None, rec_precision=None, accepted=None,
                         n_accepted=None, e_before=None, e_after=None, p0=None, u=None, g=None,
-                        streams=None, chain_offset=0, zig=True):
+                        streams=None, chain_offset=0, zig=True, keep_precision=False):
     """binf_gibbs_poly_sample_n_f64 on torch's current stream: n sweeps of the
     example's Gibbs loop in one launch.  ``streams`` = ``((seed, offset, stride),) * 3``
     for the momentum / proposal, acceptance and gamma draws that are not supplied."""
@@ -589,6 +589,7 @@ def gibbs_poly_sample_n(coefficients, precision, coefficients_out, precision_out
     a.move, a.mode, a.nsteps, a.n, a.thin = int(move), int(mode), int(nsteps), n, thin
     a.n_adapt, a.prior_first, a.gp_where = int(n_adapt), int(bool(prior_first)), int(gp_where)
     a.zig = int(bool(zig))
+    a.keep_precision = int(bool(keep_precision))
     rc = lib().binf_gibbs_poly_sample_n_f64(ctypes.byref(a), stream_handle(coefficients.device))
     check(rc, 'binf_gibbs_poly_sample_n_f64')
 

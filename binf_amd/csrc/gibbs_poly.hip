@@ -50,9 +50,9 @@ extern "C" int32_t binf_gibbs_poly_sample_n_f64(const binf_gibbs_poly_args *g, v
         return fail(BINF_E_ARG, "gibbs_poly: nsteps >= 1 required");
     if (g->gp_where < 0 || g->gp_where > 2)
         return fail(BINF_E_ARG, "gibbs_poly: gp_where must be 0, 1 or 2");
-    if (!(g->gamma_shape > 0.0))
+    if (!g->keep_precision && !(g->gamma_shape > 0.0))
         return fail(BINF_E_ARG, "gibbs_poly: gamma_shape must be > 0");
-    if (!g->g && g->gamma_shape < 1.0)
+    if (!g->keep_precision && !g->g && g->gamma_shape < 1.0)
         return fail(BINF_E_UNSUPPORTED, "gibbs_poly: generated gamma variates need gamma_shape >= 1 (got %g): supply g or sweep one at a time", g->gamma_shape);
     if (K > 16 || N > 1024 || pairwise_tree_height(N) > 3)
         return fail(BINF_E_UNSUPPORTED, "gibbs_poly: K=%lld > 16 or n_data=%lld > 1024 (or a pairwise tree deeper than 3) not covered (sweep with the per-step tier)", (long long)K, (long long)N);
@@ -92,6 +92,7 @@ extern "C" int32_t binf_gibbs_poly_sample_n_f64(const binf_gibbs_poly_args *g, v
     a.nsteps = g->nsteps; a.n = g->n; a.thin = g->thin;
     a.n_adapt = g->move == BINF_MOVE_HMC ? g->n_adapt : 0;
     a.prior_first = g->prior_first ? 1 : 0; a.gp_where = g->gp_where; a.zig = g->zig ? 1 : 0;
+    a.keep_tau = g->keep_precision ? 1 : 0;
     const bool fma = g->mode == BINF_MODE_FMA;
     hipStream_t st = (hipStream_t)stream;
     hipError_t e;

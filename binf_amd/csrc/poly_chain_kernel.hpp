@@ -87,6 +87,7 @@ struct PolyChainArgs {
     int32_t prior_first;       // the Gaussian prior term precedes the likelihood term
     int32_t gp_where;          // GIBBS: 0 no GammaPrior term, 1 before the theta terms, 2 after
     int32_t zig;               // generated momenta: 1 ziggurat, 0 Box-Muller (rng.hip streams)
+    int32_t keep_tau;          // GIBBS: no precision draw (n moves under a fixed precision)
 };
 
 constexpr int POLY_MOVE_HMC = 0;
@@ -438,7 +439,7 @@ __global__ void __launch_bounds__(256) poly_chain_kernel(const PolyChainArgs a)
             dt = acc ? dt * a.uprate : dt * a.downrate;                   // hmc.py:188-191
 
         // ---- the conjugate draw of the precision (samplers.py:27-51) -----------------------
-        if (GIBBS) {
+        if (GIBBS && !a.keep_tau) {
             // likelihood.log_prob(coefficients, precision=1.0): the chi^2 epilogue of
             // rowsum.hpp at tau = 1
             const double lp1 = -0.5 * chi2 * 1.0 + (double)N * 0.5 * log(1.0);

@@ -251,6 +251,17 @@ class HMCSampler(object):
                                  'tensor on %s' % (nrec, C, D, dev))
         if not persist and spec is not None and spec[0] == 'gauss':
             return self._sample_n_long(spec, n, thin, p0, u, record, out, q0, shape, nrec)
+        if spec is not None and spec[0] == 'poly' and self.fused_polynomial != 'lane' and \
+                self._fused_spec(name, D, C) is not None:
+            # the example's coefficient conditional: n transitions in one launch
+            from binf_amd.example import native_poly
+            handled, res = native_poly.hmc_sample_n(self, spec, n, thin, p0, u, record, out, q0)
+            if handled:
+                q_out, samples = res
+                self.state = q_out.view(shape)
+                if samples is None:
+                    return None
+                return samples if state.dim() == 2 else samples.reshape((nrec,) + tuple(shape))
         if not persist:
             # no persistent kernel for this PDF / shape: n single calls (each draws for
             # itself when no draws were supplied)

@@ -569,7 +569,10 @@ typedef struct binf_gibbs_poly_args {
     int32_t prior_first;
     int32_t gp_where;             /* 0 / 1 / 2, see above                            */
     int32_t zig;                  /* generated momenta: ziggurat (1) or Box-Muller (0) */
-    int32_t reserved;
+    int32_t keep_precision;       /* != 0: no precision draw -- n moves of the coefficients
+                                     alone under a FIXED precision: n HMCSampler.sample()
+                                     calls on the conditional posterior (g and the gamma
+                                     arguments are ignored)                              */
 } binf_gibbs_poly_args;
 int32_t binf_gibbs_poly_sample_n_f64(const binf_gibbs_poly_args *args, void *stream);
 

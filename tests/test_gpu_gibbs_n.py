@@ -308,3 +308,50 @@ def test_entry_point_argument_checks(device):
     _native.gibbs_poly_sample_n(e, e[:, 0].contiguous(), e.clone(), e[:, 0].contiguous(),
                                 xs_d, ys_d, 2, **base)
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize('K,N,C,source,per_chain_tau', [
+    (4, 20, 37, 'device', True), (7, 300, 9, 'device', False), (16, 128, 5, 'supplied', True),
+    (4, 20, 3, 'host', False), (3, 1000, 4, 'device', True)])
+def test_hmc_sample_n_on_the_coefficient_conditional_is_n_sample_calls(device, K, N, C, source,
+                                                                       per_chain_tau):
+    """HMCSampler.sample_n on the example's conditional posterior of the coefficients
+    (precision fixed): the multi-sweep launch with its precision draw switched off,
+    bit for bit n sample() calls -- states, flags, energies, adapted step sizes,
+    generator positions."""
+    from binf_amd.samplers.hmc import HMCSampler
+    n, thin, L = 7, 3, 5
+    xs, ys, c_true = model(K, N, 21)
+    rs = np.random.RandomState(K + N)
+    tau = dev_t(1.0 + rs.uniform(size=C), device) if per_chain_tau else 2.5
+    cond = posterior(xs, ys, K).conditional_factory(precision=tau)
+    theta = dev_t(c_true + 0.2 * rs.standard_normal((C, K)), device)
+    dt = 0.02 / (K * np.sqrt(N / 20.0))
+    p0 = dev_t(rs.standard_normal((n, C, K)), device)
+    u = dev_t(rs.uniform(size=(n, C)), device)
+
+    def mk():
+        rng = DeviceRNG(4, device) if source == 'device' else HostLegacyRNG()
+        return HMCSampler(cond, theta.clone(), dt, L, variable_name='coefficients', rng=rng,
+                          timestep_adaption_limit=5, record_energies=True)
+    a, b = mk(), mk()
+    np.random.seed(5)
+    xs_loop = [a.sample(p0=p0[i], u=u[i]) if source == 'supplied' else a.sample() for i in range(n)]
+    flags = torch.stack([a_.clone() for a_ in [a.last_move_accepted]])
+    np.random.seed(5)
+    rec = b.sample_n(n, thin=thin, **(dict(p0=p0, u=u) if source == 'supplied' else {}))
+    assert rec.shape == (n // thin, C, K)
+    assert torch.equal(rec[0], xs_loop[thin - 1]) and torch.equal(rec[1], xs_loop[2 * thin - 1])
+    assert torch.equal(b.state, xs_loop[-1]) and b.counter == a.counter == n
+    assert torch.equal(b.n_accepted, a.n_accepted)
+    assert torch.equal(b.last_move_accepted, flags[0])
+    assert torch.equal(b.timestep, a.timestep)
+    assert torch.equal(b.last_e_after[-1], a.last_e_after)
+    if source == 'device':
+        assert a.rng.offset == b.rng.offset == 2 * n
+    # ... and they stay in step
+    if source != 'supplied':
+        np.random.seed(6)
+        x = a.sample()
+        np.random.seed(6)
+        assert torch.equal(x, b.sample())
