@@ -15,14 +15,14 @@ from binf_amd.pdf import IsotropicGaussian
 from binf_amd.pdf.posteriors import Posterior
 from binf_amd.samplers.hmc import HMCSampler
 from binf_amd.samplers.rng import DeviceRNG
-from oracle import ref_distance as RD
 
 dev = torch.device('cuda:0')
 n, L = 256, 20
 C = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 rs = np.random.RandomState(0)
 truth = rs.standard_normal((n, 3)) * 2.0
-ys = np.abs(RD.forward(truth.reshape(-1), n) + 0.05 * rs.standard_normal(n * (n - 1) // 2))
+I_, J_ = np.triu_indices(n, 1)
+ys = np.abs(np.sqrt(np.sum((truth[I_] - truth[J_]) ** 2, axis=1)) + 0.05 * rs.standard_normal(n * (n - 1) // 2))
 x = torch.from_numpy(truth.reshape(-1)[None, :] + 0.1 * rs.standard_normal((C, 3 * n))).to(dev)
 lik = make_distance_likelihood(ys, n)
 prior = IsotropicGaussian(0.05, 0.0, name='coordinates_prior', variable_name='coordinates')
