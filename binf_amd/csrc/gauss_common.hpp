@@ -30,6 +30,7 @@ struct GaussNArgs {
     int32_t thin;            // record every thin-th state (>= 1)
     int32_t n_adapt;         // the first n_adapt transitions adapt the timestep
     int32_t stagger;         // start delay per SIMD wave slot, units of ~64 cycles (0 = none)
+    int32_t force_lds_stash; // development aid (BINF_GAUSS_STASH=lds): always stash the state in LDS
     // draws generated in the kernel (hmc_gauss_rng.hip)
     uint64_t rng_seed;
     uint64_t rng_offset;
@@ -76,6 +77,7 @@ inline GaussPlan gauss_plan(int64_t C, int64_t D)
 // hmc_gauss_split.hip: few chains of D in {768, 1024} spread over 2 / 4 waves each
 int gauss_split_factor(int64_t C, int32_t H, bool regular, int tneed);
 int gauss_stagger(int n);
+int gauss_force_lds_stash();
 hipError_t launch_gauss_split(const GaussNArgs &a, int tneed, int split, bool unit, bool fma,
                               hipStream_t st);
 

@@ -74,6 +74,18 @@ int gauss_stagger(int n)
     return 0;
 }
 
+// development aid: BINF_GAUSS_STASH=lds keeps the per-transition LDS stash even when every
+// state is recorded (A/B of the read-back-from-the-record restore)
+int gauss_force_lds_stash()
+{
+    static int forced = -1;
+    if (forced < 0) {
+        const char *e = getenv("BINF_GAUSS_STASH");
+        forced = (e && e[0] == 'l') ? 1 : 0;
+    }
+    return forced;
+}
+
 }  // namespace binf
 
 using namespace binf;
@@ -117,6 +129,7 @@ extern "C" int32_t binf_hmc_sample_n_gauss_f64(
     a.D = (int32_t)D; a.nsteps = nsteps; a.H = H; a.n = n; a.thin = thin;
     a.n_adapt = n_adapt < n ? n_adapt : n;
     a.stagger = gauss_stagger(n);
+    a.force_lds_stash = gauss_force_lds_stash();
     a.rng_seed = 0; a.rng_offset = 0; a.chain_offset = 0; a.p_dump = nullptr; a.u_dump = nullptr;
 
     const int64_t blocks = plan.blocks;

@@ -130,10 +130,17 @@ hmc_gauss_persist_kernel(const GaussNArgs a)
     double Sq_state = 0.0;
     int64_t nacc = 0;
 
+    // Where a rejected chain gets its old state back from.  When EVERY state is recorded
+    // (thin == 1) the state before transition s is what this very lane wrote to the
+    // record of transition s - 1 (q0 for s = 0): it is read back from there on the rare
+    // rejection, and the per-transition copy of the state to LDS (16 ds_write_b64 per lane)
+    // is not made at all.  Regular trees only (every lane owns what it reads back).
+    const bool stash_lds = !(REGULAR && a.samples && a.thin == 1 && !a.force_lds_stash);
+
     for (int s = 0; s < a.n; ++s) {
         const double hdt = 0.5 * dt;
         // state before the transition -> LDS (read back only on rejection)
-        if (RNG != GAUSS_RNG_DUMP) {
+        if (RNG != GAUSS_RNG_DUMP && stash_lds) {
 #pragma unroll
             for (int t = 0; t < TMAX; ++t) stash[wib][t][lane] = q[t];
         }
@@ -281,9 +288,14 @@ hmc_gauss_persist_kernel(const GaussNArgs a)
         if (acc) {
             Sq_state = Sqa;
             nacc += 1;
-        } else {
+        } else if (stash_lds) {
 #pragma unroll
             for (int t = 0; t < TMAX; ++t) q[t] = stash[wib][t][lane];
+        } else {
+            const double *prev = (s == 0) ? a.q0 + base
+                                          : a.samples + (int64_t)(s - 1) * CD + base;
+#pragma unroll
+            for (int t = 0; t < TMAX; ++t) q[t] = prev[8 * t];
         }
         if (a.samples && (s + 1) % a.thin == 0 && cvalid && canonical) {
             double *go = a.samples + (int64_t)((s + 1) / a.thin - 1) * CD + base;

@@ -83,6 +83,7 @@ extern "C" int32_t binf_hmc_sample_n_gauss_rng_f64(
     a.D = (int32_t)D; a.nsteps = nsteps; a.H = p.H; a.n = n; a.thin = thin;
     a.n_adapt = n_adapt < n ? n_adapt : n;
     a.stagger = 0;
+    a.force_lds_stash = gauss_force_lds_stash();
     a.rng_seed = seed; a.rng_offset = offset; a.chain_offset = chain_offset;
     a.p_dump = nullptr; a.u_dump = nullptr;
     const hipError_t e = launch_rng<GAUSS_RNG_FUSED>(a, p, k == 1.0 && x0 == 0.0,
