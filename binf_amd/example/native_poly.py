@@ -111,6 +111,12 @@ def _device_rng_of(obj):
     return obj if type(obj) is DeviceRNG else None
 
 
+def _same_data(a, b):
+    """Clones of a model share their device copies: identity settles it without a
+    comparison on the device (and the synchronisation that would cost every sweep)."""
+    return a is b or (a.shape == b.shape and torch.equal(a, b))
+
+
 def gibbs_sample_n(gibbs, n, thin, record):
     """``n`` sweeps of ``gibbs`` in ONE launch of ``binf_gibbs_poly_sample_n_f64``
     if it is the example's scheme -- variables ``coefficients`` (an
@@ -167,8 +173,8 @@ def gibbs_sample_n(gibbs, n, thin, record):
         return False, None
     if getattr(fwm_p, 'native_spec', lambda: None)() is None or \
             getattr(em_p, 'native_spec', lambda: None)() is None or \
-            not torch.equal(em_p.ys_device(dev), em.ys_device(dev)) or \
-            not torch.equal(fwm_p.xs_device(dev), fwm.xs_device(dev)):
+            not _same_data(em_p.ys_device(dev), em.ys_device(dev)) or \
+            not _same_data(fwm_p.xs_device(dev), fwm.xs_device(dev)):
         return False, None
     gamma_shape = float(ps._calculate_shape())
 

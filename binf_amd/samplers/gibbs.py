@@ -77,8 +77,19 @@ class GibbsSampler(object):
     def _update_state(self, **variables):
         self._state.update_variables(**variables)
 
+    # One sweep of the example's scheme as ONE launch (the multi-sweep kernel with n = 1,
+    # bit-identical to the per-variable loop below; ~8 launches otherwise).  False: always
+    # the per-variable loop (the tests hold the fused launch to it).
+    fused_sweep = True
+
     def sample(self):
         self._update_subsampler_states()          # "needed for RE", :144
+        if self.fused_sweep:
+            self._update_conditional_pdf_params()
+            from binf_amd.example import native_poly
+            if native_poly.gibbs_sample_n(self, 1, 1, False)[0]:
+                self._update_conditional_pdf_params()
+                return self._state
         for var in sorted(list(self._pdf.variables)):
             self._update_conditional_pdf_params()
             new = self._subsamplers[var].sample()

@@ -53,18 +53,23 @@ def main():
     lines = []
     for move in ('hmc', 'rwmc'):
         for C in a.chains:
-            g1, g2 = build(C, move, dev), build(C, move, dev)
+            g1, g2, g3 = build(C, move, dev), build(C, move, dev), build(C, move, dev)
+            g1.fused_sweep = False               # subsampler by subsampler (~8 launches per sweep)
             # same sweeps either way
             for _ in range(8):
                 g1.sample()
+                g3.sample()                      # the sweep as one launch
             g2.sample_n(8, record=False)
-            same = torch.equal(g1.state.variables['coefficients'], g2.state.variables['coefficients']) \
+            same = torch.equal(g1.state.variables['coefficients'], g3.state.variables['coefficients'])
+            same = same and torch.equal(g1.state.variables['coefficients'], g2.state.variables['coefficients']) \
                 and torch.equal(g1.state.variables['precision'], g2.state.variables['precision'])
             t_loop = timed(lambda: [g1.sample() for _ in range(100)], 3) / 100
+            t_one = timed(lambda: [g3.sample() for _ in range(100)], 3) / 100
             t_n = timed(lambda: g2.sample_n(a.n, thin=20), 3) / a.n
             L = 50 if move == 'hmc' else 0
             line = dict(move=move, chains=C, sweeps_per_launch=a.n, identical_states=bool(same),
-                        loop_us_per_sweep=t_loop * 1e6, launch_us_per_sweep=t_n * 1e6,
+                        loop_us_per_sweep=t_loop * 1e6, one_launch_per_sweep_us=t_one * 1e6,
+                        launch_us_per_sweep=t_n * 1e6,
                         speedup=t_loop / t_n,
                         chain_leapfrog_steps_per_s=(C * L / t_n) if L else None,
                         chain_sweeps_per_s=C / t_n)

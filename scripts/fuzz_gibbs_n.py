@@ -82,6 +82,7 @@ for case in range(n_cases):
     a = build(move, K, N, C, seed, DeviceRNG(seed % 1000, dev), L, dt, start, **kw)
     b = build(move, K, N, C, seed, DeviceRNG(seed % 1000, dev), L, dt, start, **kw)
     cs, ts = [], []
+    a.fused_sweep = False                       # the per-variable sweep, kernel by kernel
     for _ in range(n):
         s = a.sample()
         cs.append(s.variables['coefficients'].clone())

@@ -67,6 +67,9 @@ def build(device, move, K, N, C, seed, rng, dt=None, L=7, start=None, **kw):
 
 
 def run_loop(gips, n):
+    # the per-variable sweep of gibbs.py:136-151 (subsampler by subsampler: the separate
+    # transition, chi^2, generator and update kernels), NOT the one-launch sweep
+    gips.fused_sweep = False
     cs, ts, fl = [], [], []
     for _ in range(n):
         s = gips.sample()
@@ -108,9 +111,11 @@ def test_sample_n_is_n_sweeps_bit_for_bit_with_device_draws(device, move, K, N, 
         assert sb.rng.offset == sa.rng.offset
     # something moved, and the two loops stay in step afterwards
     assert 0 < int(fl.sum()) or move == 'rwmc'
-    x, y = a.sample(), b.sample()
+    x, y = a.sample(), b.sample()            # per-variable sweep vs the sweep as one launch
+    assert a.fused_sweep is False and b.fused_sweep is True
     assert torch.equal(x.variables['coefficients'], y.variables['coefficients'])
     assert torch.equal(x.variables['precision'], y.variables['precision'])
+    assert sa.rng.offset == sb.rng.offset
 
 
 @pytest.mark.parametrize('mode', ['exact', 'fma'])
