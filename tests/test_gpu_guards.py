@@ -241,3 +241,102 @@ def test_in_kernel_generator_stays_inside_its_buffers(device, D, C, n):
     assert not (pd == 77.0).any() and not (ud == 77.0).any()      # every draw written
     assert np.isfinite(pd).all() and (0.0 <= ud).all() and (ud < 1.0).all()
     assert np.isfinite(outs[0][3]).all()
+
+
+# ---------------------------------------------------------------------------
+# round 3 entry points
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize('K,N,C,n,thin,move', [(4, 20, 1, 3, 1, 'hmc'), (7, 37, 9, 5, 2, 'hmc'),
+                                               (16, 128, 33, 2, 1, 'rwmc'), (3, 300, 5, 4, 3, 'hmc'),
+                                               (1, 1000, 3, 2, 1, 'rwmc'), (15, 920, 2, 2, 2, 'hmc')])
+def test_multi_sweep_gibbs_launch_stays_inside_its_buffers(device, K, N, C, n, thin, move):
+    rs = np.random.RandomState(K * N + C)
+    xs, ys = np.linspace(-1, 1, N), rs.standard_normal(N)
+    th0, tau0 = rs.standard_normal((C, K)), 1.0 + rs.uniform(size=C)
+    p0 = rs.standard_normal((n, C, K)) * (1.0 if move == 'hmc' else 0.05)
+    u, g = rs.uniform(size=(n, C)), 8.0 + rs.uniform(size=(n, C))
+    nrec = n // thin
+    outs = []
+    for supplied in (True, False):
+        for make in (Guarded(device), None):
+            t = make if make is not None else (lambda a, dtype=torch.float64: plain(a, device, dtype))
+            o = dict(th=t(np.zeros((C, K))), tau=t(np.zeros(C)), rc=t(np.zeros((nrec, C, K))),
+                     rt=t(np.zeros((nrec, C))), acc=t(np.zeros((n, C), dtype=np.uint8), torch.uint8),
+                     nacc=t(np.zeros(C, dtype=np.int64), torch.int64), eb=t(np.zeros((n, C))),
+                     ea=t(np.zeros((n, C))), dtc=t(np.full(C, 1e-3)))
+            _native.gibbs_poly_sample_n(
+                t(th0), t(tau0), o['th'], o['tau'], t(xs), t(ys), n, thin,
+                move=_native.MOVE_HMC if move == 'hmc' else _native.MOVE_RWMC, nsteps=3,
+                dt_chain=o['dtc'], n_adapt=1 if move == 'hmc' else 0, stepsize=0.05,
+                prior_means=t(np.zeros(K)), prior_vars=t(np.full(K, 5.0)), prior_first=True,
+                gp_where=2, gp_shape=1.0, gp_rate=1.0, gamma_shape=0.5 * N + 1.0, gamma_rate=1.0,
+                rec_coefficients=o['rc'] if nrec else None, rec_precision=o['rt'] if nrec else None,
+                accepted=o['acc'], n_accepted=o['nacc'], e_before=o['eb'], e_after=o['ea'],
+                p0=t(p0) if supplied else None, u=t(u) if supplied else None,
+                g=t(g) if supplied else None, streams=((3, 0, 130), (3, 1, 130), (3, 2, 130)),
+                chain_offset=5)
+            if make is not None:
+                make.check()
+            outs.append([o[k].clone() for k in ('th', 'tau', 'rc', 'rt', 'acc', 'nacc', 'dtc')])
+        for a, b in zip(outs[-2], outs[-1]):
+            assert torch.equal(a, b) and (a.dtype != torch.float64 or bool(torch.isfinite(a).all()))
+
+
+@pytest.mark.parametrize('K,N,C,batched', [(1, 1, 1, False), (17, 65, 17, False), (33, 1000, 20, True),
+                                           (65, 129, 3, False), (5, 63, 9, True), (64, 64, 16, False)])
+def test_contraction_and_term_sum_stay_inside_their_buffers(device, K, N, C, batched):
+    rs = np.random.RandomState(K + N + C)
+    J = rs.standard_normal((C, K, N) if batched else (K, N))
+    r = rs.standard_normal((C, N))
+    gz = Guarded(device)
+    got = _native.jacobian_contract(gz(J), gz(r))
+    gz.check()
+    assert torch.equal(got, _native.jacobian_contract(plain(J, device), plain(r, device)))
+    assert bool(torch.isfinite(got).all())
+    terms = [rs.standard_normal(C) for _ in range(3)]
+    gz = Guarded(device)
+    s1 = _native.sum_terms([gz(terms[0]), 0.5, gz(terms[1]), gz(terms[2])])
+    gz.check()
+    assert torch.equal(s1, _native.sum_terms([plain(terms[0], device), 0.5, plain(terms[1], device),
+                                              plain(terms[2], device)]))
+
+
+@pytest.mark.parametrize('K,N,C,L', [(4, 20, 5, 3), (33, 1000, 20, 2), (33, 16384, 130, 1), (17, 50, 2100, 2)])
+def test_fused_polynomial_leapfrog_stays_inside_its_buffers(device, K, N, C, L):
+    rs = np.random.RandomState(K + C)
+    xs = np.linspace(-1, 1, N)
+    A = np.vstack([xs ** i for i in range(K)])
+    ys, q0, p0 = rs.standard_normal(N), rs.standard_normal((C, K)), rs.standard_normal((C, K))
+    taus, dts = rs.uniform(1, 3, size=C), np.full(C, 1e-4)
+    res = []
+    for make in (Guarded(device), None):
+        t = make if make is not None else (lambda a, dtype=torch.float64: plain(a, device, dtype))
+        q, p = t(q0), t(p0)
+        _native.poly_leapfrog(q, p, t(A), t(ys), t(taus), 0.0, t(dts), L)
+        if make is not None:
+            make.check()
+        res.append((q.clone(), p.clone()))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    assert bool(torch.isfinite(res[0][0]).all())
+
+
+@pytest.mark.parametrize('D,C,n,thin', [(8193, 3, 3, 1), (20000, 2, 4, 3), (16384 + 5, 2, 2, 2)])
+def test_long_chain_loop_from_one_call_stays_inside_its_buffers(device, D, C, n, thin):
+    rs = np.random.RandomState(D)
+    q0, p0, u = rs.standard_normal((C, D)), rs.standard_normal((n, C, D)), rs.uniform(size=(n, C))
+    nrec = n // thin
+    res = []
+    for make in (Guarded(device), None):
+        t = make if make is not None else (lambda a, dtype=torch.float64: plain(a, device, dtype))
+        qo, smp = t(np.zeros((C, D))), t(np.zeros((nrec, C, D)))
+        acc = t(np.zeros((n, C), dtype=np.uint8), torch.uint8)
+        nacc = t(np.zeros(C, dtype=np.int64), torch.int64)
+        eb, ea = t(np.zeros((n, C))), t(np.zeros((n, C)))
+        _native.hmc_sample_n_gauss_big(t(q0), t(p0), t(u), qo, smp, acc, nacc, eb, ea, 0.01, None, 3,
+                                       n, thin, 1.0, 0.0, 0, 1.05, 0.95)
+        if make is not None:
+            make.check()
+        res.append((qo.clone(), smp.clone(), acc.clone(), ea.clone()))
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+    assert bool(torch.isfinite(res[0][0]).all())
