@@ -161,9 +161,10 @@ def gibbs_sample_n(gibbs, n, thin, record):
     gp = consts[0] if consts else None
     hmc = type(cs) is HMCSampler
     if hmc:
-        if cs._variable_name != 'coefficients' or cs.fused_polynomial == 'lane' or \
+        if cs._variable_name != 'coefficients' or cs._poly_lane_layout(spec, C) or \
                 cs._fused_spec('coefficients', K, C) is None:
             return False, None
+
     # the precision sampler must look at the same data
     try:
         em_p = ps.pdf.likelihoods['points'].error_model

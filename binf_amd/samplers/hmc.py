@@ -76,10 +76,11 @@ class HMCSampler(object):
         self.last_e_after = None
         self.accepted_history = None      # [n x C] flags of the last sample_n()
         self.fused_leapfrog = True        # use a PDF's fused leapfrog kernel if it has one
-        # ... and the fused small-data polynomial transition: True (a chain's data
-        # spread over a lane group), 'always' (even where the per-step tier is faster),
-        # 'lane' (one lane per chain, <= 128 data points: the layout for ~1e5+ chains;
-        # same energies, force summed in another order) or False
+        # ... and the fused small-data polynomial transition: True (layout by the batch:
+        # a chain's data spread over a lane group up to POLY_LANE_MIN_CHAINS chains, one
+        # lane per chain from there on when there are <= 128 data points -- same energies,
+        # the force summed in another order), 'group' / 'lane' (one layout whatever the
+        # batch), 'always' (fused even where the per-step tier is faster) or False
         self.fused_polynomial = True
 
     # -- reference attributes ----------------------------------------------
@@ -251,7 +252,7 @@ class HMCSampler(object):
                                  'tensor on %s' % (nrec, C, D, dev))
         if not persist and spec is not None and spec[0] == 'gauss':
             return self._sample_n_long(spec, n, thin, p0, u, record, out, q0, shape, nrec)
-        if spec is not None and spec[0] == 'poly' and self.fused_polynomial != 'lane' and \
+        if spec is not None and spec[0] == 'poly' and not self._poly_lane_layout(spec, C) and \
                 self._fused_spec(name, D, C) is not None:
             # the example's coefficient conditional: n transitions in one launch
             from binf_amd.example import native_poly
@@ -478,7 +479,7 @@ class HMCSampler(object):
                 D <= _native_poly_limits()[0]:
             n_data = len(spec[2].ys)
             if self.fused_polynomial == 'lane' and n_data > 128:
-                return None
+                return None                  # one lane per chain covers <= 128 data points
             if n_data > 128 and C is not None and self.fused_polynomial != 'always' and \
                     float(C) * n_data * D > _POLY_WAVE_MAX_WORK:
                 # one wave per chain wins while the batch is launch-bound (3-10x up to
@@ -487,6 +488,22 @@ class HMCSampler(object):
                 return None
             return spec
         return None
+
+    def _poly_lane_layout(self, spec, C):
+        """One lane per chain (csrc/hmc_poly.hip) instead of a lane group
+        (csrc/poly_chain_kernel.hpp) for the fused polynomial transition?  A lane
+        group fills the chip from a few thousand chains (20.7 vs 42 us per
+        transition at 4096 chains); with POLY_LANE_MIN_CHAINS chains and more every
+        SIMD has work either way and one lane per chain does half the instructions
+        (2^20 chains: 0.5 vs ~2 ms).  The energies are the same bits in both; the
+        force is summed in data order vs partial sums + butterfly, so a chain's
+        trajectory differs at rounding level between batches on either side of the
+        threshold (like the MFMA gradient's batch-dependent order)."""
+        if self.fused_polynomial == 'lane':
+            return True
+        if self.fused_polynomial in ('group', False):
+            return False
+        return len(spec[2].ys) <= 128 and C >= POLY_LANE_MIN_CHAINS
 
     def _sample_fused_gauss(self, spec, q0, p0, u, accepted, adapt):
         _, k, x0 = spec
@@ -532,7 +549,7 @@ class HMCSampler(object):
                                 self._timestep, self._dt_chain, self.nsteps, adapt,
                                 self.adaption_uprate, self.adaption_downrate,
                                 _MODES[self.mode] | (_native.MODE_LANE_PER_CHAIN
-                                                     if self.fused_polynomial == 'lane' else 0))
+                                                     if self._poly_lane_layout(spec, C) else 0))
         self.last_e_before, self.last_e_after = eb, ea
         return q_out
 
@@ -605,6 +622,7 @@ class HMCSampler(object):
 
 
 _POLY_WAVE_MAX_WORK = 2.0e8    # chains x data points x coefficients (see _fused_spec)
+POLY_LANE_MIN_CHAINS = 65536   # see HMCSampler._poly_lane_layout
 
 
 def _fill(rng, kind, out):
