@@ -134,8 +134,9 @@ hmc_gauss_persist_kernel(const GaussNArgs a)
     // (thin == 1) the state before transition s is what this very lane wrote to the
     // record of transition s - 1 (q0 for s = 0): it is read back from there on the rare
     // rejection, and the per-transition copy of the state to LDS (16 ds_write_b64 per lane)
-    // is not made at all.  Regular trees only (every lane owns what it reads back).
-    const bool stash_lds = !(REGULAR && a.samples && a.thin == 1 && !a.force_lds_stash);
+    // is not made at all; a single transition (n == 1) reads q0 again.  Regular trees only
+    // (every lane owns what it reads back).
+    const bool stash_lds = !(REGULAR && ((a.samples && a.thin == 1) || a.n == 1) && !a.force_lds_stash);
 
     for (int s = 0; s < a.n; ++s) {
         const double hdt = 0.5 * dt;
