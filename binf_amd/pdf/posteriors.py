@@ -27,17 +27,15 @@ def _sum_in_order(terms):
         import torch
     except ImportError:  # pragma: no cover
         torch = None
-    if torch is not None and any(isinstance(t, torch.Tensor) and t.is_cuda and t.dim() > 0
-                                 for t in terms):
+
+    def vector(t):
+        return torch is not None and isinstance(t, torch.Tensor) and t.dim() > 0
+
+    vectors = [t for t in terms if vector(t)]
+    if vectors and len(terms) <= 16 and len(set(tuple(t.shape) for t in vectors)) == 1 and \
+            all(t.is_cuda and t.dtype == torch.float64 and t.is_contiguous() for t in vectors):
         from binf_amd import _native
-        if len(terms) <= 16 and all(
-                (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float64 and
-                 t.is_contiguous()) or not isinstance(t, torch.Tensor) or t.dim() == 0
-                for t in terms):
-            shapes = set(tuple(t.shape) for t in terms if isinstance(t, torch.Tensor) and t.dim() > 0)
-            if len(shapes) == 1:
-                return _native.sum_terms([t if (isinstance(t, torch.Tensor) and t.dim() > 0)
-                                          else float(t) for t in terms])
+        return _native.sum_terms([t if vector(t) else float(t) for t in terms])
     total = terms[0]
     for t in terms[1:]:
         total = total + t
