@@ -100,6 +100,8 @@ SIGNATURES = {
                                        _vp]),
     'binf_poly_gauss_logp_f64': (_i32, [_vp, _vp, _vp, _f64, _vp, _vp, _i64,
                                         _i64, _i64, _vp]),
+    'binf_poly_gauss_logp_memo_f64': (_i32, [_vp, _vp, _vp, _f64, _vp, _vp, _vp, _vp, _vp,
+                                             _i64, _i64, _i64, _vp]),
     'binf_poly_gauss_grad_workspace_bytes': (_i64, [_i64, _i64, _i64]),
     'binf_poly_gauss_grad_f64': (_i32, [_vp, _vp, _vp, _f64, _vp, _vp, _vp,
                                         _i64, _i64, _i64, _i64, _vp]),
@@ -493,6 +495,24 @@ def poly_gauss_logp(coeffs, xs, ys, precision):
         dptr(tau_chain, numel=C, name='precision'), dptr(out), C, K, N,
         stream_handle(coeffs.device))
     check(rc, 'binf_poly_gauss_logp_f64')
+    return out
+
+
+@_launcher
+def poly_gauss_logp_memo(coeffs, xs, ys, precision, memo):
+    """binf_poly_gauss_logp_memo_f64; ``memo = (memo_coeffs [C x K], memo_chi2 [C],
+    skip [C] uint8)``, NaN-filled before its first use."""
+    C, K = _cd(coeffs)
+    N = xs.numel()
+    tau, tau_chain = _precision_args(precision, C, coeffs.device)
+    mc, ms, sk = memo
+    out = torch.empty(C, dtype=torch.float64, device=coeffs.device)
+    rc = lib().binf_poly_gauss_logp_memo_f64(
+        dptr(coeffs, numel=C * K, name='coeffs'), dptr(xs, numel=N, name='xs'),
+        dptr(ys, numel=N, name='ys'), tau, dptr(tau_chain, numel=C, name='precision'), dptr(out),
+        dptr(mc, numel=C * K, name='memo_coeffs'), dptr(ms, numel=C, name='memo_chi2'),
+        dptr(sk, torch.uint8, C, 'skip'), C, K, N, stream_handle(coeffs.device))
+    check(rc, 'binf_poly_gauss_logp_memo_f64')
     return out
 
 

@@ -73,6 +73,10 @@ struct RowGeom {
     int32_t H;       // largest pairwise tree height among the row's 8192-element chunks
     double scale;
     GaussFinish fin;
+    // per-row memo of the raw sum (block kernel only): a row whose skip flag is set takes
+    // memo_sum[row] instead of being summed again; every row summed leaves its sum there
+    const uint8_t *skip;
+    double *memo_sum;
 };
 
 __device__ inline double row_result(const RowGeom &g, int64_t row, double sum)
@@ -137,6 +141,10 @@ row_reduce_block_kernel(const ARGS args, const RowGeom g, double *out)
     const int lane = threadIdx.x & 63;
     const int group = threadIdx.x >> 3;      // GROUPS groups of 8 lanes
     const int64_t row = blockIdx.x;
+    if (g.skip && g.skip[row]) {                 // workgroup-uniform
+        if (threadIdx.x == 0) out[row] = row_result(g, row, g.memo_sum[row]);
+        return;
+    }
     if constexpr (STAGED) {
         FM::stage(args, row, row_lds);
         __syncthreads();
@@ -173,7 +181,10 @@ row_reduce_block_kernel(const ARGS args, const RowGeom g, double *out)
         total = total + S[0];
         __syncthreads();
     }
-    if (threadIdx.x == 0) out[row] = row_result(g, row, total);
+    if (threadIdx.x == 0) {
+        if (g.memo_sum) g.memo_sum[row] = total;
+        out[row] = row_result(g, row, total);
+    }
 }
 
 template <class FM, class ARGS, bool STAGED = false>
@@ -181,7 +192,8 @@ static int32_t row_reduce_launch(const ARGS &args, int64_t C, int64_t D,
                                  double scale, double *out, hipStream_t st,
                                  bool force_block, const char *what,
                                  size_t staged_bytes = 0, bool wide = false,
-                                 const GaussFinish *fin = nullptr)
+                                 const GaussFinish *fin = nullptr,
+                                 const uint8_t *skip = nullptr, double *memo_sum = nullptr)
 {
     if (C > 0x7fffffffLL || D > 0x7fffffffLL)
         return fail(BINF_E_UNSUPPORTED, "%s: too large", what);
@@ -189,6 +201,7 @@ static int32_t row_reduce_launch(const ARGS &args, int64_t C, int64_t D,
     g.C = C; g.D = (int32_t)D; g.scale = scale;
     if (fin) g.fin = *fin;
     else { g.fin.on = 0; g.fin.tau = 1.0; g.fin.tau_chain = nullptr; g.fin.n_data = 0.0; g.fin.minus = nullptr; }
+    g.skip = skip; g.memo_sum = memo_sum;      // honoured by the block kernel (force_block)
     g.H = pairwise_tree_height(D < NPY_BUFSIZE ? D : NPY_BUFSIZE);
     if (D > NPY_BUFSIZE && D % NPY_BUFSIZE != 0) {
         const int32_t h_last = pairwise_tree_height(D % NPY_BUFSIZE);

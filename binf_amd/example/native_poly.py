@@ -30,8 +30,38 @@ def log_prob(likelihood, pair, fwm_vars, em_vars):
     if not _usable(coeffs) or 'precision' not in em_vars:
         return None
     dev = coeffs.device
-    return _native.poly_gauss_logp(_as2d(coeffs).contiguous(), fwm.xs_device(dev),
-                                   em.ys_device(dev), em_vars['precision'])
+    c2 = _as2d(coeffs).contiguous()
+    xs, ys = fwm.xs_device(dev), em.ys_device(dev)
+    if ys.numel() >= CHI2_MEMO_MIN_DATA and USE_CHI2_MEMO:
+        # a Horner pass over this much data is worth remembering per chain: the Gibbs
+        # sweep asks for the same coefficients' chi^2 three times (proposal, precision
+        # update, next E_before); the memo is checked on the device, bit for bit
+        return _native.poly_gauss_logp_memo(c2, xs, ys, em_vars['precision'],
+                                            _chi2_memo(xs, ys, c2.shape))
+    return _native.poly_gauss_logp(c2, xs, ys, em_vars['precision'])
+
+
+USE_CHI2_MEMO = True
+CHI2_MEMO_MIN_DATA = 2048       # below, the pass is a few microseconds
+_memos = {}
+
+
+def _chi2_memo(xs, ys, shape):
+    """(memo_coeffs, memo_chi2, skip) for this data set, batch shape and stream; the
+    key holds the data tensors themselves (clones of a model share them), so new data
+    get a new memo."""
+    C, K = shape
+    key = (id(xs), id(ys), C, K, _native.stream_handle(xs.device))
+    m = _memos.get(key)
+    if m is None or m[0] is not xs or m[1] is not ys:
+        nan = float('nan')
+        m = (xs, ys, (torch.full((C, K), nan, dtype=torch.float64, device=xs.device),
+                      torch.full((C,), nan, dtype=torch.float64, device=xs.device),
+                      torch.zeros(C, dtype=torch.uint8, device=xs.device)))
+        while len(_memos) >= 8:
+            _memos.pop(next(iter(_memos)))
+        _memos[key] = m
+    return m[2]
 
 
 def gradient(likelihood, pair, fwm_vars, em_vars):

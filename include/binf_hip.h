@@ -35,7 +35,8 @@ extern "C" {
  * 3: binf_hmc_sample_poly_f64 spreads a chain's data over a lane group for EVERY
  *    N <= 1024 (the force's summation order for N <= 128 changed with it; one lane
  *    per chain is now the opt-in BINF_MODE_LANE_PER_CHAIN); binf_gibbs_poly_sample_n_f64,
- *    binf_jacobian_contract_f64, binf_sum_terms_f64, binf_poly_leapfrog_f64. */
+ *    binf_jacobian_contract_f64, binf_sum_terms_f64, binf_poly_leapfrog_f64,
+ *    binf_poly_gauss_logp_memo_f64, binf_hmc_sample_n_gauss_big_f64 / _rng_f64. */
 #define BINF_ABI_VERSION 3
 
 #define BINF_E_ARG        (-1)  /* null pointer / negative size / bad flag    */
@@ -376,6 +377,26 @@ int32_t binf_poly_gauss_logp_f64(const double *coeffs, const double *xs,
                                  const double *ys, double precision,
                                  const double *precision_chain, double *out,
                                  int64_t C, int64_t K, int64_t N, void *stream);
+
+/* The same log-prob with a per-chain MEMO of chi^2 = np.sum((polyval - ys)**2), the
+ * expensive part (a Horner pass over all N data points per chain), which depends on the
+ * coefficients alone.  memo_coeffs [C x K] / memo_chi2 [C] (caller-owned, device; fill
+ * both with NaN before the first use) hold the coefficients a stored chi^2 belongs to:
+ * a chain whose coefficients equal the memo's BIT FOR BIT takes the stored chi^2, every
+ * other chain is summed and leaves its coefficients and chi^2 in the memo.  The check
+ * runs on the device, chain by chain (skip [C]: scratch, 1 = reused) -- no tensor
+ * identities, versions or host synchronisation are involved, so the results are those of
+ * binf_poly_gauss_logp_f64 bit for bit whatever happened to the buffers in between.
+ * In a Gibbs sweep (binf/samplers/gibbs.py:146-149) the log-prob is asked for the
+ * proposal (hmc.py:150), again for the same coefficients at precision = 1
+ * (binf/example/samplers.py:34-41) and once more as the next sweep's E_before
+ * (hmc.py:148): one Horner pass instead of three. */
+int32_t binf_poly_gauss_logp_memo_f64(const double *coeffs, const double *xs,
+                                      const double *ys, double precision,
+                                      const double *precision_chain, double *out,
+                                      double *memo_coeffs, double *memo_chi2,
+                                      uint8_t *skip, int64_t C, int64_t K, int64_t N,
+                                      void *stream);
 
 /* Likelihood._evaluate_gradient (binf/pdf/likelihoods.py:148-155) for the same
  * pair: out[c,:] = J . ((mock_c - ys) * precision_c) with the Jacobian

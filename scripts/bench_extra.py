@@ -62,7 +62,7 @@ def c3_polynomial(dev, C=8192, K=33, N=16384, L=20):
                       'coefficients_prior': GaussianPrior(np.zeros(K), np.ones(K) * 5)})
     cond = post.conditional_factory(precision=2.5)
     s = HMCSampler(cond, q0, 2e-4, L, variable_name='coefficients', rng=DeviceRNG(1, dev))
-    t_hmc = _timed(s.sample, 3, warm=1)
+    t_hmc = _timed(s.sample, 10, warm=3)
     return {'workload': 'C3: polynomial K=%d, N=%d, %d chains, L=%d' % (K, N, C, L),
             'grad_kernel_ms': t_grad * 1e3,
             'grad_TFLOPs': flops / t_grad / 1e12,
@@ -95,7 +95,7 @@ def c4_gibbs(dev, C=4096, K=33, N=16384, L=20):
                            precision=torch.full((C,), 2.5, dtype=torch.float64, device=dev)))
     grng = DeviceRNG(5, dev)
     gips = make_hmc_sampler(post, 2e-4, L, start, rng=DeviceRNG(2, dev), gamma=grng.gamma)
-    t = _timed(gips.sample, 4, warm=2)
+    t = _timed(gips.sample, 10, warm=3)
     return {'workload': 'C4 share: Gibbs-within-HMC, polynomial K=%d, N=%d, %d chains (32768 / 8), '
                         'L=%d' % (K, N, C, L),
             'gibbs_sweep_ms': t * 1e3, 'chain_leapfrog_steps_per_s': C * L / t}

@@ -884,3 +884,78 @@ def test_fused_polynomial_leapfrog_argument_checks(device):
                                               y.data_ptr(), 1.0, None, None, 0, C, K, N, 0.1, None, 2,
                                               0, None)
     assert rc == _native.E_ARG and 'workspace' in _native.last_error()
+
+
+def test_chi2_memo_is_checked_on_the_device_chain_by_chain(device):
+    """binf_poly_gauss_logp_memo_f64: whatever happens to the coefficient buffers in
+    between (in-place kernel writes, reallocation at the same address, partial
+    changes), the result is the plain log-prob bit for bit; chains whose
+    coefficients are unchanged are not summed again (skip flags)."""
+    K, N, C = 33, 4096, 37
+    xs, ys, theta = synth(K, N, C, 5)
+    tx, ty = dev_t(xs, device), dev_t(ys, device)
+    nan = float('nan')
+    memo = (torch.full((C, K), nan, dtype=torch.float64, device=device),
+            torch.full((C,), nan, dtype=torch.float64, device=device),
+            torch.zeros(C, dtype=torch.uint8, device=device))
+    rs = np.random.RandomState(0)
+    th = dev_t(theta, device)
+    taus = dev_t(rs.uniform(0.5, 3.0, size=C), device)
+    changed_prev = np.ones(C, dtype=bool)
+    for step in range(6):
+        prec = (2.5, 1.0, taus)[step % 3]
+        got = _native.poly_gauss_logp_memo(th, tx, ty, prec, memo)
+        want = _native.poly_gauss_logp(th, tx, ty, prec)
+        assert np.array_equal(got.cpu().numpy(), want.cpu().numpy(), equal_nan=True), step
+        assert np.array_equal(memo[2].cpu().numpy().astype(bool), ~changed_prev), step
+        assert np.array_equal(memo[0].cpu().numpy(), th.cpu().numpy(), equal_nan=True)
+        # change a random subset IN PLACE (as a kernel would: no new tensor, no version bump
+        # that anything here looks at), including a sign flip of a zero and a NaN
+        changed_prev = rs.rand(C) < 0.4
+        idx = np.nonzero(changed_prev)[0]
+        upd = theta[idx] + rs.standard_normal((len(idx), K)) * 1e-3
+        if step == 2 and len(idx) > 1:
+            upd[0, 3] = nan
+        theta[idx] = upd
+        th[torch.from_numpy(idx).to(device)] = dev_t(upd, device)
+    # +0.0 -> -0.0 is a different bit pattern: not reused (and the result is still exact)
+    th[0, 0] = 0.0
+    _native.poly_gauss_logp_memo(th, tx, ty, 2.5, memo)
+    th[0, 0] = -0.0
+    got = _native.poly_gauss_logp_memo(th, tx, ty, 2.5, memo)
+    assert int(memo[2][0]) == 0 and int(memo[2][1:].sum()) == C - 1
+    assert np.array_equal(got.cpu().numpy(), _native.poly_gauss_logp(th, tx, ty, 2.5).cpu().numpy(),
+                          equal_nan=True)
+    assert int(torch.isnan(got).sum()) == 1          # the chain that was given a NaN coefficient
+
+
+def test_gibbs_sweeps_with_and_without_the_chi2_memo_are_identical(device):
+    """Through the class stack (Posterior -> Likelihood -> native log-prob) at a data
+    size that uses the memo: Gibbs-within-HMC sweeps with per-chain precisions give
+    the same states with the memo switched off."""
+    from binf_amd.example import native_poly
+    K, N, C, L = 9, 2500, 21, 3
+    xs, ys, theta = synth(K, N, C, 8)
+    runs = []
+    for use in (True, False, True):
+        native_poly.USE_CHI2_MEMO = use
+        try:
+            lik = make_likelihood(xs, ys, POLYVAL)
+            post = Posterior({lik.name: lik}, {'precision_prior': GammaPrior(1.0, 0.2),
+                                               'coefficients_prior': GaussianPrior(np.zeros(K), np.ones(K) * 5)})
+            st = BinfState(dict(coefficients=dev_t(theta, device),
+                                precision=torch.full((C,), 2.0, dtype=torch.float64, device=device)))
+            from binf_amd.samplers.rng import DeviceRNG
+            gips = make_hmc_sampler(post, 2e-3, L, st, rng=DeviceRNG(3, device))
+            out = []
+            for _ in range(5):
+                s = gips.sample()
+                out.append((s.variables['coefficients'].clone(), s.variables['precision'].clone()))
+            runs.append(out)
+            acc = gips.subsamplers['coefficients'].acceptance_rate
+            assert 0.0 < float(acc.mean()) <= 1.0
+        finally:
+            native_poly.USE_CHI2_MEMO = True
+    for a, b, c in zip(*runs):
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+        assert torch.equal(a[0], c[0]) and torch.equal(a[1], c[1])
