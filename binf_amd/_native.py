@@ -111,6 +111,8 @@ SIGNATURES = {
                                       _f64, _vp, _i32, _i32, _vp]),
     'binf_pairdist_gauss_logp_f64': (_i32, [_vp, _vp, _vp, _vp, _f64, _vp, _vp, _i64,
                                             _i64, _i64, _vp]),
+    'binf_pairdist_gauss_logp_memo_f64': (_i32, [_vp, _vp, _vp, _vp, _f64, _vp, _vp, _vp, _vp, _vp,
+                                                 _i64, _i64, _i64, _vp]),
     'binf_pairdist_forward_f64': (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i64,
                                          _vp]),
     'binf_pairdist_gauss_grad_f64': (_i32, [_vp, _vp, _f64, _vp, _vp, _i64,
@@ -953,6 +955,27 @@ def pairdist_gauss_logp(x, pair_i, pair_j, ys, precision):
         dptr(tau_chain, numel=C, name='precision'), dptr(out), C, D // 3, P,
         stream_handle(x.device))
     check(rc, 'binf_pairdist_gauss_logp_f64')
+    return out
+
+
+@_launcher
+def pairdist_gauss_logp_memo(x, pair_i, pair_j, ys, precision, memo):
+    """binf_pairdist_gauss_logp_memo_f64; ``memo = (memo_x [C x 3n], memo_chi2 [C],
+    skip [C] uint8)``, NaN-filled before its first use."""
+    C, D = _cd(x)
+    if D % 3:
+        raise ValueError('coordinates must be [n_chains, 3 * n_beads]')
+    P = pair_i.numel()
+    tau, tau_chain = _precision_args(precision, C, x.device)
+    mx, ms, sk = memo
+    out = torch.empty(C, dtype=torch.float64, device=x.device)
+    rc = lib().binf_pairdist_gauss_logp_memo_f64(
+        dptr(x, numel=C * D, name='x'), dptr(pair_i, torch.int32, P, 'pair_i'),
+        dptr(pair_j, torch.int32, P, 'pair_j'), dptr(ys, numel=P, name='ys'), tau,
+        dptr(tau_chain, numel=C, name='precision'), dptr(out), dptr(mx, numel=C * D, name='memo_x'),
+        dptr(ms, numel=C, name='memo_chi2'), dptr(sk, torch.uint8, C, 'skip'), C, D // 3, P,
+        stream_handle(x.device))
+    check(rc, 'binf_pairdist_gauss_logp_memo_f64')
     return out
 
 

@@ -809,12 +809,48 @@ extern "C" int32_t binf_pairdist_forward_f64(const double *x, const int32_t *pai
     return 0;
 }
 
+static int32_t pairdist_logp_run(const double *x, const int32_t *pair_i, const int32_t *pair_j,
+                                 const double *ys, double precision, const double *precision_chain,
+                                 double *out, const uint8_t *skip, double *memo_chi2, int64_t C,
+                                 int64_t n_beads, int64_t n_pairs, void *stream);
+
 extern "C" int32_t binf_pairdist_gauss_logp_f64(const double *x, const int32_t *pair_i,
                                                 const int32_t *pair_j, const double *ys,
                                                 double precision,
                                                 const double *precision_chain, double *out,
                                                 int64_t C, int64_t n_beads,
                                                 int64_t n_pairs, void *stream)
+{
+    return pairdist_logp_run(x, pair_i, pair_j, ys, precision, precision_chain, out, nullptr, nullptr,
+                             C, n_beads, n_pairs, stream);
+}
+
+// The same with a per-chain memo of chi^2 (a function of the chain's coordinates alone),
+// checked on the device bit for bit: rowsum.hpp, row_memo_check_kernel.
+extern "C" int32_t binf_pairdist_gauss_logp_memo_f64(const double *x, const int32_t *pair_i,
+                                                     const int32_t *pair_j, const double *ys,
+                                                     double precision,
+                                                     const double *precision_chain, double *out,
+                                                     double *memo_x, double *memo_chi2,
+                                                     uint8_t *skip, int64_t C, int64_t n_beads,
+                                                     int64_t n_pairs, void *stream)
+{
+    if (C < 0 || n_beads < 0 || n_pairs < 0)
+        return fail(BINF_E_ARG, "pairdist_gauss_logp_memo: negative size");
+    if (C == 0) return 0;
+    if (!x || !memo_x || !memo_chi2 || !skip)
+        return fail(BINF_E_ARG, "pairdist_gauss_logp_memo: null buffer");
+    const int32_t rc = row_memo_check(x, memo_x, skip, C, 3 * n_beads, (hipStream_t)stream,
+                                      "pairdist_gauss_logp_memo check launch");
+    if (rc) return rc;
+    return pairdist_logp_run(x, pair_i, pair_j, ys, precision, precision_chain, out, skip, memo_chi2,
+                             C, n_beads, n_pairs, stream);
+}
+
+static int32_t pairdist_logp_run(const double *x, const int32_t *pair_i, const int32_t *pair_j,
+                                 const double *ys, double precision, const double *precision_chain,
+                                 double *out, const uint8_t *skip, double *memo_chi2, int64_t C,
+                                 int64_t n_beads, int64_t n_pairs, void *stream)
 {
     if (C < 0 || n_beads < 0 || n_pairs < 0)
         return fail(BINF_E_ARG, "pairdist_gauss_logp: negative size");
@@ -834,10 +870,12 @@ extern "C" int32_t binf_pairdist_gauss_logp_f64(const double *x, const int32_t *
         rc = row_reduce_launch<PairResidMake, PairArgs, true>(a, C, n_pairs, 1.0, out, st, true,
                                                              "pairdist_gauss_logp",
                                                              (size_t)n_beads * 3 * sizeof(double),
-                                                             C < 1024 && n_pairs >= 2048, &fin);
+                                                             C < 1024 && n_pairs >= 2048, &fin, skip,
+                                                             memo_chi2);
     else
         rc = row_reduce_launch<PairResidMake, PairArgs>(a, C, n_pairs, 1.0, out, st, true,
-                                                       "pairdist_gauss_logp", 0, false, &fin);
+                                                       "pairdist_gauss_logp", 0, false, &fin, skip,
+                                                       memo_chi2);
     if (rc) return rc;
     return 0;
 }

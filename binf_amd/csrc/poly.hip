@@ -501,25 +501,6 @@ extern "C" int32_t binf_poly_gauss_logp_f64(const double *coeffs, const double *
     return rc;
 }
 
-// ---- chi^2 memo: which chains still have the coefficients their stored chi^2 belongs to?
-// One wave per chain: lane k compares coefficient k BIT FOR BIT with the memo's copy;
-// a chain that differs anywhere gets skip = 0 and its coefficients copied into the memo
-// (the reduction that follows stores the new sum beside them).
-__global__ void __launch_bounds__(256)
-theta_memo_check_kernel(const double *theta, double *memo_theta, uint8_t *skip, int64_t C, int32_t K)
-{
-    const int lane = threadIdx.x & 63;
-    const int64_t c = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (c >= C) return;
-    bool same = true;
-    for (int k = lane; k < K; k += 64)
-        same = same && (__double_as_longlong(theta[c * K + k]) == __double_as_longlong(memo_theta[c * K + k]));
-    const bool all_same = __all(same);
-    if (!all_same)
-        for (int k = lane; k < K; k += 64) memo_theta[c * K + k] = theta[c * K + k];
-    if (lane == 0) skip[c] = all_same ? 1 : 0;
-}
-
 extern "C" int32_t binf_poly_gauss_logp_memo_f64(const double *coeffs, const double *xs,
                                                  const double *ys, double precision,
                                                  const double *precision_chain, double *out,
@@ -532,12 +513,10 @@ extern "C" int32_t binf_poly_gauss_logp_memo_f64(const double *coeffs, const dou
     if (C == 0) return 0;
     if (!coeffs || ((!xs || !ys) && N > 0) || !out || !memo_coeffs || !memo_chi2 || !skip)
         return fail(BINF_E_ARG, "poly_gauss_logp_memo: null buffer");
-    if (C > 0x7fffffffLL * 4) return fail(BINF_E_UNSUPPORTED, "poly_gauss_logp_memo: too many chains");
     hipStream_t st = (hipStream_t)stream;
-    theta_memo_check_kernel<<<dim3((unsigned)((C + 3) / 4)), 256, 0, st>>>(coeffs, memo_coeffs, skip, C,
-                                                                         (int32_t)K);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return hip_fail(e, "poly_gauss_logp_memo check launch");
+    // which chains still have the coefficients their stored chi^2 belongs to (rowsum.hpp)
+    rc = row_memo_check(coeffs, memo_coeffs, skip, C, K, st, "poly_gauss_logp_memo check launch");
+    if (rc) return rc;
     PolyArgs a;
     a.theta = coeffs; a.xs = xs; a.ys = ys; a.K = (int32_t)K;
     GaussFinish fin;

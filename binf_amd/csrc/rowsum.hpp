@@ -226,6 +226,40 @@ static int32_t row_reduce_launch(const ARGS &args, int64_t C, int64_t D,
     return 0;
 }
 
+// ---- per-row memo of a reduction whose value depends on a small per-row argument vector
+// (the chi^2 of a likelihood as a function of a chain's coefficients / coordinates).
+// One wave per row: lane k compares argument k BIT FOR BIT with the memo's copy; a row
+// that differs anywhere gets skip = 0 and its arguments copied into the memo (the block
+// reduction that follows stores the new sum in RowGeom::memo_sum), a row that is the same
+// gets skip = 1 and is not summed again.  Content-checked on the device: no tensor
+// identities, versions or host synchronisation involved.
+template <int UNUSED = 0>
+__global__ void __launch_bounds__(256)
+row_memo_check_kernel(const double *arg, double *memo_arg, uint8_t *skip, int64_t C, int32_t K)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t c = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (c >= C) return;
+    bool same = true;
+    for (int k = lane; k < K; k += 64)
+        same = same && (__double_as_longlong(arg[c * K + k]) == __double_as_longlong(memo_arg[c * K + k]));
+    const bool all_same = __all(same);
+    if (!all_same)
+        for (int k = lane; k < K; k += 64) memo_arg[c * K + k] = arg[c * K + k];
+    if (lane == 0) skip[c] = all_same ? 1 : 0;
+}
+
+static int32_t row_memo_check(const double *arg, double *memo_arg, uint8_t *skip, int64_t C,
+                              int64_t K, hipStream_t st, const char *what)
+{
+    if (C > 0x7fffffffLL * 4 || K > 0x7fffffffLL)
+        return fail(BINF_E_UNSUPPORTED, "%s: too large", what);
+    row_memo_check_kernel<><<<dim3((unsigned)((C + 3) / 4)), 256, 0, st>>>(arg, memo_arg, skip, C, (int32_t)K);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, what);
+    return 0;
+}
+
 // Gaussian error model on top of a chi^2 row reduction (shared by the polynomial
 // and the pair-distance likelihoods)
 // lp[c] = -0.5 * chi2[c] * tau_c + N * 0.5 * log(tau_c)     likelihood.py:54-57

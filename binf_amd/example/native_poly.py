@@ -32,7 +32,7 @@ def log_prob(likelihood, pair, fwm_vars, em_vars):
     dev = coeffs.device
     c2 = _as2d(coeffs).contiguous()
     xs, ys = fwm.xs_device(dev), em.ys_device(dev)
-    if ys.numel() >= CHI2_MEMO_MIN_DATA and USE_CHI2_MEMO:
+    if ys.numel() >= CHI2_MEMO_MIN_DATA and USE_CHI2_MEMO and c2.numel() * 8 <= (1 << 28):
         # a Horner pass over this much data is worth remembering per chain: the Gibbs
         # sweep asks for the same coefficients' chi^2 three times (proposal, precision
         # update, next E_before); the memo is checked on the device, bit for bit

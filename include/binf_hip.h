@@ -669,6 +669,17 @@ int32_t binf_pairdist_gauss_logp_f64(const double *x, const int32_t *pair_i,
                                      double *out, int64_t C, int64_t n_beads,
                                      int64_t n_pairs, void *stream);
 
+/* The same with a per-chain memo of chi^2 (it depends on the chain's coordinates alone):
+ * memo_x [C x 3 n_beads] / memo_chi2 [C] / skip [C] as in binf_poly_gauss_logp_memo_f64 --
+ * HMCSampler.sample() asks for the log-prob of the state it ended the last transition
+ * with again as E_before (binf/samplers/hmc.py:148). */
+int32_t binf_pairdist_gauss_logp_memo_f64(const double *x, const int32_t *pair_i,
+                                          const int32_t *pair_j, const double *ys,
+                                          double precision, const double *precision_chain,
+                                          double *out, double *memo_x, double *memo_chi2,
+                                          uint8_t *skip, int64_t C, int64_t n_beads,
+                                          int64_t n_pairs, void *stream);
+
 /* Energy gradient of the Gaussian restraint likelihood,
  *   out[c, 3i+a] = precision_c * sum_{j != i} (d_ij - ymat[j][i]) (x_i - x_j)[a] / d_ij,
  * i.e. Likelihood._evaluate_gradient (binf/pdf/likelihoods.py:148-155) without

@@ -13,6 +13,7 @@ from binf_amd.example.distance import (DistanceErrorModel, DistanceForwardModel,
 from binf_amd.pdf import IsotropicGaussian
 from binf_amd.pdf.posteriors import Posterior
 from binf_amd.samplers.hmc import HMCSampler
+from binf_amd.samplers.rng import DeviceRNG
 from conftest import golden_files, load_golden
 from oracle import ref_distance as RD
 from oracle import ref_numpy as R
@@ -239,3 +240,43 @@ def test_distance_posterior_reproduces_golden_vectors(device, path):
         assert np.abs(out - g['q_out'][i]).max() <= 1e-9 * np.abs(g['q_out'][i]).max()
         assert np.allclose(s.last_e_before.cpu().numpy(), g['e_before'][i], rtol=1e-9, atol=0)
         assert np.allclose(s.last_e_after.cpu().numpy(), g['e_after'][i], rtol=1e-8, atol=0)
+
+
+def test_chi2_memo_of_the_pair_distance_log_prob(device):
+    """binf_pairdist_gauss_logp_memo_f64: the plain fused log-prob bit for bit whatever
+    is changed in place in between; unchanged chains are not summed again; and a
+    sampler run through the class stack is identical with the memo switched off."""
+    from binf_amd.example import distance as DM
+    n, C = 80, 9
+    ys, x = synth(n, C, 11)
+    L_ = make_distance_likelihood(ys, n)
+    I, J = L_.forward_model.pair_index(device)
+    ty = L_.error_model.ys_device(device)
+    nan = float('nan')
+    memo = (torch.full((C, 3 * n), nan, dtype=torch.float64, device=device),
+            torch.full((C,), nan, dtype=torch.float64, device=device),
+            torch.zeros(C, dtype=torch.uint8, device=device))
+    tx = dev_t(x, device)
+    rs = np.random.RandomState(1)
+    changed = np.ones(C, dtype=bool)
+    for step in range(5):
+        prec = 2.0 if step % 2 else dev_t(rs.uniform(1, 4, size=C), device)
+        got = _native.pairdist_gauss_logp_memo(tx, I, J, ty, prec, memo)
+        assert torch.equal(got, _native.pairdist_gauss_logp(tx, I, J, ty, prec)), step
+        assert np.array_equal(memo[2].cpu().numpy().astype(bool), ~changed), step
+        changed = rs.rand(C) < 0.5
+        idx = torch.from_numpy(np.nonzero(changed)[0]).to(device)
+        tx[idx] = tx[idx] + 1e-3 * torch.randn((len(idx), 3 * n), dtype=torch.float64, device=device)
+    runs = []
+    for use in (True, False):
+        DM.USE_CHI2_MEMO = use
+        try:
+            s = HMCSampler(make_post(ys, n).conditional_factory(precision=3.0), dev_t(x, device), 0.002, 4,
+                           variable_name='coordinates', rng=DeviceRNG(5, device), record_energies=True)
+            out = [s.sample().clone() for _ in range(4)]
+            runs.append((out, s.last_e_before.clone(), s.n_accepted.clone()))
+        finally:
+            DM.USE_CHI2_MEMO = True
+    for a, b in zip(runs[0][0], runs[1][0]):
+        assert torch.equal(a, b)
+    assert torch.equal(runs[0][1], runs[1][1]) and torch.equal(runs[0][2], runs[1][2])
