@@ -28,15 +28,15 @@ extern "C" {
 
 /* 2: every entry point that GENERATES draws takes the global index of its first
  *    chain / element (chain_offset, elem_offset) so that a sharded run reproduces
- *    the unsharded one bit for bit; new entry points for the RWMC subsampler, the
- *    multi-sweep Gibbs launch, the Jacobian contraction and the term sum.
+ *    the unsharded one bit for bit; new entry points for the RWMC subsampler.
  *    (1 -> 2 also covers the contract changes made late in ABI 1: the polynomial
  *    gradient's workspace is mandatory, binf_hmc_sample_poly_f64 accepts N <= 1024.)
  * 3: binf_hmc_sample_poly_f64 spreads a chain's data over a lane group for EVERY
  *    N <= 1024 (the force's summation order for N <= 128 changed with it; one lane
  *    per chain is now the opt-in BINF_MODE_LANE_PER_CHAIN); binf_gibbs_poly_sample_n_f64,
  *    binf_jacobian_contract_f64, binf_sum_terms_f64, binf_poly_leapfrog_f64,
- *    binf_poly_gauss_logp_memo_f64, binf_hmc_sample_n_gauss_big_f64 / _rng_f64. */
+ *    binf_poly_gauss_logp_memo_f64, binf_pairdist_gauss_logp_memo_f64,
+ *    binf_hmc_sample_n_gauss_big_f64 / _rng_f64. */
 #define BINF_ABI_VERSION 3
 
 #define BINF_E_ARG        (-1)  /* null pointer / negative size / bad flag    */
