@@ -85,7 +85,6 @@ class GibbsSampler(object):
     def sample(self):
         self._update_subsampler_states()          # "needed for RE", :144
         if self.fused_sweep:
-            self._update_conditional_pdf_params()
             from binf_amd.example import native_poly
             if native_poly.gibbs_sample_n(self, 1, 1, False)[0]:
                 self._update_conditional_pdf_params()

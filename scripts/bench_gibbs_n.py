@@ -81,5 +81,5 @@ def main():
                 f.write(json.dumps(l) + '\n')
 
 
-if __name__ == '__main__':
+if __name__ == "__main__":
     main()
