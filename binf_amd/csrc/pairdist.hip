@@ -24,6 +24,29 @@
 
 namespace binf {
 
+// Correctly rounded sqrt of a squared distance.  The compiler's expansion of sqrt(double)
+// is rsq + one coupled Goldschmidt step + two residual corrections, wrapped in a scaling
+// of inputs below 2^-767 and a pass-through of 0 / inf (18 instructions, 8 of them that
+// wrapping).  For an argument in [2^-767, inf) the wrapping does nothing: the same
+// iteration without it gives the same bits; any other argument takes the library path.
+__device__ inline double sqrt_rn(double s)
+{
+    const uint32_t hi = (uint32_t)__double2hiint(s);
+    const bool plain = hi - 0x10000000u < 0x7ff00000u - 0x10000000u;
+    const double r = __builtin_amdgcn_rsq(s);
+    double g = s * r;
+    double h = r * 0.5;
+    const double e = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, e, g);
+    h = __builtin_fma(h, e, h);
+    double d = __builtin_fma(-g, g, s);
+    g = __builtin_fma(d, h, g);
+    d = __builtin_fma(-g, g, s);
+    g = __builtin_fma(d, h, g);
+    if (__builtin_expect(!plain, 0)) g = sqrt(s);
+    return g;
+}
+
 // d[c, p] for p-th pair (I[p], J[p]); coordinates x[c, 3*bead + axis]
 __global__ void __launch_bounds__(256)
 pairdist_forward_kernel(const double *x, const int32_t *I, const int32_t *J,
@@ -39,7 +62,7 @@ pairdist_forward_kernel(const double *x, const int32_t *I, const int32_t *J,
         const double e = xc[3 * i + 2] - xc[3 * j + 2];
         // np.sum(diff**2, axis=1): sequential over the 3 components
         const double s = (a * a + b * b) + e * e;
-        out[c * n_pairs + p] = sqrt(s);
+        out[c * n_pairs + p] = sqrt_rn(s);
     }
 }
 
@@ -66,7 +89,7 @@ struct PairResid {
         const double b = xc[3 * i + 1] - xc[3 * j + 1];
         const double e = xc[3 * i + 2] - xc[3 * j + 2];
         const double s = (a * a + b * b) + e * e;
-        const double d = sqrt(s) - ys[p];
+        const double d = sqrt_rn(s) - ys[p];
         return d * d;
     }
 };
@@ -98,6 +121,184 @@ struct PairResidMake {
         return f;
     }
 };
+
+// ---- chi^2 of ROWS chains per workgroup: the pair list (I, J, y) is the same for every
+// chain, so one pass over it serves ROWS chains -- the index / target loads and their
+// address arithmetic are paid once, and each lane has 8 x ROWS independent square roots
+// in flight.  With one chain per workgroup the list is streamed from L2 once per chain
+// (16 bytes per pair and chain: 1 GB per evaluation at 2048 chains of 256 beads), which
+// is what bounded the one-row kernel there.  Same tree, same order as
+// row_reduce_block_kernel: the results are bit-identical to the one-row path.
+// LDS: coordinates interleaved [3*bead + axis][row], so one bead's ROWS values of an axis
+// are one 16- or 32-byte read.
+template <int ROWS>
+struct PairResidRows {
+    const double *xl;
+    const int32_t *I;
+    const int32_t *J;
+    const double *ys;
+    __device__ inline void operator()(int p, double (&v)[ROWS]) const
+    {
+        const int i = 3 * ROWS * I[p], j = 3 * ROWS * J[p];
+        const double y = ys[p];
+        double xi[3][ROWS], xj[3][ROWS];
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax)
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) {
+                xi[ax][r] = xl[i + ax * ROWS + r];
+                xj[ax][r] = xl[j + ax * ROWS + r];
+            }
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            const double a = xi[0][r] - xj[0][r];
+            const double b = xi[1][r] - xj[1][r];
+            const double e = xi[2][r] - xj[2][r];
+            const double s = (a * a + b * b) + e * e;
+            const double d = sqrt_rn(s) - y;
+            v[r] = d * d;
+        }
+    }
+};
+
+// leaf_sum_f (rowsum.hpp) for ROWS rows at once; U element values per row in flight
+template <int ROWS, int U, class F>
+__device__ inline void leaf_sum_rows(const F &f, int off, int n, int lane, bool active,
+                                     double (&res)[ROWS])
+{
+    const int j = lane & 7;
+    const int T = (n >= 8) ? (n >> 3) : 0;
+    const int rem = (n >= 8) ? (n & 7) : n;
+    double r[ROWS];
+#pragma unroll
+    for (int q = 0; q < ROWS; ++q) r[q] = 0.0;
+    if (active && T > 0) {
+        int t = 0;
+        for (; t + U <= T; t += U) {
+            double v[U][ROWS];
+#pragma unroll
+            for (int u = 0; u < U; ++u) f(off + 8 * (t + u) + j, v[u]);
+#pragma unroll
+            for (int q = 0; q < ROWS; ++q) r[q] = (t == 0) ? v[0][q] : r[q] + v[0][q];
+#pragma unroll
+            for (int u = 1; u < U; ++u)
+#pragma unroll
+                for (int q = 0; q < ROWS; ++q) r[q] = r[q] + v[u][q];
+        }
+        for (; t < T; ++t) {
+            double v[ROWS];
+            f(off + 8 * t + j, v);
+#pragma unroll
+            for (int q = 0; q < ROWS; ++q) r[q] = (t == 0) ? v[q] : r[q] + v[q];
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < ROWS; ++q) {
+        const double s8 = sum8_f64(r[q]);
+        res[q] = (T > 0) ? s8 : -0.0;
+    }
+    if (__any(rem != 0)) {
+        double tail[ROWS];
+#pragma unroll
+        for (int q = 0; q < ROWS; ++q) tail[q] = 0.0;
+        if (active && j < rem) f(off + 8 * T + j, tail);
+        const int leafbase = lane & ~7;
+#pragma unroll
+        for (int i = 0; i < 7; ++i)
+#pragma unroll
+            for (int q = 0; q < ROWS; ++q) {
+                const double v = shfl_f64(tail[q], leafbase + i);
+                const double s = res[q] + v;
+                res[q] = (i < rem) ? s : res[q];
+            }
+    }
+}
+
+template <int ROWS, int U>
+__global__ void __launch_bounds__(256)
+pairdist_chi2_rows_kernel(const PairArgs a, const RowGeom g, double *out)
+{
+    constexpr int GROUPS = 256 / 8;
+    __shared__ double S[ROWS][128];
+    __shared__ int dep[128];
+    extern __shared__ double row_lds[];
+    const int H = g.H;
+    const int npaths = 1 << H;
+    const int lane = threadIdx.x & 63;
+    const int group = threadIdx.x >> 3;
+    const int64_t row0 = (int64_t)blockIdx.x * ROWS;
+    int64_t rows[ROWS];                          // the last workgroup repeats the last chain
+#pragma unroll
+    for (int q = 0; q < ROWS; ++q) rows[q] = (row0 + q < g.C) ? row0 + q : g.C - 1;
+    if (g.skip) {                                // workgroup-uniform
+        bool all_skip = true;
+#pragma unroll
+        for (int q = 0; q < ROWS; ++q) all_skip = all_skip && g.skip[rows[q]] != 0;
+        if (all_skip) {
+            if (threadIdx.x < ROWS && row0 + threadIdx.x < g.C) {
+                const int64_t row = row0 + threadIdx.x;
+                out[row] = row_result(g, row, g.memo_sum[row]);
+            }
+            return;
+        }
+    }
+    const int n3 = 3 * (int)a.n_beads;
+#pragma unroll
+    for (int q = 0; q < ROWS; ++q) {
+        const double *xc = a.x + rows[q] * n3;
+        for (int k = threadIdx.x; k < n3; k += 256) row_lds[k * ROWS + q] = xc[k];
+    }
+    __syncthreads();
+    PairResidRows<ROWS> f;
+    f.xl = row_lds; f.I = a.I; f.J = a.J; f.ys = a.ys;
+    double total[ROWS];
+#pragma unroll
+    for (int q = 0; q < ROWS; ++q) total[q] = 0.0;
+    for (int cbase = 0; cbase == 0 || cbase < g.D; cbase += NPY_BUFSIZE) {
+        const int n = (g.D - cbase < NPY_BUFSIZE) ? g.D - cbase : NPY_BUFSIZE;
+        for (int base = 0; base < npaths; base += GROUPS) {
+            const int path = base + group;
+            const bool act = path < npaths;
+            const Leaf L = pairwise_leaf(n, H, act ? path : 0);
+            double s[ROWS];
+            leaf_sum_rows<ROWS, U>(f, cbase + L.off, L.len, lane, act, s);
+            if (act && (lane & 7) == 0) {
+#pragma unroll
+                for (int q = 0; q < ROWS; ++q) S[q][path] = s[q];
+                dep[path] = L.depth;
+            }
+        }
+        __syncthreads();
+        for (int l = 0; l < H; ++l) {
+            double v[ROWS];
+            const int p = threadIdx.x;
+            if (p < npaths) {
+                const bool join = dep[p] >= H - l;
+#pragma unroll
+                for (int q = 0; q < ROWS; ++q) {
+                    const double mine = S[q][p];
+                    v[q] = join ? mine + S[q][p ^ (1 << l)] : mine;
+                }
+            }
+            __syncthreads();
+            if (p < npaths)
+#pragma unroll
+                for (int q = 0; q < ROWS; ++q) S[q][p] = v[q];
+            __syncthreads();
+        }
+#pragma unroll
+        for (int q = 0; q < ROWS; ++q) total[q] = total[q] + S[q][0];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int q = 0; q < ROWS; ++q) {
+            if (row0 + q >= g.C) break;
+            if (g.memo_sum) g.memo_sum[row0 + q] = total[q];
+            out[row0 + q] = row_result(g, row0 + q, total[q]);
+        }
+    }
+}
 
 // Restraint weight of one pair: w = (d - y) / d = 1 - y / d with d = |x_i - x_j|.
 // IEEE sqrt + IEEE divide cost ~55 FP64 instructions per pair; instead
@@ -847,6 +1048,24 @@ extern "C" int32_t binf_pairdist_gauss_logp_memo_f64(const double *x, const int3
                              C, n_beads, n_pairs, stream);
 }
 
+// chains per workgroup of the chi^2 reduction: more than one once there are enough chains
+// to fill the chip that way (development aid: BINF_PD_LOGP_ROWS = 1, 2, 4)
+static int pairdist_logp_rows(int64_t C, int64_t n_beads, int64_t n_pairs)
+{
+    static std::atomic<int> forced(-1);
+    int v = forced.load(std::memory_order_relaxed);
+    if (v < 0) {
+        const char *e = getenv("BINF_PD_LOGP_ROWS");
+        v = e ? atoi(e) : 0;
+        if (v != 1 && v != 2 && v != 4) v = 0;
+        forced.store(v, std::memory_order_relaxed);
+    }
+    int rows = v;
+    if (rows == 0) rows = (C >= 2048 && n_pairs >= 2048) ? 2 : 1;
+    while (rows > 1 && (int64_t)rows * n_beads * 3 * (int64_t)sizeof(double) > 48 * 1024) rows >>= 1;
+    return rows;
+}
+
 static int32_t pairdist_logp_run(const double *x, const int32_t *pair_i, const int32_t *pair_j,
                                  const double *ys, double precision, const double *precision_chain,
                                  double *out, const uint8_t *skip, double *memo_chi2, int64_t C,
@@ -863,6 +1082,26 @@ static int32_t pairdist_logp_run(const double *x, const int32_t *pair_i, const i
     int32_t rc;
     GaussFinish fin;                // lp = -0.5 chi2 tau + N/2 log tau, written by the reduction
     fin.on = 1; fin.minus = nullptr; fin.tau = precision; fin.tau_chain = precision_chain; fin.n_data = (double)n_pairs;
+    const int rows = pairdist_logp_rows(C, n_beads, n_pairs);
+    if (rows > 1) {
+        if (C > 0x7fffffffLL || n_pairs > 0x7fffffffLL)
+            return fail(BINF_E_UNSUPPORTED, "pairdist_gauss_logp: too large");
+        RowGeom g;
+        g.C = C; g.D = (int32_t)n_pairs; g.scale = 1.0; g.fin = fin; g.skip = skip; g.memo_sum = memo_chi2;
+        g.H = pairwise_tree_height(n_pairs < NPY_BUFSIZE ? n_pairs : NPY_BUFSIZE);
+        if (n_pairs > NPY_BUFSIZE && n_pairs % NPY_BUFSIZE != 0) {
+            const int32_t h_last = pairwise_tree_height(n_pairs % NPY_BUFSIZE);
+            if (h_last > g.H) g.H = h_last;
+        }
+        if (g.H > 7) return fail(BINF_E_UNSUPPORTED, "pairdist_gauss_logp: pairwise tree height %d", g.H);
+        const size_t lds = (size_t)rows * n_beads * 3 * sizeof(double);
+        const dim3 grid((unsigned)((C + rows - 1) / rows));
+        if (rows == 2) pairdist_chi2_rows_kernel<2, 8><<<grid, 256, lds, st>>>(a, g, out);
+        else           pairdist_chi2_rows_kernel<4, 4><<<grid, 256, lds, st>>>(a, g, out);
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return hip_fail(e, "pairdist_gauss_logp");
+        return 0;
+    }
     if (n_beads <= 2048)            // 48 KiB of coordinates fit the static LDS budget
         // fewer rows than ~4 workgroups per CU (and rows long enough to feed them):
         // 16 waves per row instead of 4

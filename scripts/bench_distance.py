@@ -41,11 +41,15 @@ def timed(fn, k):
 
 
 t_g = timed(lambda: lik.gradient(coordinates=x, precision=4.0), 20)
-t_l = timed(lambda: lik.log_prob(coordinates=x, precision=4.0), 20)
+from binf_amd import _native
+_I, _J = lik.forward_model.pair_index(dev)
+_ty = lik.error_model.ys_device(dev)
+t_l = timed(lambda: _native.pairdist_gauss_logp(x, _I, _J, _ty, 4.0), 20)       # every chain summed
+t_lm = timed(lambda: lik.log_prob(coordinates=x, precision=4.0), 20)            # unchanged chains: memo hit
 s = HMCSampler(cond, x, 0.002, L, variable_name='coordinates', rng=DeviceRNG(0, dev))
 t_h = timed(s.sample, 30)
 print(json.dumps({'config': {'chains': C, 'beads': n, 'L': L},
                   'force_kernel_ms': t_g * 1e3, 'pair_interactions_per_s': C * n * n / t_g,
-                  'logp_ms': t_l * 1e3, 'hmc_sample_ms': t_h * 1e3,
+                  'logp_ms': t_l * 1e3, 'logp_memo_hit_ms': t_lm * 1e3, 'hmc_sample_ms': t_h * 1e3,
                   'chain_leapfrog_steps_per_s': C * L / t_h,
                   'acceptance': float(s.acceptance_rate.mean())}))
