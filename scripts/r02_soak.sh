@@ -2,7 +2,7 @@ set -o pipefail
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r02_soak
 mkdir -p $O
-timeout -k 10 420 python3 scripts/fuzz_gauss.py 6000 11 > $O/fuzz_gauss.log 2>&1; echo "fuzz_gauss rc=$?" | tee -a $O/rc.txt; tail -2 $O/fuzz_gauss.log
-timeout -k 10 300 python3 scripts/fuzz_models.py 400 12 > $O/fuzz_models.log 2>&1; echo "fuzz_models rc=$?" | tee -a $O/rc.txt; tail -2 $O/fuzz_models.log
-timeout -k 10 200 python3 scripts/fuzz_reductions.py 4000 13 > $O/fuzz_reductions.log 2>&1; echo "fuzz_reductions rc=$?" | tee -a $O/rc.txt; tail -2 $O/fuzz_reductions.log
+timeout -k 10 420 python3 tests/soak/fuzz_gauss.py 6000 11 > $O/fuzz_gauss.log 2>&1; echo "fuzz_gauss rc=$?" | tee -a $O/rc.txt; tail -2 $O/fuzz_gauss.log
+timeout -k 10 300 python3 tests/soak/fuzz_models.py 400 12 > $O/fuzz_models.log 2>&1; echo "fuzz_models rc=$?" | tee -a $O/rc.txt; tail -2 $O/fuzz_models.log
+timeout -k 10 200 python3 tests/soak/fuzz_reductions.py 4000 13 > $O/fuzz_reductions.log 2>&1; echo "fuzz_reductions rc=$?" | tee -a $O/rc.txt; tail -2 $O/fuzz_reductions.log
 grep -c MISMATCH $O/*.log || true

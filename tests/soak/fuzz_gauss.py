@@ -1,7 +1,7 @@
 """Randomised differential test of the fused Gaussian HMC kernels (all layouts:
 several chains per wave, one wave per chain, several waves per chain, split
 chains, irregular pairwise trees) against the C oracle, bit for bit.
-Development aid / soak test:  python scripts/fuzz_gauss.py [n_cases] [seed]"""
+Development aid / soak test:  python tests/soak/fuzz_gauss.py [n_cases] [seed]"""
 import os
 import sys
 import time
@@ -9,7 +9,7 @@ import time
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from binf_amd import _native
 from binf_amd.pdf import IsotropicGaussian
 from binf_amd.samplers.hmc import HMCSampler

@@ -5,7 +5,7 @@
   sharded launches with chain offsets;
 * binf_jacobian_contract_f64 vs numpy within 1e-10 sum|J||r|, shared and per-chain,
   and batch independence; binf_sum_terms_f64 vs the sequential sum, bit for bit.
-  python scripts/fuzz_gibbs_n.py [n_cases] [seed]"""
+  python tests/soak/fuzz_gibbs_n.py [n_cases] [seed]"""
 import os
 import sys
 import time
@@ -13,7 +13,7 @@ import time
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from binf_amd import _native
 from binf_amd.example.likelihood import POLYVAL, ForwardModel, GaussianErrorModel
 from binf_amd.example.priors import GammaPrior, GaussianPrior

@@ -7,7 +7,7 @@
   for bit, state to 1e-10, same flags);
 * Gibbs-within-HMC sweeps (fused transition + conjugate precision update)
   through the class stack vs the single-chain numpy restatement.
-  python scripts/fuzz_models.py [n_cases] [seed]"""
+  python tests/soak/fuzz_models.py [n_cases] [seed]"""
 import os
 import sys
 import time
@@ -15,7 +15,7 @@ import time
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from binf_amd import _native
 from binf_amd.example.distance import make_distance_likelihood
 from binf_amd.example.likelihood import POLYVAL, ForwardModel, GaussianErrorModel

@@ -1,6 +1,6 @@
 """Randomised differential test of the np.sum-order reductions behind the
 generic tier and the polynomial log-prob, bit for bit against numpy.
-Development aid / soak test:  python scripts/fuzz_reductions.py [n_cases] [seed]"""
+Development aid / soak test:  python tests/soak/fuzz_reductions.py [n_cases] [seed]"""
 import os
 import sys
 import time
@@ -8,7 +8,7 @@ import time
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from binf_amd import _native
 
 dev = torch.device('cuda:0')
