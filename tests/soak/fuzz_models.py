@@ -72,6 +72,17 @@ for case in range(n_cases):
         gs = lik.gradient(coordinates=t(x), precision=2.0).cpu().numpy()
         if not np.array_equal(gb[:C], gs):
             report('pairdist batch independence', n=n, C=C)
+    # chi^2 with two chains per workgroup (>= 2048 chains) vs one: the same bits, and numpy's
+    if n <= 300 and case % 8 == 1:
+        extra = 2047 + int(rs.randint(3))
+        big = np.concatenate([x, x[:1].repeat(extra, 0) + 0.1 * rs.standard_normal((extra, 3 * n))])
+        lb = lik.log_prob(coordinates=t(big), precision=2.0).cpu().numpy()
+        ls = lik.log_prob(coordinates=t(x), precision=2.0).cpu().numpy()
+        if not np.array_equal(lb[:C], ls):
+            report('pairdist log-prob, chains per workgroup', n=n, C=C)
+        c = int(rs.randint(len(big)))
+        if lb[c] != RD.log_prob(big[c], ys, 2.0, n):
+            report('pairdist log-prob vs numpy', n=n, c=c)
     # fused leapfrog vs per-step
     with_prior = bool(rs.randint(2))
     priors = {}
