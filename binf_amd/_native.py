@@ -120,6 +120,13 @@ SIGNATURES = {
     'binf_pairdist_leapfrog_f64': (_i32, [_vp, _vp, _vp, _f64, _vp, _i32, _f64,
                                           _f64, _i32, _f64, _vp, _i32, _i64,
                                           _i64, _i32, _vp]),
+    'binf_pairdist_packed_targets_bytes': (_i64, [_i64]),
+    'binf_pairdist_pack_targets_f64': (_i32, [_vp, _vp, _i64, _vp]),
+    'binf_pairdist_gauss_grad_packed_f64': (_i32, [_vp, _vp, _vp, _f64, _vp, _vp, _i64,
+                                                   _i64, _vp]),
+    'binf_pairdist_leapfrog_packed_f64': (_i32, [_vp, _vp, _vp, _vp, _f64, _vp, _i32, _f64,
+                                                 _f64, _i32, _f64, _vp, _i32, _i64,
+                                                 _i64, _i32, _vp]),
     'binf_rng_uniform_f64': (_i32, [_vp, _i64, ctypes.c_uint64, ctypes.c_uint64,
                                     _i64, _vp]),
     'binf_rng_normal_f64': (_i32, [_vp, _i64, ctypes.c_uint64, ctypes.c_uint64,
@@ -144,7 +151,7 @@ SIGNATURES = {
                                   ctypes.POINTER(_i32), ctypes.POINTER(_i32)]),
 }
 
-ABI_VERSION = 3        # keep in step with BINF_ABI_VERSION (include/binf_hip.h)
+ABI_VERSION = 4        # keep in step with BINF_ABI_VERSION (include/binf_hip.h)
 
 
 def lib():
@@ -500,10 +507,19 @@ def poly_gauss_logp(coeffs, xs, ys, precision):
     return out
 
 
+def new_chi2_memo(C, K, device):
+    """Buffers of the two-entry per-chain chi^2 memo (include/binf_hip.h,
+    binf_poly_gauss_logp_memo_f64): ``(memo_args [2 x C x K] NaN, memo_chi2 [2 x C] NaN,
+    memo_state [2 x C] uint8 zero)``; ``memo_state[0]`` = chains the last call reused."""
+    nan = float('nan')
+    return (torch.full((2, C, K), nan, dtype=torch.float64, device=device),
+            torch.full((2, C), nan, dtype=torch.float64, device=device),
+            torch.zeros((2, C), dtype=torch.uint8, device=device))
+
+
 @_launcher
 def poly_gauss_logp_memo(coeffs, xs, ys, precision, memo):
-    """binf_poly_gauss_logp_memo_f64; ``memo = (memo_coeffs [C x K], memo_chi2 [C],
-    skip [C] uint8)``, NaN-filled before its first use."""
+    """binf_poly_gauss_logp_memo_f64; ``memo = new_chi2_memo(C, K, device)``."""
     C, K = _cd(coeffs)
     N = xs.numel()
     tau, tau_chain = _precision_args(precision, C, coeffs.device)
@@ -512,8 +528,8 @@ def poly_gauss_logp_memo(coeffs, xs, ys, precision, memo):
     rc = lib().binf_poly_gauss_logp_memo_f64(
         dptr(coeffs, numel=C * K, name='coeffs'), dptr(xs, numel=N, name='xs'),
         dptr(ys, numel=N, name='ys'), tau, dptr(tau_chain, numel=C, name='precision'), dptr(out),
-        dptr(mc, numel=C * K, name='memo_coeffs'), dptr(ms, numel=C, name='memo_chi2'),
-        dptr(sk, torch.uint8, C, 'skip'), C, K, N, stream_handle(coeffs.device))
+        dptr(mc, numel=2 * C * K, name='memo_coeffs'), dptr(ms, numel=2 * C, name='memo_chi2'),
+        dptr(sk, torch.uint8, 2 * C, 'memo_state'), C, K, N, stream_handle(coeffs.device))
     check(rc, 'binf_poly_gauss_logp_memo_f64')
     return out
 
@@ -960,8 +976,7 @@ def pairdist_gauss_logp(x, pair_i, pair_j, ys, precision):
 
 @_launcher
 def pairdist_gauss_logp_memo(x, pair_i, pair_j, ys, precision, memo):
-    """binf_pairdist_gauss_logp_memo_f64; ``memo = (memo_x [C x 3n], memo_chi2 [C],
-    skip [C] uint8)``, NaN-filled before its first use."""
+    """binf_pairdist_gauss_logp_memo_f64; ``memo = new_chi2_memo(C, 3 * n_beads, device)``."""
     C, D = _cd(x)
     if D % 3:
         raise ValueError('coordinates must be [n_chains, 3 * n_beads]')
@@ -972,26 +987,49 @@ def pairdist_gauss_logp_memo(x, pair_i, pair_j, ys, precision, memo):
     rc = lib().binf_pairdist_gauss_logp_memo_f64(
         dptr(x, numel=C * D, name='x'), dptr(pair_i, torch.int32, P, 'pair_i'),
         dptr(pair_j, torch.int32, P, 'pair_j'), dptr(ys, numel=P, name='ys'), tau,
-        dptr(tau_chain, numel=C, name='precision'), dptr(out), dptr(mx, numel=C * D, name='memo_x'),
-        dptr(ms, numel=C, name='memo_chi2'), dptr(sk, torch.uint8, C, 'skip'), C, D // 3, P,
+        dptr(tau_chain, numel=C, name='precision'), dptr(out), dptr(mx, numel=2 * C * D, name='memo_x'),
+        dptr(ms, numel=2 * C, name='memo_chi2'), dptr(sk, torch.uint8, 2 * C, 'memo_state'), C, D // 3, P,
         stream_handle(x.device))
     check(rc, 'binf_pairdist_gauss_logp_memo_f64')
     return out
 
 
 @_launcher
-def pairdist_gauss_grad(x, ymat, precision):
+@_launcher
+def pairdist_pack_targets(ymat):
+    """binf_pairdist_pack_targets_f64: the targets in the order the 32..256-bead force
+    kernels hold them (pass as ``packed=`` to the two functions below); None for bead
+    counts that have no packed form."""
+    n = ymat.shape[0]
+    nbytes = lib().binf_pairdist_packed_targets_bytes(n)
+    if nbytes <= 0:
+        return None
+    out = torch.empty(nbytes // 8, dtype=torch.float64, device=ymat.device)
+    rc = lib().binf_pairdist_pack_targets_f64(dptr(ymat, numel=n * n, name='ymat'), dptr(out), n,
+                                              stream_handle(ymat.device))
+    check(rc, 'binf_pairdist_pack_targets_f64')
+    return out
+
+
+def _packed_ptr(packed, n):
+    if packed is None:
+        return None
+    return dptr(packed, numel=lib().binf_pairdist_packed_targets_bytes(n) // 8, name='packed')
+
+
+@_launcher
+def pairdist_gauss_grad(x, ymat, precision, packed=None):
     C, D = _cd(x)
     if D % 3:
         raise ValueError('coordinates must be [n_chains, 3 * n_beads]')
     n = D // 3
     tau, tau_chain = _precision_args(precision, C, x.device)
     out = torch.empty_like(x)
-    rc = lib().binf_pairdist_gauss_grad_f64(
+    rc = lib().binf_pairdist_gauss_grad_packed_f64(
         dptr(x, numel=C * D, name='x'), dptr(ymat, numel=n * n, name='ymat'),
-        tau, dptr(tau_chain, numel=C, name='precision'), dptr(out), C, n,
+        _packed_ptr(packed, n), tau, dptr(tau_chain, numel=C, name='precision'), dptr(out), C, n,
         stream_handle(x.device))
-    check(rc, 'binf_pairdist_gauss_grad_f64')
+    check(rc, 'binf_pairdist_gauss_grad_packed_f64')
     return out
 
 
@@ -1062,7 +1100,7 @@ def rng_fill(kind, out, seed, offset, shape=None, elem_offset=0):
 
 @_launcher
 def pairdist_leapfrog(q, p, ymat, precision, prior, prior_first, timestep,
-                      dt_chain, nsteps, mode=MODE_EXACT):
+                      dt_chain, nsteps, mode=MODE_EXACT, packed=None):
     """In-place leapfrog of (q, p) for the restraint posterior; prior is None
     or (k, x0) of an isotropic Gaussian on the coordinates."""
     C, D = _cd(q)
@@ -1071,11 +1109,11 @@ def pairdist_leapfrog(q, p, ymat, precision, prior, prior_first, timestep,
     n = D // 3
     tau, tau_chain = _precision_args(precision, C, q.device)
     k, x0 = prior if prior is not None else (0.0, 0.0)
-    rc = lib().binf_pairdist_leapfrog_f64(
+    rc = lib().binf_pairdist_leapfrog_packed_f64(
         dptr(q, numel=C * D, name='q'), dptr(p, numel=C * D, name='p'),
-        dptr(ymat, numel=n * n, name='ymat'), tau,
+        dptr(ymat, numel=n * n, name='ymat'), _packed_ptr(packed, n), tau,
         dptr(tau_chain, numel=C, name='precision'), int(prior is not None),
         float(k), float(x0), int(bool(prior_first)), float(timestep),
         dptr(dt_chain, numel=C, name='dt_chain'), int(nsteps), C, n, int(mode),
         stream_handle(q.device))
-    check(rc, 'binf_pairdist_leapfrog_f64')
+    check(rc, 'binf_pairdist_leapfrog_packed_f64')

@@ -237,7 +237,7 @@ pairdist_chi2_rows_kernel(const PairArgs a, const RowGeom g, double *out)
         if (all_skip) {
             if (threadIdx.x < ROWS && row0 + threadIdx.x < g.C) {
                 const int64_t row = row0 + threadIdx.x;
-                out[row] = row_result(g, row, g.memo_sum[row]);
+                out[row] = row_result(g, row, *row_memo_slot(g, row));
             }
             return;
         }
@@ -294,7 +294,7 @@ pairdist_chi2_rows_kernel(const PairArgs a, const RowGeom g, double *out)
 #pragma unroll
         for (int q = 0; q < ROWS; ++q) {
             if (row0 + q >= g.C) break;
-            if (g.memo_sum) g.memo_sum[row0 + q] = total[q];
+            if (g.memo_sum) *row_memo_slot(g, row0 + q) = total[q];
             out[row0 + q] = row_result(g, row0 + q, total[q]);
         }
     }
@@ -495,6 +495,7 @@ struct PairLeapArgs {
     double *q;               // [C x 3n] in/out
     double *p;               // [C x 3n] in/out
     const double *ymat;      // [n x n]
+    const double *ypk;       // sym kernels: the targets in lane order (sym_pack_targets_kernel), or null
     const double *tau_chain; // [C] or null
     const double *dt_chain;  // [C] or null
     double tau;
@@ -713,11 +714,19 @@ __device__ inline SymRole sym_role()
 
 // The lane's 32 target distances y[k] = ymat[64 bi + l][64 bj + (l + off + k) mod 64]
 // (0 where a bead does not exist), and the bit mask of its pairs that do exist.
-template <int NBLK>
+template <int NBLK, bool PK>
 __device__ inline void sym_load_targets(double (&y)[SYM_STEPS], unsigned &live, SymShared<NBLK> &sh,
-                                        const double *ymat, int n, const SymRole &ro)
+                                        const double *ymat, const double *ypk, int n,
+                                        const SymRole &ro)
 {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if constexpr (PK) {
+        // packed by sym_pack_targets_kernel: step k of wave w, lane l at ypk[(32 w + k) 64 + l]
+        // -- 32 independent coalesced loads, no exchange through LDS
+        const double *src = ypk + (int64_t)wave * SYM_STEPS * 64 + lane;
+#pragma unroll
+        for (int k = 0; k < SYM_STEPS; ++k) y[k] = src[k * 64];
+    } else {
     // The tile goes through a scratch area of the wave's own, SYM_ROWS rows at a
     // time (lane = column on the way in: coalesced 512-byte rows; lane = row on the
     // way out), the next rows' loads in flight meanwhile.  No other wave touches the
@@ -750,6 +759,7 @@ __device__ inline void sym_load_targets(double (&y)[SYM_STEPS], unsigned &live, 
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
     __syncthreads();                     // the scratch shares its LDS with the partial sums
+    }
     live = 0;
     const int i = 64 * ro.bi + lane;
 #pragma unroll
@@ -757,6 +767,22 @@ __device__ inline void sym_load_targets(double (&y)[SYM_STEPS], unsigned &live, 
         const int j = 64 * ro.bj + ((lane + ro.off + k) & 63);
         const bool ok = i < n && j < n && !(ro.diag && k == SYM_STEPS - 1 && lane >= 32);
         live |= ok ? (1u << k) : 0u;
+    }
+}
+
+// The targets in the order the waves of the sym kernels hold them: a function of
+// (ymat, n) alone, written once per model and read by every launch after that
+// (256 beads: 256 KiB instead of a 512 KiB matrix walked tile by tile through LDS).
+template <int NBLK>
+__global__ void __launch_bounds__(1024) sym_pack_targets_kernel(const double *ymat, double *ypk, int n)
+{
+    const SymRole ro = sym_role<NBLK>();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int i = 64 * ro.bi + lane;
+    for (int k = 0; k < SYM_STEPS; ++k) {
+        const int j = 64 * ro.bj + ((lane + ro.off + k) & 63);
+        ypk[((int64_t)wave * SYM_STEPS + k) * 64 + lane] =
+            (i < n && j < n) ? ymat[(int64_t)i * n + j] : 0.0;
     }
 }
 
@@ -832,17 +858,17 @@ __device__ inline void sym_publish(SymShared<NBLK> &sh, int t, const double (&q)
 // holds at a time (126 VGPRs: 16 waves per CU), so with more chains than that the
 // target load is paid once per workgroup, not once per chain.
 // __launch_bounds__(1024) whatever NBLK: it is what keeps the kernel within 128 VGPRs.
-template <bool FULL, int NBLK>
+template <bool FULL, int NBLK, bool PK>
 __global__ void __launch_bounds__(1024)
-pairdist_grad_sym_kernel(const double *x, const double *ymat, double tau, const double *tau_chain,
-                         double *out, int32_t n_beads, int64_t n_chains)
+pairdist_grad_sym_kernel(const double *x, const double *ymat, const double *ypk, double tau,
+                         const double *tau_chain, double *out, int32_t n_beads, int64_t n_chains)
 {
     __shared__ SymShared<NBLK> sh;
     const int n = n_beads, t = threadIdx.x;
     const SymRole ro = sym_role<NBLK>();
     double y[SYM_STEPS];
     unsigned live;
-    sym_load_targets<NBLK>(y, live, sh, ymat, n, ro);
+    sym_load_targets<NBLK, PK>(y, live, sh, ymat, ypk, n, ro);
     for (int64_t c = blockIdx.x; c < n_chains; c += gridDim.x) {
         const double *xc = x + c * 3 * (int64_t)n;
         if (t < 64 * NBLK) {
@@ -866,7 +892,7 @@ pairdist_grad_sym_kernel(const double *x, const double *ymat, double tau, const 
 
 // The whole _leapfrog() (binf/samplers/hmc.py:92-125) in one launch with the
 // scheme above: owner threads keep q and p of their bead in registers.
-template <bool FMA, bool FULL, int NBLK>
+template <bool FMA, bool FULL, int NBLK, bool PK>
 __global__ void __launch_bounds__(1024) pairdist_leapfrog_sym_kernel(const PairLeapArgs a)
 {
     __shared__ SymShared<NBLK> sh;
@@ -875,7 +901,7 @@ __global__ void __launch_bounds__(1024) pairdist_leapfrog_sym_kernel(const PairL
     const bool owner = t < n;
     double y[SYM_STEPS];
     unsigned live;
-    sym_load_targets<NBLK>(y, live, sh, a.ymat, n, ro);
+    sym_load_targets<NBLK, PK>(y, live, sh, a.ymat, a.ypk, n, ro);
     for (int64_t c = blockIdx.x; c < a.n_chains; c += gridDim.x) {
         double *qc = a.q + c * 3 * (int64_t)n;
         double *pc = a.p + c * 3 * (int64_t)n;
@@ -963,17 +989,18 @@ static unsigned sym_grid(int64_t C, int nblk)
 }
 
 template <int NBLK>
-static void launch_grad_sym(const double *x, const double *ymat, double precision,
+static void launch_grad_sym(const double *x, const double *ymat, const double *ypk, double precision,
                             const double *precision_chain, double *out, int64_t C, int64_t n,
                             hipStream_t st)
 {
     const dim3 grid(sym_grid(C, NBLK)), block(64 * NBLK * NBLK);
-    if (n == 64 * NBLK)
-        pairdist_grad_sym_kernel<true, NBLK><<<grid, block, 0, st>>>(x, ymat, precision, precision_chain,
-                                                                     out, (int32_t)n, C);
-    else
-        pairdist_grad_sym_kernel<false, NBLK><<<grid, block, 0, st>>>(x, ymat, precision, precision_chain,
-                                                                      out, (int32_t)n, C);
+    const bool full = n == 64 * NBLK;
+#define GRAD_SYM(FULLV, PKV) \
+    pairdist_grad_sym_kernel<FULLV, NBLK, PKV><<<grid, block, 0, st>>>(x, ymat, ypk, precision, \
+                                                                       precision_chain, out, (int32_t)n, C)
+    if (ypk) { if (full) GRAD_SYM(true, true); else GRAD_SYM(false, true); }
+    else     { if (full) GRAD_SYM(true, false); else GRAD_SYM(false, false); }
+#undef GRAD_SYM
 }
 
 template <int NBLK>
@@ -981,13 +1008,14 @@ static void launch_leapfrog_sym(const PairLeapArgs &a, bool fma, hipStream_t st)
 {
     const dim3 grid(sym_grid(a.n_chains, NBLK)), block(64 * NBLK * NBLK);
     const bool full = a.n_beads == 64 * NBLK;
-    if (fma) {
-        if (full) pairdist_leapfrog_sym_kernel<true, true, NBLK><<<grid, block, 0, st>>>(a);
-        else      pairdist_leapfrog_sym_kernel<true, false, NBLK><<<grid, block, 0, st>>>(a);
-    } else {
-        if (full) pairdist_leapfrog_sym_kernel<false, true, NBLK><<<grid, block, 0, st>>>(a);
-        else      pairdist_leapfrog_sym_kernel<false, false, NBLK><<<grid, block, 0, st>>>(a);
-    }
+#define LEAP_SYM(FMAV, FULLV) \
+    do { \
+        if (a.ypk) pairdist_leapfrog_sym_kernel<FMAV, FULLV, NBLK, true><<<grid, block, 0, st>>>(a); \
+        else       pairdist_leapfrog_sym_kernel<FMAV, FULLV, NBLK, false><<<grid, block, 0, st>>>(a); \
+    } while (0)
+    if (fma) { if (full) LEAP_SYM(true, true); else LEAP_SYM(true, false); }
+    else     { if (full) LEAP_SYM(false, true); else LEAP_SYM(false, false); }
+#undef LEAP_SYM
 }
 
 extern "C" int32_t binf_pairdist_forward_f64(const double *x, const int32_t *pair_i,
@@ -1087,7 +1115,8 @@ static int32_t pairdist_logp_run(const double *x, const int32_t *pair_i, const i
         if (C > 0x7fffffffLL || n_pairs > 0x7fffffffLL)
             return fail(BINF_E_UNSUPPORTED, "pairdist_gauss_logp: too large");
         RowGeom g;
-        g.C = C; g.D = (int32_t)n_pairs; g.scale = 1.0; g.fin = fin; g.skip = skip; g.memo_sum = memo_chi2;
+        g.C = C; g.D = (int32_t)n_pairs; g.scale = 1.0; g.fin = fin;
+        g.skip = skip; g.way = skip ? skip + C : nullptr; g.memo_sum = memo_chi2;
         g.H = pairwise_tree_height(n_pairs < NPY_BUFSIZE ? n_pairs : NPY_BUFSIZE);
         if (n_pairs > NPY_BUFSIZE && n_pairs % NPY_BUFSIZE != 0) {
             const int32_t h_last = pairwise_tree_height(n_pairs % NPY_BUFSIZE);
@@ -1119,11 +1148,53 @@ static int32_t pairdist_logp_run(const double *x, const int32_t *pair_i, const i
     return 0;
 }
 
+static bool sym_serves(int64_t n_beads)
+{
+    return n_beads >= SYM_MIN_BEADS && n_beads <= SYM_MAX_BEADS && sym_enabled();
+}
+
+extern "C" int64_t binf_pairdist_packed_targets_bytes(int64_t n_beads)
+{
+    if (!sym_serves(n_beads)) return 0;
+    const int64_t nblk = (n_beads + 63) / 64;
+    return nblk * nblk * SYM_STEPS * 64 * (int64_t)sizeof(double);
+}
+
+extern "C" int32_t binf_pairdist_pack_targets_f64(const double *ymat, double *packed,
+                                                  int64_t n_beads, void *stream)
+{
+    if (n_beads < 1) return fail(BINF_E_ARG, "pairdist_pack_targets: bad size");
+    if (!sym_serves(n_beads))
+        return fail(BINF_E_UNSUPPORTED, "pairdist_pack_targets: n_beads=%lld has no packed form "
+                    "(binf_pairdist_packed_targets_bytes is 0)", (long long)n_beads);
+    if (!ymat || !packed) return fail(BINF_E_ARG, "pairdist_pack_targets: null buffer");
+    hipStream_t st = (hipStream_t)stream;
+    const int nblk = (int)((n_beads + 63) / 64);
+    const dim3 block(64 * nblk * nblk);
+    if (nblk == 1)      sym_pack_targets_kernel<1><<<1, block, 0, st>>>(ymat, packed, (int)n_beads);
+    else if (nblk == 2) sym_pack_targets_kernel<2><<<1, block, 0, st>>>(ymat, packed, (int)n_beads);
+    else if (nblk == 3) sym_pack_targets_kernel<3><<<1, block, 0, st>>>(ymat, packed, (int)n_beads);
+    else                sym_pack_targets_kernel<4><<<1, block, 0, st>>>(ymat, packed, (int)n_beads);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "pairdist_pack_targets launch");
+    return 0;
+}
+
 extern "C" int32_t binf_pairdist_gauss_grad_f64(const double *x, const double *ymat,
                                                 double precision,
                                                 const double *precision_chain,
                                                 double *out, int64_t C,
                                                 int64_t n_beads, void *stream)
+{
+    return binf_pairdist_gauss_grad_packed_f64(x, ymat, nullptr, precision, precision_chain, out, C,
+                                               n_beads, stream);
+}
+
+extern "C" int32_t binf_pairdist_gauss_grad_packed_f64(const double *x, const double *ymat,
+                                                       const double *packed, double precision,
+                                                       const double *precision_chain,
+                                                       double *out, int64_t C,
+                                                       int64_t n_beads, void *stream)
 {
     if (C < 0 || n_beads < 1) return fail(BINF_E_ARG, "pairdist_gauss_grad: bad sizes");
     if (C == 0) return 0;
@@ -1132,12 +1203,12 @@ extern "C" int32_t binf_pairdist_gauss_grad_f64(const double *x, const double *y
         return fail(BINF_E_UNSUPPORTED, "pairdist_gauss_grad: too large");
     const size_t lds = (size_t)n_beads * 3 * sizeof(double);
     hipStream_t gst = (hipStream_t)stream;
-    if (n_beads >= SYM_MIN_BEADS && n_beads <= SYM_MAX_BEADS && sym_enabled()) {
+    if (sym_serves(n_beads)) {
         const int nblk = (int)((n_beads + 63) / 64);
-        if (nblk == 1)      launch_grad_sym<1>(x, ymat, precision, precision_chain, out, C, n_beads, gst);
-        else if (nblk == 2) launch_grad_sym<2>(x, ymat, precision, precision_chain, out, C, n_beads, gst);
-        else if (nblk == 3) launch_grad_sym<3>(x, ymat, precision, precision_chain, out, C, n_beads, gst);
-        else                launch_grad_sym<4>(x, ymat, precision, precision_chain, out, C, n_beads, gst);
+        if (nblk == 1)      launch_grad_sym<1>(x, ymat, packed, precision, precision_chain, out, C, n_beads, gst);
+        else if (nblk == 2) launch_grad_sym<2>(x, ymat, packed, precision, precision_chain, out, C, n_beads, gst);
+        else if (nblk == 3) launch_grad_sym<3>(x, ymat, packed, precision, precision_chain, out, C, n_beads, gst);
+        else                launch_grad_sym<4>(x, ymat, packed, precision, precision_chain, out, C, n_beads, gst);
     }
     else if (n_beads <= 1024 && lanes_per_bead(C) == 4)
         pairdist_grad4_kernel<<<dim3((unsigned)C), 1024, lds, (hipStream_t)stream>>>(
@@ -1160,6 +1231,19 @@ extern "C" int32_t binf_pairdist_leapfrog_f64(double *q, double *p, const double
                                               const double *dt_chain, int32_t nsteps, int64_t C,
                                               int64_t n_beads, int32_t mode, void *stream)
 {
+    return binf_pairdist_leapfrog_packed_f64(q, p, ymat, nullptr, precision, precision_chain, has_prior,
+                                             prior_k, prior_x0, prior_first, timestep, dt_chain, nsteps,
+                                             C, n_beads, mode, stream);
+}
+
+extern "C" int32_t binf_pairdist_leapfrog_packed_f64(double *q, double *p, const double *ymat,
+                                                     const double *packed, double precision,
+                                                     const double *precision_chain,
+                                                     int32_t has_prior, double prior_k, double prior_x0,
+                                                     int32_t prior_first, double timestep,
+                                                     const double *dt_chain, int32_t nsteps, int64_t C,
+                                                     int64_t n_beads, int32_t mode, void *stream)
+{
     if (C < 0 || n_beads < 1 || nsteps < 1)
         return fail(BINF_E_ARG, "pairdist_leapfrog: need C>=0, n_beads>=1, nsteps>=1");
     if (mode != BINF_MODE_EXACT && mode != BINF_MODE_FMA)
@@ -1170,7 +1254,7 @@ extern "C" int32_t binf_pairdist_leapfrog_f64(double *q, double *p, const double
         return fail(BINF_E_UNSUPPORTED, "pairdist_leapfrog: n_beads=%lld > 1024 not covered by the fused kernel", (long long)n_beads);
     if (C > 0x7fffffffLL) return fail(BINF_E_UNSUPPORTED, "pairdist_leapfrog: too many chains");
     PairLeapArgs a;
-    a.q = q; a.p = p; a.ymat = ymat; a.tau_chain = precision_chain; a.dt_chain = dt_chain;
+    a.q = q; a.p = p; a.ymat = ymat; a.ypk = packed; a.tau_chain = precision_chain; a.dt_chain = dt_chain;
     a.tau = precision; a.timestep = timestep; a.prior_k = prior_k; a.prior_x0 = prior_x0;
     a.has_prior = has_prior ? 1 : 0; a.prior_first = prior_first ? 1 : 0;
     a.nsteps = nsteps; a.n_beads = (int32_t)n_beads; a.n_chains = C;
@@ -1181,7 +1265,7 @@ extern "C" int32_t binf_pairdist_leapfrog_f64(double *q, double *p, const double
     const bool four = lanes_per_bead(C) == 4;
     // positions; four tiles x four lanes keep the momentum there as well
     const size_t lds = (size_t)n_beads * 3 * sizeof(double) * ((nb >= 4 && four) ? 2 : 1);
-    if (n_beads >= SYM_MIN_BEADS && n_beads <= SYM_MAX_BEADS && sym_enabled()) {
+    if (sym_serves(n_beads)) {
         const int nblk = (int)((n_beads + 63) / 64);
         if (nblk == 1)      launch_leapfrog_sym<1>(a, fma, st);
         else if (nblk == 2) launch_leapfrog_sym<2>(a, fma, st);

@@ -73,11 +73,18 @@ struct RowGeom {
     int32_t H;       // largest pairwise tree height among the row's 8192-element chunks
     double scale;
     GaussFinish fin;
-    // per-row memo of the raw sum (block kernel only): a row whose skip flag is set takes
-    // memo_sum[row] instead of being summed again; every row summed leaves its sum there
-    const uint8_t *skip;
-    double *memo_sum;
+    // per-row memo of the raw sum (block kernel only), two entries per row: a row whose skip
+    // flag is set takes memo_sum[way[row]][row] instead of being summed again; every row
+    // summed leaves its sum there (row_memo_check_kernel sets skip and way)
+    const uint8_t *skip;     // [C]
+    const uint8_t *way;      // [C]
+    double *memo_sum;        // [2][C]
 };
+
+__device__ inline double *row_memo_slot(const RowGeom &g, int64_t row)
+{
+    return g.memo_sum + (int64_t)g.way[row] * g.C + row;
+}
 
 __device__ inline double row_result(const RowGeom &g, int64_t row, double sum)
 {
@@ -142,7 +149,7 @@ row_reduce_block_kernel(const ARGS args, const RowGeom g, double *out)
     const int group = threadIdx.x >> 3;      // GROUPS groups of 8 lanes
     const int64_t row = blockIdx.x;
     if (g.skip && g.skip[row]) {                 // workgroup-uniform
-        if (threadIdx.x == 0) out[row] = row_result(g, row, g.memo_sum[row]);
+        if (threadIdx.x == 0) out[row] = row_result(g, row, *row_memo_slot(g, row));
         return;
     }
     if constexpr (STAGED) {
@@ -182,7 +189,7 @@ row_reduce_block_kernel(const ARGS args, const RowGeom g, double *out)
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        if (g.memo_sum) g.memo_sum[row] = total;
+        if (g.memo_sum) *row_memo_slot(g, row) = total;
         out[row] = row_result(g, row, total);
     }
 }
@@ -193,7 +200,7 @@ static int32_t row_reduce_launch(const ARGS &args, int64_t C, int64_t D,
                                  bool force_block, const char *what,
                                  size_t staged_bytes = 0, bool wide = false,
                                  const GaussFinish *fin = nullptr,
-                                 const uint8_t *skip = nullptr, double *memo_sum = nullptr)
+                                 const uint8_t *memo_state = nullptr, double *memo_sum = nullptr)
 {
     if (C > 0x7fffffffLL || D > 0x7fffffffLL)
         return fail(BINF_E_UNSUPPORTED, "%s: too large", what);
@@ -201,7 +208,8 @@ static int32_t row_reduce_launch(const ARGS &args, int64_t C, int64_t D,
     g.C = C; g.D = (int32_t)D; g.scale = scale;
     if (fin) g.fin = *fin;
     else { g.fin.on = 0; g.fin.tau = 1.0; g.fin.tau_chain = nullptr; g.fin.n_data = 0.0; g.fin.minus = nullptr; }
-    g.skip = skip; g.memo_sum = memo_sum;      // honoured by the block kernel (force_block)
+    // honoured by the block kernel (force_block); memo_state = [skip [C], way [C]]
+    g.skip = memo_state; g.way = memo_state ? memo_state + C : nullptr; g.memo_sum = memo_sum;
     g.H = pairwise_tree_height(D < NPY_BUFSIZE ? D : NPY_BUFSIZE);
     if (D > NPY_BUFSIZE && D % NPY_BUFSIZE != 0) {
         const int32_t h_last = pairwise_tree_height(D % NPY_BUFSIZE);
@@ -228,33 +236,52 @@ static int32_t row_reduce_launch(const ARGS &args, int64_t C, int64_t D,
 
 // ---- per-row memo of a reduction whose value depends on a small per-row argument vector
 // (the chi^2 of a likelihood as a function of a chain's coefficients / coordinates).
-// One wave per row: lane k compares argument k BIT FOR BIT with the memo's copy; a row
-// that differs anywhere gets skip = 0 and its arguments copied into the memo (the block
-// reduction that follows stores the new sum in RowGeom::memo_sum), a row that is the same
-// gets skip = 1 and is not summed again.  Content-checked on the device: no tensor
-// identities, versions or host synchronisation involved.
+// TWO entries per row: HMCSampler.sample() evaluates the state (E_before, hmc.py:148) and
+// the proposal (E_after, hmc.py:150), and the next call's state is one of the two --
+// whichever way the acceptance test went, it is in the memo.
+// One wave per row: lane k compares argument k BIT FOR BIT with both entries' copies.  A
+// row that equals one gets skip = 1 and way = that entry; a row that equals neither gets
+// skip = 0, way = the entry NOT used last, and its arguments copied there (the block
+// reduction that follows stores the new sum in memo_sum[way]).  Content-checked on the
+// device: no tensor identities, versions or host synchronisation involved.
+// memo_arg [2][C][K], state [2][C] = skip flags, then ways.
 template <int UNUSED = 0>
 __global__ void __launch_bounds__(256)
-row_memo_check_kernel(const double *arg, double *memo_arg, uint8_t *skip, int64_t C, int32_t K)
+row_memo_check_kernel(const double *arg, double *memo_arg, uint8_t *state, int64_t C, int32_t K)
 {
     const int lane = threadIdx.x & 63;
     const int64_t c = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (c >= C) return;
-    bool same = true;
-    for (int k = lane; k < K; k += 64)
-        same = same && (__double_as_longlong(arg[c * K + k]) == __double_as_longlong(memo_arg[c * K + k]));
-    const bool all_same = __all(same);
-    if (!all_same)
-        for (int k = lane; k < K; k += 64) memo_arg[c * K + k] = arg[c * K + k];
-    if (lane == 0) skip[c] = all_same ? 1 : 0;
+    const double *a = arg + c * K;
+    double *m0 = memo_arg + c * K, *m1 = memo_arg + (C + c) * K;
+    bool same0 = true, same1 = true;
+    for (int k = lane; k < K; k += 64) {
+        const long long bits = __double_as_longlong(a[k]);
+        same0 = same0 && (bits == __double_as_longlong(m0[k]));
+        same1 = same1 && (bits == __double_as_longlong(m1[k]));
+    }
+    const bool hit0 = __all(same0), hit1 = __all(same1);
+    uint8_t *skip = state, *way = state + C;
+    int w;
+    if (hit0 || hit1) {
+        w = hit0 ? 0 : 1;
+    } else {
+        w = 1 - (way[c] & 1);
+        double *m = w ? m1 : m0;
+        for (int k = lane; k < K; k += 64) m[k] = a[k];
+    }
+    if (lane == 0) {
+        skip[c] = (hit0 || hit1) ? 1 : 0;
+        way[c] = (uint8_t)w;
+    }
 }
 
-static int32_t row_memo_check(const double *arg, double *memo_arg, uint8_t *skip, int64_t C,
+static int32_t row_memo_check(const double *arg, double *memo_arg, uint8_t *state, int64_t C,
                               int64_t K, hipStream_t st, const char *what)
 {
     if (C > 0x7fffffffLL * 4 || K > 0x7fffffffLL)
         return fail(BINF_E_UNSUPPORTED, "%s: too large", what);
-    row_memo_check_kernel<><<<dim3((unsigned)((C + 3) / 4)), 256, 0, st>>>(arg, memo_arg, skip, C, (int32_t)K);
+    row_memo_check_kernel<><<<dim3((unsigned)((C + 3) / 4)), 256, 0, st>>>(arg, memo_arg, state, C, (int32_t)K);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, what);
     return 0;

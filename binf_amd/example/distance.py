@@ -88,6 +88,15 @@ class DistanceErrorModel(GaussianErrorModel):
             self._ymat[device] = torch.from_numpy(m).to(device)
         return self._ymat[device]
 
+    def ypacked_device(self, device):
+        """The targets in the order the 32..256-bead force kernels hold them
+        (binf_pairdist_pack_targets_f64), made once per device; None for other
+        bead counts."""
+        key = ('packed', device)
+        if key not in self._ymat:
+            self._ymat[key] = _native.pairdist_pack_targets(self.ymat_device(device))
+        return self._ymat[key]
+
     def clone(self):
         copy = self.__class__(self.ys, self.n_beads)
         copy._dev = self._dev
@@ -141,10 +150,7 @@ def _chi2_memo(I, ys, shape):
     key = (id(I), id(ys), C, D, _native.stream_handle(ys.device))
     m = _memos.get(key)
     if m is None or m[0] is not I or m[1] is not ys:
-        nan = float('nan')
-        m = (I, ys, (torch.full((C, D), nan, dtype=torch.float64, device=ys.device),
-                     torch.full((C,), nan, dtype=torch.float64, device=ys.device),
-                     torch.zeros(C, dtype=torch.uint8, device=ys.device)))
+        m = (I, ys, _native.new_chi2_memo(C, D, ys.device))
         while len(_memos) >= 8:
             _memos.pop(next(iter(_memos)))
         _memos[key] = m
@@ -162,5 +168,5 @@ def native_gradient(likelihood, fwm, em, fwm_vars, em_vars):
         return None
     x2 = x if x.dim() == 2 else x.reshape(1, -1)
     out = _native.pairdist_gauss_grad(x2.contiguous(), em.ymat_device(x.device),
-                                      em_vars['precision'])
+                                      em_vars['precision'], packed=em.ypacked_device(x.device))
     return out if x.dim() == 2 else out.reshape(-1)

@@ -47,17 +47,14 @@ _memos = {}
 
 
 def _chi2_memo(xs, ys, shape):
-    """(memo_coeffs, memo_chi2, skip) for this data set, batch shape and stream; the
+    """(memo_coeffs, memo_chi2, memo_state) for this data set, batch shape and stream; the
     key holds the data tensors themselves (clones of a model share them), so new data
     get a new memo."""
     C, K = shape
     key = (id(xs), id(ys), C, K, _native.stream_handle(xs.device))
     m = _memos.get(key)
     if m is None or m[0] is not xs or m[1] is not ys:
-        nan = float('nan')
-        m = (xs, ys, (torch.full((C, K), nan, dtype=torch.float64, device=xs.device),
-                      torch.full((C,), nan, dtype=torch.float64, device=xs.device),
-                      torch.zeros(C, dtype=torch.uint8, device=xs.device)))
+        m = (xs, ys, _native.new_chi2_memo(C, K, xs.device))
         while len(_memos) >= 8:
             _memos.pop(next(iter(_memos)))
         _memos[key] = m

@@ -578,8 +578,10 @@ class HMCSampler(object):
                 and q2.shape[1] // 3 <= 1024:
             # the whole integration in one launch (bit-identical to the loop)
             _, em, precision, prior, prior_first = leap
+            packed = getattr(em, 'ypacked_device', None)
             _native.pairdist_leapfrog(q2, p2, em.ymat_device(q2.device), precision,
-                                      prior, prior_first, dt, dtc, nsteps, mode)
+                                      prior, prior_first, dt, dtc, nsteps, mode,
+                                      packed=packed(q2.device) if packed is not None else None)
             return q, p
         if leap is not None and leap[0] == 'poly' and q2.is_cuda and q2.shape[1] <= 64:
             # gradient, partial-sum reduction, kick and drift of every step in one launch

@@ -36,8 +36,12 @@ extern "C" {
  *    per chain is now the opt-in BINF_MODE_LANE_PER_CHAIN); binf_gibbs_poly_sample_n_f64,
  *    binf_jacobian_contract_f64, binf_sum_terms_f64, binf_poly_leapfrog_f64,
  *    binf_poly_gauss_logp_memo_f64, binf_pairdist_gauss_logp_memo_f64,
- *    binf_hmc_sample_n_gauss_big_f64 / _rng_f64. */
-#define BINF_ABI_VERSION 3
+ *    binf_hmc_sample_n_gauss_big_f64 / _rng_f64.
+ * 4: binf_pairdist_packed_targets_bytes, binf_pairdist_pack_targets_f64,
+ *    binf_pairdist_gauss_grad_packed_f64, binf_pairdist_leapfrog_packed_f64; the chi^2
+ *    memos of binf_poly_gauss_logp_memo_f64 / binf_pairdist_gauss_logp_memo_f64 hold two
+ *    entries per chain (their buffers are twice the ABI 3 size). */
+#define BINF_ABI_VERSION 4
 
 #define BINF_E_ARG        (-1)  /* null pointer / negative size / bad flag    */
 #define BINF_E_UNSUPPORTED (-2) /* shape outside what the kernels cover       */
@@ -380,22 +384,26 @@ int32_t binf_poly_gauss_logp_f64(const double *coeffs, const double *xs,
 
 /* The same log-prob with a per-chain MEMO of chi^2 = np.sum((polyval - ys)**2), the
  * expensive part (a Horner pass over all N data points per chain), which depends on the
- * coefficients alone.  memo_coeffs [C x K] / memo_chi2 [C] (caller-owned, device; fill
- * both with NaN before the first use) hold the coefficients a stored chi^2 belongs to:
- * a chain whose coefficients equal the memo's BIT FOR BIT takes the stored chi^2, every
- * other chain is summed and leaves its coefficients and chi^2 in the memo.  The check
- * runs on the device, chain by chain (skip [C]: scratch, 1 = reused) -- no tensor
- * identities, versions or host synchronisation are involved, so the results are those of
+ * coefficients alone.  The memo has TWO entries per chain (HMCSampler.sample() evaluates
+ * the state and the proposal, hmc.py:148,150, and the next call's state is one of the two
+ * whichever way the acceptance test went): memo_coeffs [2 x C x K] / memo_chi2 [2 x C]
+ * (caller-owned, device; fill both with NaN before the first use) hold the coefficients
+ * a stored chi^2 belongs to; memo_state [2 x C] bytes (zero before the first use) is the
+ * memo's bookkeeping: [0..C) 1 = this call reused a stored chi^2 for the chain, [C..2C)
+ * the entry it used or refilled.  A chain whose coefficients equal one entry's BIT FOR BIT
+ * takes that entry's chi^2; every other chain is summed and replaces the entry it did not
+ * use last.  The check runs on the device, chain by chain -- no tensor identities,
+ * versions or host synchronisation are involved, so the results are those of
  * binf_poly_gauss_logp_f64 bit for bit whatever happened to the buffers in between.
  * In a Gibbs sweep (binf/samplers/gibbs.py:146-149) the log-prob is asked for the
- * proposal (hmc.py:150), again for the same coefficients at precision = 1
+ * proposal (hmc.py:150), again for the sweep's new coefficients at precision = 1
  * (binf/example/samplers.py:34-41) and once more as the next sweep's E_before
- * (hmc.py:148): one Horner pass instead of three. */
+ * (hmc.py:148): one Horner pass instead of three, accepted or not. */
 int32_t binf_poly_gauss_logp_memo_f64(const double *coeffs, const double *xs,
                                       const double *ys, double precision,
                                       const double *precision_chain, double *out,
                                       double *memo_coeffs, double *memo_chi2,
-                                      uint8_t *skip, int64_t C, int64_t K, int64_t N,
+                                      uint8_t *memo_state, int64_t C, int64_t K, int64_t N,
                                       void *stream);
 
 /* Likelihood._evaluate_gradient (binf/pdf/likelihoods.py:148-155) for the same
@@ -669,15 +677,16 @@ int32_t binf_pairdist_gauss_logp_f64(const double *x, const int32_t *pair_i,
                                      double *out, int64_t C, int64_t n_beads,
                                      int64_t n_pairs, void *stream);
 
-/* The same with a per-chain memo of chi^2 (it depends on the chain's coordinates alone):
- * memo_x [C x 3 n_beads] / memo_chi2 [C] / skip [C] as in binf_poly_gauss_logp_memo_f64 --
- * HMCSampler.sample() asks for the log-prob of the state it ended the last transition
- * with again as E_before (binf/samplers/hmc.py:148). */
+/* The same with a two-entry per-chain memo of chi^2 (it depends on the chain's coordinates
+ * alone): memo_x [2 x C x 3 n_beads] / memo_chi2 [2 x C] / memo_state [2 x C] as in
+ * binf_poly_gauss_logp_memo_f64 -- HMCSampler.sample() asks for the log-prob of the state
+ * it ended the last transition with again as E_before (binf/samplers/hmc.py:148); that
+ * state is the last proposal or the state before it, and both are in the memo. */
 int32_t binf_pairdist_gauss_logp_memo_f64(const double *x, const int32_t *pair_i,
                                           const int32_t *pair_j, const double *ys,
                                           double precision, const double *precision_chain,
                                           double *out, double *memo_x, double *memo_chi2,
-                                          uint8_t *skip, int64_t C, int64_t n_beads,
+                                          uint8_t *memo_state, int64_t C, int64_t n_beads,
                                           int64_t n_pairs, void *stream);
 
 /* Energy gradient of the Gaussian restraint likelihood,
@@ -694,6 +703,23 @@ int32_t binf_pairdist_gauss_grad_f64(const double *x, const double *ymat,
                                      double *out, int64_t C, int64_t n_beads,
                                      void *stream);
 
+/* The targets of the 32..256-bead force kernels in the order their waves hold them
+ * (every unordered pair once, 32 targets per lane in registers): a function of
+ * (ymat, n_beads) alone.  Packed once per model, the `_packed_` entry points below
+ * read 32 coalesced values per lane at the start of a launch instead of walking the
+ * [n x n] matrix tile by tile through LDS (once per workgroup: ~10 of the 175 us of
+ * a 20-step trajectory at 256 chains).  binf_pairdist_packed_targets_bytes: size of
+ * the packed form, 0 for bead counts the one-sided kernels serve (then there is
+ * nothing to pack and `packed` must be null).  The results are the same bits with
+ * and without `packed`; `packed` must have been made from the same ymat. */
+int64_t binf_pairdist_packed_targets_bytes(int64_t n_beads);
+int32_t binf_pairdist_pack_targets_f64(const double *ymat, double *packed, int64_t n_beads,
+                                       void *stream);
+int32_t binf_pairdist_gauss_grad_packed_f64(const double *x, const double *ymat,
+                                            const double *packed, double precision,
+                                            const double *precision_chain, double *out,
+                                            int64_t C, int64_t n_beads, void *stream);
+
 /* The whole leapfrog integration HMCSampler._leapfrog (binf/samplers/hmc.py:92-125)
  * for the restraint posterior in one launch: q, p device [C * 3n], integrated in
  * place over nsteps steps (half kick, (nsteps-1) x [drift, kick], drift, half
@@ -707,6 +733,14 @@ int32_t binf_pairdist_leapfrog_f64(double *q, double *p, const double *ymat,
                                    int32_t prior_first, double timestep,
                                    const double *dt_chain, int32_t nsteps, int64_t C,
                                    int64_t n_beads, int32_t mode, void *stream);
+/* the same with the packed targets (null: as binf_pairdist_leapfrog_f64) */
+int32_t binf_pairdist_leapfrog_packed_f64(double *q, double *p, const double *ymat,
+                                          const double *packed, double precision,
+                                          const double *precision_chain, int32_t has_prior,
+                                          double prior_k, double prior_x0, int32_t prior_first,
+                                          double timestep, const double *dt_chain,
+                                          int32_t nsteps, int64_t C, int64_t n_beads,
+                                          int32_t mode, void *stream);
 
 /* ------------------------------------------------------------------------
  * Device random draws (throughput mode): counter-based Philox4x32-10, key =

@@ -31,14 +31,15 @@ for n in (256, 200, 48):
     for C in (16, 256, 512, 1024, 2048):
         x0 = torch.from_numpy(truth.reshape(-1)[None, :] + 0.1 * rs.standard_normal((C, 3 * n))).to(dev)
         p0 = torch.from_numpy(rs.standard_normal((C, 3 * n))).to(dev)
-        res = {}
-        for L in (1, 20):
-            q, p = x0.clone(), p0.clone()
-            res[L] = timed(lambda: _native.pairdist_leapfrog(q, p, ymat, 4.0, (0.01, 0.0), True,
-                                                             1e-4, None, L), 100)
-        per_eval = (res[20] - res[1]) / 19
-        tg = timed(lambda: _native.pairdist_gauss_grad(x0, ymat, 4.0), 100)
-        print('n=%3d C=%5d  leapfrog L=1 %.1f us, L=20 %.1f us -> %.2f us per force evaluation, '
-              '%.1f us once per launch; force-only kernel %.1f us; %.2e pairs/s in the trajectory'
-              % (n, C, res[1] * 1e6, res[20] * 1e6, per_eval * 1e6, (res[1] - 2 * per_eval) * 1e6,
-                 tg * 1e6, C * n * (n - 1) / per_eval))
+        for packed in (None, _native.pairdist_pack_targets(ymat)):
+            res = {}
+            for L in (1, 20):
+                q, p = x0.clone(), p0.clone()
+                res[L] = timed(lambda: _native.pairdist_leapfrog(q, p, ymat, 4.0, (0.01, 0.0), True,
+                                                                 1e-4, None, L, packed=packed), 100)
+            per_eval = (res[20] - res[1]) / 19
+            tg = timed(lambda: _native.pairdist_gauss_grad(x0, ymat, 4.0, packed=packed), 100)
+            print('n=%3d C=%5d %s leapfrog L=1 %.1f us, L=20 %.1f us -> %.2f us per force evaluation, '
+                  '%.1f us once per launch; force-only kernel %.1f us; %.2e pairs/s in the trajectory'
+                  % (n, C, 'matrix' if packed is None else 'packed', res[1] * 1e6, res[20] * 1e6,
+                     per_eval * 1e6, (res[1] - 2 * per_eval) * 1e6, tg * 1e6, C * n * (n - 1) / per_eval))

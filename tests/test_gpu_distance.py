@@ -255,10 +255,8 @@ def test_chi2_memo_of_the_pair_distance_log_prob(device, n, C):
     L_ = make_distance_likelihood(ys, n)
     I, J = L_.forward_model.pair_index(device)
     ty = L_.error_model.ys_device(device)
-    nan = float('nan')
-    memo = (torch.full((C, 3 * n), nan, dtype=torch.float64, device=device),
-            torch.full((C,), nan, dtype=torch.float64, device=device),
-            torch.zeros(C, dtype=torch.uint8, device=device))
+    memo = _native.new_chi2_memo(C, 3 * n, device)
+    reused = lambda: memo[2][0].cpu().numpy().astype(bool)
     tx = dev_t(x, device)
     rs = np.random.RandomState(1)
     changed = np.ones(C, dtype=bool)
@@ -266,10 +264,23 @@ def test_chi2_memo_of_the_pair_distance_log_prob(device, n, C):
         prec = 2.0 if step % 2 else dev_t(rs.uniform(1, 4, size=C), device)
         got = _native.pairdist_gauss_logp_memo(tx, I, J, ty, prec, memo)
         assert torch.equal(got, _native.pairdist_gauss_logp(tx, I, J, ty, prec)), step
-        assert np.array_equal(memo[2].cpu().numpy().astype(bool), ~changed), step
+        assert np.array_equal(reused(), ~changed), step
         changed = rs.rand(C) < 0.5
         idx = torch.from_numpy(np.nonzero(changed)[0]).to(device)
         tx[idx] = tx[idx] + 1e-3 * torch.randn((len(idx), 3 * n), dtype=torch.float64, device=device)
+    # two entries per chain: the state (E_before) and the proposal (E_after) are both kept, so
+    # the next transition's state is not summed again whichever chains were accepted
+    state = tx.clone()
+    for step in range(3):
+        prop = state + 1e-3 * torch.randn_like(state)
+        _native.pairdist_gauss_logp_memo(state, I, J, ty, 2.0, memo)
+        assert reused().all() or step == 0
+        _native.pairdist_gauss_logp_memo(prop, I, J, ty, 2.0, memo)
+        assert not reused().any()
+        acc = torch.from_numpy(rs.rand(C) < 0.5).to(device)
+        state = torch.where(acc[:, None], prop, state)
+    got = _native.pairdist_gauss_logp_memo(state, I, J, ty, 2.0, memo)
+    assert reused().all() and torch.equal(got, _native.pairdist_gauss_logp(state, I, J, ty, 2.0))
     if C > 100:
         return
     runs = []
@@ -285,3 +296,43 @@ def test_chi2_memo_of_the_pair_distance_log_prob(device, n, C):
     for a, b in zip(runs[0][0], runs[1][0]):
         assert torch.equal(a, b)
     assert torch.equal(runs[0][1], runs[1][1]) and torch.equal(runs[0][2], runs[1][2])
+
+
+@pytest.mark.parametrize('n', [32, 48, 64, 65, 100, 128, 150, 192, 200, 256])
+def test_packed_targets_change_no_bit(device, n):
+    """binf_pairdist_pack_targets_f64 + the `_packed_` entry points: the targets in the
+    order the 32..256-bead kernels hold them, read coalesced at the start of a launch
+    instead of tile by tile through LDS -- force and fused leapfrog bit for bit as
+    without them, for one chain per workgroup and for workgroups that walk several."""
+    ys, x = synth(n, 5, 7 * n)
+    lik = make_distance_likelihood(ys, n)
+    em = lik.error_model
+    ymat = em.ymat_device(device)
+    packed = _native.pairdist_pack_targets(ymat)
+    assert packed is not None and packed.numel() * 8 == _native.lib().binf_pairdist_packed_targets_bytes(n)
+    assert em.ypacked_device(device) is em.ypacked_device(device)
+    rs = np.random.RandomState(n)
+    for C in (5, 4200 if n <= 64 else 300):
+        xx = dev_t(x[:1].repeat(C, 0) + 0.1 * rs.standard_normal((C, 3 * n)), device)
+        tau = dev_t(rs.uniform(0.5, 3.0, size=C), device)
+        assert torch.equal(_native.pairdist_gauss_grad(xx, ymat, tau, packed=packed),
+                           _native.pairdist_gauss_grad(xx, ymat, tau))
+        p0 = dev_t(rs.standard_normal((C, 3 * n)), device)
+        for mode in (_native.MODE_EXACT, _native.MODE_FMA):
+            qa, pa, qb, pb = xx.clone(), p0.clone(), xx.clone(), p0.clone()
+            _native.pairdist_leapfrog(qa, pa, ymat, tau, (0.05, 0.1), True, 2e-3, None, 5, mode)
+            _native.pairdist_leapfrog(qb, pb, ymat, tau, (0.05, 0.1), True, 2e-3, None, 5, mode,
+                                      packed=packed)
+            assert torch.equal(qa, qb) and torch.equal(pa, pb)
+
+
+def test_bead_counts_without_a_packed_form(device):
+    for n in (8, 31, 257, 300):
+        assert _native.lib().binf_pairdist_packed_targets_bytes(n) == 0
+        ys, _ = synth(n, 1, n)
+        em = make_distance_likelihood(ys, n).error_model
+        assert em.ypacked_device(device) is None
+        buf = torch.empty(16, dtype=torch.float64, device=device)
+        rc = _native.lib().binf_pairdist_pack_targets_f64(em.ymat_device(device).data_ptr(), buf.data_ptr(), n,
+                                                          _native.stream_handle(device))
+        assert rc == _native.E_UNSUPPORTED

@@ -895,9 +895,8 @@ def test_chi2_memo_is_checked_on_the_device_chain_by_chain(device):
     xs, ys, theta = synth(K, N, C, 5)
     tx, ty = dev_t(xs, device), dev_t(ys, device)
     nan = float('nan')
-    memo = (torch.full((C, K), nan, dtype=torch.float64, device=device),
-            torch.full((C,), nan, dtype=torch.float64, device=device),
-            torch.zeros(C, dtype=torch.uint8, device=device))
+    memo = _native.new_chi2_memo(C, K, device)
+    reused = lambda: memo[2][0].cpu().numpy().astype(bool)
     rs = np.random.RandomState(0)
     th = dev_t(theta, device)
     taus = dev_t(rs.uniform(0.5, 3.0, size=C), device)
@@ -907,8 +906,9 @@ def test_chi2_memo_is_checked_on_the_device_chain_by_chain(device):
         got = _native.poly_gauss_logp_memo(th, tx, ty, prec, memo)
         want = _native.poly_gauss_logp(th, tx, ty, prec)
         assert np.array_equal(got.cpu().numpy(), want.cpu().numpy(), equal_nan=True), step
-        assert np.array_equal(memo[2].cpu().numpy().astype(bool), ~changed_prev), step
-        assert np.array_equal(memo[0].cpu().numpy(), th.cpu().numpy(), equal_nan=True)
+        assert np.array_equal(reused(), ~changed_prev), step
+        entry = memo[0][memo[2][1].long(), torch.arange(C, device=device)]     # the entry each chain used
+        assert np.array_equal(entry.cpu().numpy(), th.cpu().numpy(), equal_nan=True)
         # change a random subset IN PLACE (as a kernel would: no new tensor, no version bump
         # that anything here looks at), including a sign flip of a zero and a NaN
         changed_prev = rs.rand(C) < 0.4
@@ -923,10 +923,26 @@ def test_chi2_memo_is_checked_on_the_device_chain_by_chain(device):
     _native.poly_gauss_logp_memo(th, tx, ty, 2.5, memo)
     th[0, 0] = -0.0
     got = _native.poly_gauss_logp_memo(th, tx, ty, 2.5, memo)
-    assert int(memo[2][0]) == 0 and int(memo[2][1:].sum()) == C - 1
+    assert not reused()[0] and int(reused()[1:].sum()) == C - 1
     assert np.array_equal(got.cpu().numpy(), _native.poly_gauss_logp(th, tx, ty, 2.5).cpu().numpy(),
                           equal_nan=True)
     assert int(torch.isnan(got).sum()) == 1          # the chain that was given a NaN coefficient
+    # two entries per chain: state, proposal, then EITHER of them again (the acceptance test
+    # of hmc.py:152-158 went one way for some chains, the other way for the rest) is not
+    # summed again -- and that for every transition that follows
+    state = th.clone()
+    for step in range(4):
+        prop = state + 1e-3 * torch.randn_like(state)
+        _native.poly_gauss_logp_memo(state, tx, ty, 2.5, memo)           # E_before
+        assert reused().all() or step == 0
+        _native.poly_gauss_logp_memo(prop, tx, ty, 2.5, memo)            # E_after
+        assert not reused().any()
+        acc = torch.from_numpy(rs.rand(C) < 0.5).to(device)
+        state = torch.where(acc[:, None], prop, state)
+        got = _native.poly_gauss_logp_memo(state, tx, ty, 1.0, memo)     # the precision update's chi^2
+        assert reused().all()
+        assert np.array_equal(got.cpu().numpy(), _native.poly_gauss_logp(state, tx, ty, 1.0).cpu().numpy(),
+                              equal_nan=True)
 
 
 def test_gibbs_sweeps_with_and_without_the_chi2_memo_are_identical(device):
