@@ -120,6 +120,8 @@ SIGNATURES = {
     'binf_pairdist_leapfrog_f64': (_i32, [_vp, _vp, _vp, _f64, _vp, _i32, _f64,
                                           _f64, _i32, _f64, _vp, _i32, _i64,
                                           _i64, _i32, _vp]),
+    'binf_pairdist_hmc_energy_f64': (_i32, [_vp, _vp, _vp, _vp, _vp, _f64, _vp, _i32, _f64, _f64,
+                                            _i32, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp]),
     'binf_pairdist_packed_targets_bytes': (_i64, [_i64]),
     'binf_pairdist_pack_targets_f64': (_i32, [_vp, _vp, _i64, _vp]),
     'binf_pairdist_gauss_grad_packed_f64': (_i32, [_vp, _vp, _vp, _f64, _vp, _vp, _i64,
@@ -995,6 +997,33 @@ def pairdist_gauss_logp_memo(x, pair_i, pair_j, ys, precision, memo):
 
 
 @_launcher
+@_launcher
+def pairdist_hmc_energy(x, p, pair_i, pair_j, ys, precision, prior, prior_first, memo=None,
+                        want_log_prob=False):
+    """binf_pairdist_hmc_energy_f64: ``0.5 * sum(p**2) - log_prob`` of the restraint
+    posterior (likelihood + optional isotropic Gaussian prior ``(k, x0)``) in one launch;
+    ``memo = new_chi2_memo(C, 3 * n_beads, device)`` or None.  Returns the energy, or
+    ``(energy, log_prob)``."""
+    C, D = _cd(x)
+    if D % 3:
+        raise ValueError('coordinates must be [n_chains, 3 * n_beads]')
+    P = pair_i.numel()
+    tau, tau_chain = _precision_args(precision, C, x.device)
+    k, x0 = prior if prior is not None else (0.0, 0.0)
+    mx, ms, st = memo if memo is not None else (None, None, None)
+    energy = torch.empty(C, dtype=torch.float64, device=x.device)
+    lp = torch.empty(C, dtype=torch.float64, device=x.device) if want_log_prob else None
+    rc = lib().binf_pairdist_hmc_energy_f64(
+        dptr(x, numel=C * D, name='x'), dptr(p, numel=C * D, name='p'),
+        dptr(pair_i, torch.int32, P, 'pair_i'), dptr(pair_j, torch.int32, P, 'pair_j'),
+        dptr(ys, numel=P, name='ys'), tau, dptr(tau_chain, numel=C, name='precision'),
+        int(prior is not None), float(k), float(x0), int(bool(prior_first)), dptr(energy), dptr(lp),
+        dptr(mx, numel=2 * C * D, name='memo_x'), dptr(ms, numel=2 * C, name='memo_chi2'),
+        dptr(st, torch.uint8, 2 * C, 'memo_state'), C, D // 3, P, stream_handle(x.device))
+    check(rc, 'binf_pairdist_hmc_energy_f64')
+    return (energy, lp) if want_log_prob else energy
+
+
 @_launcher
 def pairdist_pack_targets(ymat):
     """binf_pairdist_pack_targets_f64: the targets in the order the 32..256-bead force

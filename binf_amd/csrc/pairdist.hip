@@ -214,48 +214,22 @@ __device__ inline void leaf_sum_rows(const F &f, int off, int n, int lane, bool 
     }
 }
 
-template <int ROWS, int U>
-__global__ void __launch_bounds__(256)
-pairdist_chi2_rows_kernel(const PairArgs a, const RowGeom g, double *out)
+// One np.sum-order reduction of D elements for ROWS rows by the whole workgroup (THREADS / 8
+// lane groups walk the leaves, the tree goes through S / dep); f(i, v[ROWS]) = element i of
+// every row.  The totals come back in every thread; ends behind a barrier, so S and dep can
+// be used again at once.
+template <int ROWS, int U, int THREADS, class F>
+__device__ inline void block_sum_rows(const F &f, int D, int H, double (*S)[128], int *dep,
+                                      double (&total)[ROWS])
 {
-    constexpr int GROUPS = 256 / 8;
-    __shared__ double S[ROWS][128];
-    __shared__ int dep[128];
-    extern __shared__ double row_lds[];
-    const int H = g.H;
+    constexpr int GROUPS = THREADS / 8;
     const int npaths = 1 << H;
     const int lane = threadIdx.x & 63;
     const int group = threadIdx.x >> 3;
-    const int64_t row0 = (int64_t)blockIdx.x * ROWS;
-    int64_t rows[ROWS];                          // the last workgroup repeats the last chain
-#pragma unroll
-    for (int q = 0; q < ROWS; ++q) rows[q] = (row0 + q < g.C) ? row0 + q : g.C - 1;
-    if (g.skip) {                                // workgroup-uniform
-        bool all_skip = true;
-#pragma unroll
-        for (int q = 0; q < ROWS; ++q) all_skip = all_skip && g.skip[rows[q]] != 0;
-        if (all_skip) {
-            if (threadIdx.x < ROWS && row0 + threadIdx.x < g.C) {
-                const int64_t row = row0 + threadIdx.x;
-                out[row] = row_result(g, row, *row_memo_slot(g, row));
-            }
-            return;
-        }
-    }
-    const int n3 = 3 * (int)a.n_beads;
-#pragma unroll
-    for (int q = 0; q < ROWS; ++q) {
-        const double *xc = a.x + rows[q] * n3;
-        for (int k = threadIdx.x; k < n3; k += 256) row_lds[k * ROWS + q] = xc[k];
-    }
-    __syncthreads();
-    PairResidRows<ROWS> f;
-    f.xl = row_lds; f.I = a.I; f.J = a.J; f.ys = a.ys;
-    double total[ROWS];
 #pragma unroll
     for (int q = 0; q < ROWS; ++q) total[q] = 0.0;
-    for (int cbase = 0; cbase == 0 || cbase < g.D; cbase += NPY_BUFSIZE) {
-        const int n = (g.D - cbase < NPY_BUFSIZE) ? g.D - cbase : NPY_BUFSIZE;
+    for (int cbase = 0; cbase == 0 || cbase < D; cbase += NPY_BUFSIZE) {
+        const int n = (D - cbase < NPY_BUFSIZE) ? D - cbase : NPY_BUFSIZE;
         for (int base = 0; base < npaths; base += GROUPS) {
             const int path = base + group;
             const bool act = path < npaths;
@@ -290,12 +264,199 @@ pairdist_chi2_rows_kernel(const PairArgs a, const RowGeom g, double *out)
         for (int q = 0; q < ROWS; ++q) total[q] = total[q] + S[q][0];
         __syncthreads();
     }
+}
+
+template <int ROWS, int U>
+__global__ void __launch_bounds__(256)
+pairdist_chi2_rows_kernel(const PairArgs a, const RowGeom g, double *out)
+{
+    __shared__ double S[ROWS][128];
+    __shared__ int dep[128];
+    extern __shared__ double row_lds[];
+    const int64_t row0 = (int64_t)blockIdx.x * ROWS;
+    int64_t rows[ROWS];                          // the last workgroup repeats the last chain
+#pragma unroll
+    for (int q = 0; q < ROWS; ++q) rows[q] = (row0 + q < g.C) ? row0 + q : g.C - 1;
+    if (g.skip) {                                // workgroup-uniform
+        bool all_skip = true;
+#pragma unroll
+        for (int q = 0; q < ROWS; ++q) all_skip = all_skip && g.skip[rows[q]] != 0;
+        if (all_skip) {
+            if (threadIdx.x < ROWS && row0 + threadIdx.x < g.C) {
+                const int64_t row = row0 + threadIdx.x;
+                out[row] = row_result(g, row, *row_memo_slot(g, row));
+            }
+            return;
+        }
+    }
+    const int n3 = 3 * (int)a.n_beads;
+#pragma unroll
+    for (int q = 0; q < ROWS; ++q) {
+        const double *xc = a.x + rows[q] * n3;
+        for (int k = threadIdx.x; k < n3; k += 256) row_lds[k * ROWS + q] = xc[k];
+    }
+    __syncthreads();
+    PairResidRows<ROWS> f;
+    f.xl = row_lds; f.I = a.I; f.J = a.J; f.ys = a.ys;
+    double total[ROWS];
+    block_sum_rows<ROWS, U, 256>(f, g.D, g.H, S, dep, total);
     if (threadIdx.x == 0) {
 #pragma unroll
         for (int q = 0; q < ROWS; ++q) {
             if (row0 + q >= g.C) break;
             if (g.memo_sum) *row_memo_slot(g, row0 + q) = total[q];
             out[row0 + q] = row_result(g, row0 + q, total[q]);
+        }
+    }
+}
+
+// ---- the energy of HMCSampler.sample() (hmc.py:143,148,150) for the restraint posterior in
+// ONE launch:  E = 0.5 np.sum(p**2) - log_prob,  log_prob = the Posterior's sum of its
+// components in their order (binf/pdf/posteriors.py:147-151): the restraint likelihood
+// (-0.5 chi^2 tau + N/2 log tau) and at most one isotropic Gaussian prior
+// ((-0.5 k) np.sum((x - x0)**2)).  The per-step tier spends six launches on it (prior row
+// sum, memo check, chi^2, term sum, kinetic row sum with the subtraction as its epilogue);
+// a workgroup has the chain's coordinates in LDS anyway, so the two short row sums, the
+// memo check and the few scalar operations ride along.  Every sum in numpy's order and
+// every scalar operation as the per-step tier does it: the same bits.
+struct PairEnergyArgs {
+    const double *x;         // [C][3n]
+    const double *p;         // [C][3n]
+    const int32_t *I;
+    const int32_t *J;
+    const double *ys;
+    double *memo_x;          // [2][C][3n] or null (no memo)
+    uint8_t *memo_state;     // [2][C]
+    double *energy;          // [C]
+    double *log_prob;        // [C] or null
+    double prior_scale;      // -0.5 k
+    double prior_x0;
+    int32_t has_prior;
+    int32_t prior_first;
+    int32_t n_beads;
+    int32_t H_d;             // tree height of a 3n-element sum
+};
+
+template <int ROWS>
+struct ShiftSqRows {         // (x - x0)**2 from the interleaved LDS copy
+    const double *xl;
+    double x0;
+    __device__ inline void operator()(int i, double (&v)[ROWS]) const
+    {
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            const double d = xl[i * ROWS + r] - x0;
+            v[r] = d * d;
+        }
+    }
+};
+
+template <int ROWS>
+struct SqRows {              // p**2 from HBM
+    const double *row[ROWS];
+    __device__ inline void operator()(int i, double (&v)[ROWS]) const
+    {
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            const double x = row[r][i];
+            v[r] = x * x;
+        }
+    }
+};
+
+template <int ROWS, int U, int THREADS>
+__global__ void __launch_bounds__(THREADS)
+pairdist_energy_kernel(const PairEnergyArgs a, const RowGeom g)
+{
+    __shared__ double S[ROWS][128];
+    __shared__ int dep[128];
+    __shared__ int differs[ROWS][2];
+    extern __shared__ double row_lds[];
+    const int64_t row0 = (int64_t)blockIdx.x * ROWS;
+    int64_t rows[ROWS];                          // the last workgroup repeats the last chain
+#pragma unroll
+    for (int q = 0; q < ROWS; ++q) rows[q] = (row0 + q < g.C) ? row0 + q : g.C - 1;
+    const int n3 = 3 * a.n_beads;
+    const bool memo = a.memo_x != nullptr;
+    if (threadIdx.x < 2 * ROWS) differs[threadIdx.x >> 1][threadIdx.x & 1] = 0;
+    __syncthreads();
+    // coordinates to LDS; on the way, compared BIT FOR BIT with the memo's two entries
+    // (row_memo_check_kernel, rowsum.hpp)
+#pragma unroll
+    for (int q = 0; q < ROWS; ++q) {
+        const double *xc = a.x + rows[q] * n3;
+        const double *m0 = memo ? a.memo_x + rows[q] * n3 : xc;
+        const double *m1 = memo ? a.memo_x + (g.C + rows[q]) * n3 : xc;
+        bool d0 = false, d1 = false;
+        for (int k = threadIdx.x; k < n3; k += THREADS) {
+            const double v = xc[k];
+            row_lds[k * ROWS + q] = v;
+            if (memo) {
+                const long long bits = __double_as_longlong(v);
+                d0 = d0 || bits != __double_as_longlong(m0[k]);
+                d1 = d1 || bits != __double_as_longlong(m1[k]);
+            }
+        }
+        if (d0) differs[q][0] = 1;
+        if (d1) differs[q][1] = 1;
+    }
+    __syncthreads();
+    bool hit[ROWS], all_hit = memo;
+    int way[ROWS];
+#pragma unroll
+    for (int q = 0; q < ROWS; ++q) {
+        const bool h0 = memo && !differs[q][0], h1 = memo && !differs[q][1];
+        hit[q] = h0 || h1;
+        way[q] = hit[q] ? (h0 ? 0 : 1) : (memo ? 1 - (a.memo_state[g.C + rows[q]] & 1) : 0);
+        all_hit = all_hit && hit[q];
+    }
+    if (memo) {
+#pragma unroll
+        for (int q = 0; q < ROWS; ++q) {
+            if (hit[q] || row0 + q >= g.C) continue;         // uniform
+            double *m = a.memo_x + ((int64_t)way[q] * g.C + rows[q]) * n3;
+            for (int k = threadIdx.x; k < n3; k += THREADS) m[k] = row_lds[k * ROWS + q];
+        }
+    }
+    double chi2[ROWS];
+    if (!all_hit) {                              // uniform
+        PairResidRows<ROWS> f;
+        f.xl = row_lds; f.I = a.I; f.J = a.J; f.ys = a.ys;
+        block_sum_rows<ROWS, U, THREADS>(f, g.D, g.H, S, dep, chi2);
+    } else {
+#pragma unroll
+        for (int q = 0; q < ROWS; ++q) chi2[q] = g.memo_sum[(int64_t)way[q] * g.C + rows[q]];
+    }
+    double prior[ROWS], kin[ROWS];
+#pragma unroll
+    for (int q = 0; q < ROWS; ++q) prior[q] = 0.0;
+    if (a.has_prior) {
+        ShiftSqRows<ROWS> fp;
+        fp.xl = row_lds; fp.x0 = a.prior_x0;
+        block_sum_rows<ROWS, U, THREADS>(fp, n3, a.H_d, S, dep, prior);
+    }
+    SqRows<ROWS> fk;
+#pragma unroll
+    for (int q = 0; q < ROWS; ++q) fk.row[q] = a.p + rows[q] * n3;
+    block_sum_rows<ROWS, U, THREADS>(fk, n3, a.H_d, S, dep, kin);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int q = 0; q < ROWS; ++q) {
+            const int64_t row = row0 + q;
+            if (row >= g.C) break;
+            if (memo) {
+                g.memo_sum[(int64_t)way[q] * g.C + row] = chi2[q];
+                a.memo_state[row] = hit[q] ? 1 : 0;
+                a.memo_state[g.C + row] = (uint8_t)way[q];
+            }
+            const double lp_lik = row_result(g, row, chi2[q]);
+            double lp = lp_lik;
+            if (a.has_prior) {
+                const double lp_prior = a.prior_scale * prior[q];
+                lp = a.prior_first ? lp_prior + lp_lik : lp_lik + lp_prior;
+            }
+            if (a.log_prob) a.log_prob[row] = lp;
+            a.energy[row] = 0.5 * kin[q] - lp;
         }
     }
 }
@@ -1145,6 +1306,67 @@ static int32_t pairdist_logp_run(const double *x, const int32_t *pair_i, const i
                                                        "pairdist_gauss_logp", 0, false, &fin, skip,
                                                        memo_chi2);
     if (rc) return rc;
+    return 0;
+}
+
+// tree height of an np.sum over D elements as the block reductions walk it (rowsum.hpp:
+// the largest height among the 8192-element chunks)
+static int32_t npsum_tree_height(int64_t D)
+{
+    int32_t H = pairwise_tree_height(D < NPY_BUFSIZE ? D : NPY_BUFSIZE);
+    if (D > NPY_BUFSIZE && D % NPY_BUFSIZE != 0) {
+        const int32_t h_last = pairwise_tree_height(D % NPY_BUFSIZE);
+        if (h_last > H) H = h_last;
+    }
+    return H;
+}
+
+extern "C" int32_t binf_pairdist_hmc_energy_f64(const double *x, const double *p,
+                                                const int32_t *pair_i, const int32_t *pair_j,
+                                                const double *ys, double precision,
+                                                const double *precision_chain, int32_t has_prior,
+                                                double prior_k, double prior_x0, int32_t prior_first,
+                                                double *energy, double *log_prob, double *memo_x,
+                                                double *memo_chi2, uint8_t *memo_state, int64_t C,
+                                                int64_t n_beads, int64_t n_pairs, void *stream)
+{
+    if (C < 0 || n_beads < 1 || n_pairs < 0)
+        return fail(BINF_E_ARG, "pairdist_hmc_energy: bad sizes");
+    if (C == 0) return 0;
+    if (!x || !p || !energy || (n_pairs > 0 && (!pair_i || !pair_j || !ys)))
+        return fail(BINF_E_ARG, "pairdist_hmc_energy: null buffer");
+    if ((memo_x != nullptr) != (memo_chi2 != nullptr) || (memo_x != nullptr) != (memo_state != nullptr))
+        return fail(BINF_E_ARG, "pairdist_hmc_energy: memo_x, memo_chi2 and memo_state go together");
+    if (C > 0x7fffffffLL || n_pairs > 0x7fffffffLL)
+        return fail(BINF_E_UNSUPPORTED, "pairdist_hmc_energy: too large");
+    if (n_beads > 2048)
+        return fail(BINF_E_UNSUPPORTED, "pairdist_hmc_energy: n_beads=%lld > 2048 (coordinates staged in LDS)",
+                    (long long)n_beads);
+    RowGeom g;
+    g.C = C; g.D = (int32_t)n_pairs; g.scale = 1.0;
+    g.fin.on = 1; g.fin.minus = nullptr; g.fin.tau = precision; g.fin.tau_chain = precision_chain;
+    g.fin.n_data = (double)n_pairs;
+    g.skip = nullptr; g.way = nullptr; g.memo_sum = memo_chi2;
+    g.H = npsum_tree_height(n_pairs);
+    PairEnergyArgs a;
+    a.x = x; a.p = p; a.I = pair_i; a.J = pair_j; a.ys = ys; a.memo_x = memo_x; a.memo_state = memo_state;
+    a.energy = energy; a.log_prob = log_prob;
+    a.prior_scale = -0.5 * prior_k; a.prior_x0 = prior_x0;
+    a.has_prior = has_prior ? 1 : 0; a.prior_first = prior_first ? 1 : 0;
+    a.n_beads = (int32_t)n_beads; a.H_d = npsum_tree_height(3 * n_beads);
+    if (g.H > 7 || a.H_d > 7)
+        return fail(BINF_E_UNSUPPORTED, "pairdist_hmc_energy: pairwise tree height %d", g.H > a.H_d ? g.H : a.H_d);
+    hipStream_t st = (hipStream_t)stream;
+    const int rows = pairdist_logp_rows(C, n_beads, n_pairs);
+    const size_t lds = (size_t)rows * n_beads * 3 * sizeof(double);
+    if (rows == 2)
+        pairdist_energy_kernel<2, 8, 256><<<dim3((unsigned)((C + 1) / 2)), 256, lds, st>>>(a, g);
+    else if (C < 1024 && n_pairs >= 2048)           // few chains: 16 waves per chain (as the log-prob)
+        pairdist_energy_kernel<1, 8, 1024><<<dim3((unsigned)C), 1024, lds, st>>>(a, g);
+    else
+        pairdist_energy_kernel<1, 8, 256><<<dim3((unsigned)C), 256, lds, st>>>(a, g);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "pairdist_hmc_energy launch");
     return 0;
 }
 

@@ -141,6 +141,19 @@ def native_log_prob(likelihood, fwm, em, fwm_vars, em_vars):
     return _native.pairdist_gauss_logp(x2, I, J, ys, em_vars['precision'])
 
 
+def native_hmc_energy(likelihood, x2, p2, precision, prior, prior_first):
+    """``0.5 * sum(p**2) - log_prob`` of a posterior made of this likelihood and at most one
+    isotropic Gaussian prior ``(k, x0)`` (``Posterior.native_energy_spec``), one launch:
+    binf_pairdist_hmc_energy_f64.  Shares the chi^2 memo with ``native_log_prob``."""
+    fwm, em = likelihood.forward_model, likelihood.error_model
+    I, J = fwm.pair_index(x2.device)
+    ys = em.ys_device(x2.device)
+    memo = None
+    if USE_CHI2_MEMO and ys.numel() >= 2048 and x2.numel() * 8 <= (1 << 28):
+        memo = _chi2_memo(I, ys, x2.shape)
+    return _native.pairdist_hmc_energy(x2, p2, I, J, ys, precision, prior, prior_first, memo)
+
+
 USE_CHI2_MEMO = True
 _memos = {}
 

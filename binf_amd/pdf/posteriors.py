@@ -179,15 +179,28 @@ class Posterior(AbstractBinfPDF):
         differentiable variable do not enter the force anyway (quirk Q4).
         The tuple records the order of the two force terms, which is this
         class's sorted-component-name order."""
-        from binf_amd.pdf import IsotropicGaussian
-        from binf_amd.pdf.likelihoods import Likelihood
         poly = self._native_poly_leapfrog_spec(variable_name)
         if poly is not None:
             return poly
+        return self._native_pairdist_spec(variable_name, strict=False)
+
+    def native_energy_spec(self, variable_name):
+        """Descriptor of a fused kernel for ``HMCSampler.sample()``'s energy
+        ``0.5 * sum(p**2) - log_prob`` under THIS posterior, or None.  As
+        ``native_leapfrog_spec`` for the restraint posterior, but EVERY component
+        must be the likelihood or the one prior: a component without differentiable
+        variables drops out of the force, not out of ``log_prob``."""
+        return self._native_pairdist_spec(variable_name, strict=True)
+
+    def _native_pairdist_spec(self, variable_name, strict):
+        from binf_amd.pdf import IsotropicGaussian
+        from binf_amd.pdf.likelihoods import Likelihood
         lik = prior = None
         order = []
         for f in self._ordered_components():
             if not (len(f.variables) > 0 and len(f.differentiable_variables) > 0):
+                if strict:
+                    return None
                 continue
             if isinstance(f, Likelihood):
                 fs = getattr(f.forward_model, 'native_spec', lambda: None)()
@@ -209,6 +222,7 @@ class Posterior(AbstractBinfPDF):
         if lik is None:
             return None
         em = lik.error_model
-        return ('pairdist', em, em['precision'].value,
+        spec = ('pairdist', em, em['precision'].value,
                 None if prior is None else (float(prior['k'].value), float(prior['x0'].value)),
                 order[0] == 'prior')
+        return spec + (lik,) if strict else spec

@@ -76,6 +76,7 @@ class HMCSampler(object):
         self.last_e_after = None
         self.accepted_history = None      # [n x C] flags of the last sample_n()
         self.fused_leapfrog = True        # use a PDF's fused leapfrog kernel if it has one
+        self.fused_energy = True          # ... and its one-launch energy (native_energy_spec)
         # ... and the fused small-data polynomial transition: True (layout by the batch:
         # a chain's data spread over a lane group up to POLY_LANE_MIN_CHAINS chains, one
         # lane per chain from there on when there are <= 128 data points -- same energies,
@@ -609,6 +610,15 @@ class HMCSampler(object):
         # subtraction as its epilogue (one launch; the same bits as negate, sum, add)
         E = lambda x, mom: _native.hmc_energy(
             mom, _as_chain_vector(pdf.log_prob(**{name: x.view(shape)})).contiguous())
+        espec = getattr(pdf, 'native_energy_spec', None)
+        espec = espec(name) if (espec is not None and self.fused_energy and q0.is_cuda) else None
+        if espec is not None and espec[0] == 'pairdist' and q0.shape[1] % 3 == 0 \
+                and q0.shape[1] // 3 <= 2048:
+            # prior row sum, chi^2 (with its memo), term sum and kinetic energy in one launch
+            # (bit-identical to the calls above)
+            from binf_amd.example import distance as _dist
+            _, em, precision, prior, prior_first, lik = espec
+            E = lambda x, mom: _dist.native_hmc_energy(lik, x, mom, precision, prior, prior_first)
 
         q = q0.clone()
         p = p0 if own_p else p0.clone()

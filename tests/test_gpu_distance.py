@@ -336,3 +336,66 @@ def test_bead_counts_without_a_packed_form(device):
         rc = _native.lib().binf_pairdist_pack_targets_f64(em.ymat_device(device).data_ptr(), buf.data_ptr(), n,
                                                           _native.stream_handle(device))
         assert rc == _native.E_UNSUPPORTED
+
+
+@pytest.mark.parametrize('n,C', [(5, 3), (17, 9), (64, 5), (100, 1030), (128, 4), (256, 7), (300, 3),
+                                 (40, 2051), (131, 2048), (700, 2)])
+def test_one_launch_energy_is_the_per_step_tier_bit_for_bit(device, n, C):
+    """binf_pairdist_hmc_energy_f64 against the calls it replaces (prior row sum, chi^2,
+    binf_sum_terms_f64, binf_hmc_energy_f64) for every component order, with and without
+    the memo, scalar and per-chain precision; the memo it fills serves the log-prob and
+    the other way round."""
+    ys, x = synth(n, C, 13 * n + C)
+    rs = np.random.RandomState(n + C)
+    lik = make_distance_likelihood(ys, n)
+    I, J = lik.forward_model.pair_index(device)
+    ty = lik.error_model.ys_device(device)
+    tx, tp = dev_t(x, device), dev_t(rs.standard_normal((C, 3 * n)), device)
+    taus = dev_t(rs.uniform(0.5, 3.0, size=C), device)
+    for prec in (2.5, taus):
+        lp_lik = _native.pairdist_gauss_logp(tx, I, J, ty, prec)
+        for prior, first in ((None, False), ((0.05, 0.1), True), ((0.7, -0.3), False)):
+            if prior is None:
+                lp = lp_lik
+            else:
+                lp_prior = _native.row_sum(tx, _native.ROW_SUMSQ_SHIFT, shift=prior[1], scale=-0.5 * prior[0])
+                lp = _native.sum_terms([lp_prior, lp_lik] if first else [lp_lik, lp_prior])
+            want = _native.hmc_energy(tp, lp)
+            got, got_lp = _native.pairdist_hmc_energy(tx, tp, I, J, ty, prec, prior, first,
+                                                      want_log_prob=True)
+            assert torch.equal(got, want) and torch.equal(got_lp, lp)
+            memo = _native.new_chi2_memo(C, 3 * n, device)
+            for rep in range(2):
+                assert torch.equal(_native.pairdist_hmc_energy(tx, tp, I, J, ty, prec, prior, first, memo), want)
+                assert bool(memo[2][0].all()) == (rep == 1)
+            assert torch.equal(_native.pairdist_gauss_logp_memo(tx, I, J, ty, prec, memo), lp_lik)
+            assert bool(memo[2][0].all())
+            x2 = tx.clone()
+            x2[::2] += 1e-3
+            _native.pairdist_gauss_logp_memo(x2, I, J, ty, prec, memo)            # second entry
+            assert torch.equal(_native.pairdist_hmc_energy(tx, tp, I, J, ty, prec, prior, first, memo), want)
+            assert bool(memo[2][0].all())
+
+
+def test_sample_with_and_without_the_one_launch_energy(device):
+    """HMCSampler.sample() on the restraint posterior: the fused energy changes no bit of
+    states, flags, energies or adapted step sizes; a posterior with a further component
+    (which the energy spec does not cover) still samples through the per-step energy."""
+    n, C = 48, 11
+    ys, x = synth(n, C, 21)
+    runs = []
+    for fused in (True, False):
+        s = HMCSampler(make_post(ys, n).conditional_factory(precision=3.0), dev_t(x, device), 0.002, 4,
+                       timestep_adaption_limit=3, variable_name='coordinates', rng=DeviceRNG(5, device),
+                       record_energies=True)
+        s.fused_energy = fused
+        out = [s.sample().clone() for _ in range(5)]
+        runs.append((out, s.last_e_before.clone(), s.last_e_after.clone(), s.n_accepted.clone(),
+                     s.timestep.clone()))
+    for a, b in zip(runs[0][0], runs[1][0]):
+        assert torch.equal(a, b)
+    for k in range(1, 5):
+        assert torch.equal(runs[0][k], runs[1][k])
+    post = make_post(ys, n)
+    assert post.conditional_factory(precision=3.0).native_energy_spec('coordinates') is not None
+    assert post.native_energy_spec('coordinates') is None          # precision not fixed
