@@ -214,64 +214,85 @@ __device__ inline void leaf_sum_rows(const F &f, int off, int n, int lane, bool 
     }
 }
 
-// One np.sum-order reduction of D elements for ROWS rows by the whole workgroup (THREADS / 8
-// lane groups walk the leaves, the tree goes through S / dep); f(i, v[ROWS]) = element i of
-// every row.  The totals come back in every thread; ends behind a barrier, so S and dep can
-// be used again at once.
+// One np.sum-order reduction of D elements for ROWS rows by the whole workgroup;
+// f(i, v[ROWS]) = element i of every row.  THREADS / 8 lane groups sum leaves: with 16
+// waves a round covers two 64-leaf chunks at once, with 4 waves a chunk takes two passes.
+// The leaf sums of a round go to LDS, ONE barrier, and wave 0 alone walks the round's trees
+// with lane exchanges (lane = path) and adds the chunk sums to the running total in chunk
+// order -- a tree through LDS costs two barriers per level, 14 per chunk, which at one
+// 1024-thread workgroup per CU was a third of the kernel.  The LDS buffers alternate
+// between rounds (`round` runs on through consecutive calls), so the barrier of round r + 1
+// is all that separates wave 0's reads of round r from the writes of round r + 2.
+// The totals come back in THREAD 0 only.
+struct BlockSumScratch {
+    double S[2][2][128];     // [round parity][row][slot]   (ROWS <= 2)
+    int dep[2][128];
+};
+
 template <int ROWS, int U, int THREADS, class F>
-__device__ inline void block_sum_rows(const F &f, int D, int H, double (*S)[128], int *dep,
+__device__ inline void block_sum_rows(const F &f, int D, int H, BlockSumScratch &sc, int &round,
                                       double (&total)[ROWS])
 {
+    static_assert(ROWS <= 2, "BlockSumScratch holds two rows");
     constexpr int GROUPS = THREADS / 8;
-    const int npaths = 1 << H;
+    const int npaths = 1 << H;                                   // <= 128
     const int lane = threadIdx.x & 63;
     const int group = threadIdx.x >> 3;
+    const int nchunks = D <= 0 ? 1 : (D + NPY_BUFSIZE - 1) / NPY_BUFSIZE;
+    const int R = GROUPS >= npaths ? GROUPS / npaths : 1;        // chunks per round
+    const int passes = GROUPS >= npaths ? 1 : npaths / GROUPS;   // passes per chunk
 #pragma unroll
     for (int q = 0; q < ROWS; ++q) total[q] = 0.0;
-    for (int cbase = 0; cbase == 0 || cbase < D; cbase += NPY_BUFSIZE) {
-        const int n = (D - cbase < NPY_BUFSIZE) ? D - cbase : NPY_BUFSIZE;
-        for (int base = 0; base < npaths; base += GROUPS) {
-            const int path = base + group;
-            const bool act = path < npaths;
+    for (int c0 = 0; c0 < nchunks; c0 += R, ++round) {
+        const int b = round & 1;
+        for (int ps = 0; ps < passes; ++ps) {
+            const int item = ps * GROUPS + group;                // (chunk of the round, path)
+            const int cr = item >> H, path = item & (npaths - 1);
+            const int chunk = c0 + cr;
+            const bool act = cr < R && chunk < nchunks;
+            const int cbase = act ? chunk * NPY_BUFSIZE : 0;
+            const int n = (D - cbase < NPY_BUFSIZE) ? D - cbase : NPY_BUFSIZE;
             const Leaf L = pairwise_leaf(n, H, act ? path : 0);
             double s[ROWS];
             leaf_sum_rows<ROWS, U>(f, cbase + L.off, L.len, lane, act, s);
             if (act && (lane & 7) == 0) {
 #pragma unroll
-                for (int q = 0; q < ROWS; ++q) S[q][path] = s[q];
-                dep[path] = L.depth;
+                for (int q = 0; q < ROWS; ++q) sc.S[b][q][item] = s[q];
+                sc.dep[b][item] = L.depth;
             }
         }
         __syncthreads();
-        for (int l = 0; l < H; ++l) {
-            double v[ROWS];
-            const int p = threadIdx.x;
-            if (p < npaths) {
-                const bool join = dep[p] >= H - l;
+        if (threadIdx.x < 64) {
+            for (int cr = 0; cr < R && c0 + cr < nchunks; ++cr) {
+                const int base = cr << H;
+                const bool two = npaths > 64;                    // H = 7: paths p and p + 64 per lane
+                const int p0 = base + (lane & (npaths - 1)), p1 = base + ((lane + 64) & (npaths - 1));
+                const int d0 = sc.dep[b][p0], d1 = sc.dep[b][p1];
 #pragma unroll
                 for (int q = 0; q < ROWS; ++q) {
-                    const double mine = S[q][p];
-                    v[q] = join ? mine + S[q][p ^ (1 << l)] : mine;
+                    double v0 = sc.S[b][q][p0], v1 = sc.S[b][q][p1];
+                    for (int l = 0; l < H && l < 6; ++l) {
+                        const double o0 = shfl_f64(v0, lane ^ (1 << l));
+                        v0 = (d0 >= H - l) ? v0 + o0 : v0;
+                        if (two) {
+                            const double o1 = shfl_f64(v1, lane ^ (1 << l));
+                            v1 = (d1 >= H - l) ? v1 + o1 : v1;
+                        }
+                    }
+                    if (two) v0 = (d0 >= 1) ? v0 + v1 : v0;      // level 6 joins paths p and p + 64
+                    total[q] = total[q] + v0;                    // lane 0: path 0, the chunk's sum
                 }
             }
-            __syncthreads();
-            if (p < npaths)
-#pragma unroll
-                for (int q = 0; q < ROWS; ++q) S[q][p] = v[q];
-            __syncthreads();
         }
-#pragma unroll
-        for (int q = 0; q < ROWS; ++q) total[q] = total[q] + S[q][0];
-        __syncthreads();
     }
 }
 
-template <int ROWS, int U>
-__global__ void __launch_bounds__(256)
+template <int ROWS, int U, int THREADS>
+__global__ void __launch_bounds__(THREADS)
 pairdist_chi2_rows_kernel(const PairArgs a, const RowGeom g, double *out)
 {
-    __shared__ double S[ROWS][128];
-    __shared__ int dep[128];
+    __shared__ BlockSumScratch sc;
+    int round = 0;
     extern __shared__ double row_lds[];
     const int64_t row0 = (int64_t)blockIdx.x * ROWS;
     int64_t rows[ROWS];                          // the last workgroup repeats the last chain
@@ -293,13 +314,13 @@ pairdist_chi2_rows_kernel(const PairArgs a, const RowGeom g, double *out)
 #pragma unroll
     for (int q = 0; q < ROWS; ++q) {
         const double *xc = a.x + rows[q] * n3;
-        for (int k = threadIdx.x; k < n3; k += 256) row_lds[k * ROWS + q] = xc[k];
+        for (int k = threadIdx.x; k < n3; k += THREADS) row_lds[k * ROWS + q] = xc[k];
     }
     __syncthreads();
     PairResidRows<ROWS> f;
     f.xl = row_lds; f.I = a.I; f.J = a.J; f.ys = a.ys;
     double total[ROWS];
-    block_sum_rows<ROWS, U, 256>(f, g.D, g.H, S, dep, total);
+    block_sum_rows<ROWS, U, THREADS>(f, g.D, g.H, sc, round, total);
     if (threadIdx.x == 0) {
 #pragma unroll
         for (int q = 0; q < ROWS; ++q) {
@@ -368,9 +389,9 @@ template <int ROWS, int U, int THREADS>
 __global__ void __launch_bounds__(THREADS)
 pairdist_energy_kernel(const PairEnergyArgs a, const RowGeom g)
 {
-    __shared__ double S[ROWS][128];
-    __shared__ int dep[128];
+    __shared__ BlockSumScratch sc;
     __shared__ int differs[ROWS][2];
+    int round = 0;
     extern __shared__ double row_lds[];
     const int64_t row0 = (int64_t)blockIdx.x * ROWS;
     int64_t rows[ROWS];                          // the last workgroup repeats the last chain
@@ -422,7 +443,7 @@ pairdist_energy_kernel(const PairEnergyArgs a, const RowGeom g)
     if (!all_hit) {                              // uniform
         PairResidRows<ROWS> f;
         f.xl = row_lds; f.I = a.I; f.J = a.J; f.ys = a.ys;
-        block_sum_rows<ROWS, U, THREADS>(f, g.D, g.H, S, dep, chi2);
+        block_sum_rows<ROWS, U, THREADS>(f, g.D, g.H, sc, round, chi2);
     } else {
 #pragma unroll
         for (int q = 0; q < ROWS; ++q) chi2[q] = g.memo_sum[(int64_t)way[q] * g.C + rows[q]];
@@ -433,12 +454,12 @@ pairdist_energy_kernel(const PairEnergyArgs a, const RowGeom g)
     if (a.has_prior) {
         ShiftSqRows<ROWS> fp;
         fp.xl = row_lds; fp.x0 = a.prior_x0;
-        block_sum_rows<ROWS, U, THREADS>(fp, n3, a.H_d, S, dep, prior);
+        block_sum_rows<ROWS, U, THREADS>(fp, n3, a.H_d, sc, round, prior);
     }
     SqRows<ROWS> fk;
 #pragma unroll
     for (int q = 0; q < ROWS; ++q) fk.row[q] = a.p + rows[q] * n3;
-    block_sum_rows<ROWS, U, THREADS>(fk, n3, a.H_d, S, dep, kin);
+    block_sum_rows<ROWS, U, THREADS>(fk, n3, a.H_d, sc, round, kin);
     if (threadIdx.x == 0) {
 #pragma unroll
         for (int q = 0; q < ROWS; ++q) {
@@ -1237,8 +1258,34 @@ extern "C" int32_t binf_pairdist_gauss_logp_memo_f64(const double *x, const int3
                              C, n_beads, n_pairs, stream);
 }
 
+// tree height of an np.sum over D elements as the block reductions walk it (rowsum.hpp:
+// the largest height among the 8192-element chunks)
+static int32_t npsum_tree_height(int64_t D)
+{
+    int32_t H = pairwise_tree_height(D < NPY_BUFSIZE ? D : NPY_BUFSIZE);
+    if (D > NPY_BUFSIZE && D % NPY_BUFSIZE != 0) {
+        const int32_t h_last = pairwise_tree_height(D % NPY_BUFSIZE);
+        if (h_last > H) H = h_last;
+    }
+    return H;
+}
+
+// development aid: BINF_PD_LOGP_LDS_TREE=1 sends the chi^2 of <= 2048 beads through the generic
+// block reduction (tree through LDS, two barriers per level) instead of pairdist_chi2_rows_kernel
+static bool pairdist_logp_lds_tree()
+{
+    static std::atomic<int> on(-1);
+    int v = on.load(std::memory_order_relaxed);
+    if (v < 0) {
+        const char *e = getenv("BINF_PD_LOGP_LDS_TREE");
+        v = (e && e[0] == '1') ? 1 : 0;
+        on.store(v, std::memory_order_relaxed);
+    }
+    return v != 0;
+}
+
 // chains per workgroup of the chi^2 reduction: more than one once there are enough chains
-// to fill the chip that way (development aid: BINF_PD_LOGP_ROWS = 1, 2, 4)
+// to fill the chip that way (development aid: BINF_PD_LOGP_ROWS = 1, 2)
 static int pairdist_logp_rows(int64_t C, int64_t n_beads, int64_t n_pairs)
 {
     static std::atomic<int> forced(-1);
@@ -1246,11 +1293,11 @@ static int pairdist_logp_rows(int64_t C, int64_t n_beads, int64_t n_pairs)
     if (v < 0) {
         const char *e = getenv("BINF_PD_LOGP_ROWS");
         v = e ? atoi(e) : 0;
-        if (v != 1 && v != 2 && v != 4) v = 0;
+        if (v != 1 && v != 2) v = 0;
         forced.store(v, std::memory_order_relaxed);
     }
     int rows = v;
-    if (rows == 0) rows = (C >= 2048 && n_pairs >= 2048) ? 2 : 1;
+    if (rows == 0) rows = (C >= 1024 && n_pairs >= 2048) ? 2 : 1;
     while (rows > 1 && (int64_t)rows * n_beads * 3 * (int64_t)sizeof(double) > 48 * 1024) rows >>= 1;
     return rows;
 }
@@ -1271,31 +1318,30 @@ static int32_t pairdist_logp_run(const double *x, const int32_t *pair_i, const i
     int32_t rc;
     GaussFinish fin;                // lp = -0.5 chi2 tau + N/2 log tau, written by the reduction
     fin.on = 1; fin.minus = nullptr; fin.tau = precision; fin.tau_chain = precision_chain; fin.n_data = (double)n_pairs;
-    const int rows = pairdist_logp_rows(C, n_beads, n_pairs);
-    if (rows > 1) {
+    if (n_beads <= 2048 && !pairdist_logp_lds_tree()) {       // 48 KiB of coordinates fit the LDS budget
         if (C > 0x7fffffffLL || n_pairs > 0x7fffffffLL)
             return fail(BINF_E_UNSUPPORTED, "pairdist_gauss_logp: too large");
+        const int rows = pairdist_logp_rows(C, n_beads, n_pairs);
         RowGeom g;
         g.C = C; g.D = (int32_t)n_pairs; g.scale = 1.0; g.fin = fin;
         g.skip = skip; g.way = skip ? skip + C : nullptr; g.memo_sum = memo_chi2;
-        g.H = pairwise_tree_height(n_pairs < NPY_BUFSIZE ? n_pairs : NPY_BUFSIZE);
-        if (n_pairs > NPY_BUFSIZE && n_pairs % NPY_BUFSIZE != 0) {
-            const int32_t h_last = pairwise_tree_height(n_pairs % NPY_BUFSIZE);
-            if (h_last > g.H) g.H = h_last;
-        }
+        g.H = npsum_tree_height(n_pairs);
         if (g.H > 7) return fail(BINF_E_UNSUPPORTED, "pairdist_gauss_logp: pairwise tree height %d", g.H);
         const size_t lds = (size_t)rows * n_beads * 3 * sizeof(double);
         const dim3 grid((unsigned)((C + rows - 1) / rows));
-        if (rows == 2) pairdist_chi2_rows_kernel<2, 8><<<grid, 256, lds, st>>>(a, g, out);
-        else           pairdist_chi2_rows_kernel<4, 4><<<grid, 256, lds, st>>>(a, g, out);
+        // two chains per workgroup from 2048 chains up; fewer chains than ~4 workgroups per CU
+        // (and rows long enough to feed them): 16 waves per chain instead of 4
+        if (rows == 2)
+            pairdist_chi2_rows_kernel<2, 8, 256><<<grid, 256, lds, st>>>(a, g, out);
+        else if (C < 1024 && n_pairs >= 2048)
+            pairdist_chi2_rows_kernel<1, 8, 1024><<<grid, 1024, lds, st>>>(a, g, out);
+        else
+            pairdist_chi2_rows_kernel<1, 8, 256><<<grid, 256, lds, st>>>(a, g, out);
         const hipError_t e = hipGetLastError();
         if (e != hipSuccess) return hip_fail(e, "pairdist_gauss_logp");
         return 0;
     }
-    if (n_beads <= 2048)            // 48 KiB of coordinates fit the static LDS budget
-        // fewer rows than ~4 workgroups per CU (and rows long enough to feed them):
-        // 16 waves per row instead of 4
-        // (256 chains: 41 -> 30 us; 2048 chains: 141 vs 122 us, so not there)
+    if (n_beads <= 2048)            // development aid (BINF_PD_LOGP_LDS_TREE=1): the generic block kernel
         rc = row_reduce_launch<PairResidMake, PairArgs, true>(a, C, n_pairs, 1.0, out, st, true,
                                                              "pairdist_gauss_logp",
                                                              (size_t)n_beads * 3 * sizeof(double),
@@ -1307,18 +1353,6 @@ static int32_t pairdist_logp_run(const double *x, const int32_t *pair_i, const i
                                                        memo_chi2);
     if (rc) return rc;
     return 0;
-}
-
-// tree height of an np.sum over D elements as the block reductions walk it (rowsum.hpp:
-// the largest height among the 8192-element chunks)
-static int32_t npsum_tree_height(int64_t D)
-{
-    int32_t H = pairwise_tree_height(D < NPY_BUFSIZE ? D : NPY_BUFSIZE);
-    if (D > NPY_BUFSIZE && D % NPY_BUFSIZE != 0) {
-        const int32_t h_last = pairwise_tree_height(D % NPY_BUFSIZE);
-        if (h_last > H) H = h_last;
-    }
-    return H;
 }
 
 extern "C" int32_t binf_pairdist_hmc_energy_f64(const double *x, const double *p,

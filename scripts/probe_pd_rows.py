@@ -1,6 +1,7 @@
-"""Pair-distance chi^2 with 1 / 2 / 4 chains per workgroup (BINF_PD_LOGP_ROWS), one child
-process per setting: time per evaluation and a digest of the result bits (the settings
-must agree bit for bit).  Usage: python scripts/probe_pd_rows.py [n_beads]"""
+"""Pair-distance chi^2: the variants against each other, one child process per setting
+(BINF_PD_LOGP_ROWS = 1 / 2 chains per workgroup; BINF_PD_LOGP_LDS_TREE=1 = the generic block
+reduction with its tree through LDS): time per evaluation and a digest of the result bits
+(all settings must agree bit for bit).  Usage: python scripts/probe_pd_rows.py [n_beads]"""
 import hashlib, os, subprocess, sys, json
 
 def child(n):
@@ -12,7 +13,7 @@ def child(n):
     ti = torch.from_numpy(I.astype(np.int32)).to(dev); tj = torch.from_numpy(J.astype(np.int32)).to(dev)
     ys = torch.from_numpy(np.random.RandomState(3).uniform(0.5, 3.0, I.size)).to(dev)
     res = {}
-    for C in (255, 2048, 4097, 16384):
+    for C in (255, 1024, 2048, 4097, 16384):
         x = torch.from_numpy(np.random.RandomState(C).standard_normal((C, 3 * n))).to(dev)
         out = _native.pairdist_gauss_logp(x, ti, tj, ys, 2.5)
         torch.cuda.synchronize()
@@ -29,7 +30,8 @@ if __name__ == '__main__':
         child(int(sys.argv[1]))
     else:
         n = sys.argv[1] if len(sys.argv) > 1 else '256'
-        for rows in ('1', '2', '4'):
-            env = dict(os.environ, BINF_PD_LOGP_ROWS=rows)
-            r = subprocess.run([sys.executable, __file__, n, 'child'], env=env, capture_output=True, text=True)
-            print('rows', rows, r.stdout.strip() or r.stderr[-400:], flush=True)
+        for name, env in (('lds tree', {'BINF_PD_LOGP_LDS_TREE': '1'}), ('rows 1', {'BINF_PD_LOGP_ROWS': '1'}),
+                          ('rows 2', {'BINF_PD_LOGP_ROWS': '2'}), ('default', {})):
+            r = subprocess.run([sys.executable, __file__, n, 'child'], env=dict(os.environ, **env),
+                               capture_output=True, text=True)
+            print('%-9s' % name, r.stdout.strip() or r.stderr[-400:], flush=True)
