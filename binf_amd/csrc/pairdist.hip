@@ -855,7 +855,8 @@ constexpr int SYM_ROWS = 8;              // rows of a wave's 64 x 64 target tile
 // beads: 16 / 4 chains per CU at a time instead of 1) does not change a bit.
 template <int NBLK>
 struct SymShared {
-    double sx[3][NBLK][128];             // positions [axis][block][slot]; slots 64-127 repeat 0-63
+    double sx[NBLK][3][128];             // positions [block][axis][slot]; slots 64-127 repeat 0-63
+                                         // (a block's three axes within one ds_read2 offset range)
     union {
         double part[2 * NBLK][3][64 * NBLK];     // partial forces [partner block * 2 + k][axis][bead]
         double ytile[NBLK * NBLK][SYM_ROWS][64]; // launch prologue only
@@ -978,11 +979,11 @@ __device__ inline void sym_partials(const double (&y)[SYM_STEPS], unsigned live,
     const int lane = threadIdx.x & 63;
     double F0 = 0.0, F1 = 0.0, F2 = 0.0, R0 = 0.0, R1 = 0.0, R2 = 0.0;
     if (64 * ro.bi < n && 64 * ro.bj < n) {            // wave-uniform
-        const double x0 = sh.sx[0][ro.bi][lane], x1 = sh.sx[1][ro.bi][lane],
-                     x2 = sh.sx[2][ro.bi][lane];
-        const double *pj0 = &sh.sx[0][ro.bj][lane + ro.off];
-        const double *pj1 = &sh.sx[1][ro.bj][lane + ro.off];
-        const double *pj2 = &sh.sx[2][ro.bj][lane + ro.off];
+        const double x0 = sh.sx[ro.bi][0][lane], x1 = sh.sx[ro.bi][1][lane],
+                     x2 = sh.sx[ro.bi][2][lane];
+        const double *pj0 = &sh.sx[ro.bj][0][lane + ro.off];
+        const double *pj1 = &sh.sx[ro.bj][1][lane + ro.off];
+        const double *pj2 = &sh.sx[ro.bj][2][lane + ro.off];
 #pragma unroll
         for (int k = 0; k < SYM_STEPS; ++k) {
             const double d0 = x0 - pj0[k], d1 = x1 - pj1[k], d2 = x2 - pj2[k];
@@ -1030,8 +1031,8 @@ __device__ inline void sym_publish(SymShared<NBLK> &sh, int t, const double (&q)
 {
 #pragma unroll
     for (int ax = 0; ax < 3; ++ax) {
-        sh.sx[ax][t >> 6][t & 63] = q[ax];
-        sh.sx[ax][t >> 6][(t & 63) + 64] = q[ax];
+        sh.sx[t >> 6][ax][t & 63] = q[ax];
+        sh.sx[t >> 6][ax][(t & 63) + 64] = q[ax];
     }
 }
 
