@@ -124,11 +124,12 @@ def c5_distance(dev, C=256, n=256, L=20):
     # one force evaluation INSIDE the fused trajectory kernel: launch time against the
     # trajectory length (the target distances reach registers once per launch)
     ymat = lik.error_model.ymat_device(dev)
+    packed = lik.error_model.ypacked_device(dev)     # as HMCSampler._leapfrog passes it
     q, p = x.clone(), torch.zeros_like(x)
     t_l = {}
     for nst in (1, L):
         t_l[nst] = _timed(lambda: _native.pairdist_leapfrog(q, p, ymat, 4.0, (0.05, 0.0), True,
-                                                            1e-5, None, nst), 40, warm=5)
+                                                            1e-5, None, nst, packed=packed), 40, warm=5)
     t_e = (t_l[L] - t_l[1]) / (L - 1)
     s = HMCSampler(cond, x, 0.002, L, variable_name='coordinates', rng=DeviceRNG(0, dev))
     t_h = _timed(s.sample, 30, warm=3, settle_s=0.1)
@@ -245,8 +246,10 @@ def roofline_child():
     lik = make_distance_likelihood(np.abs(d + 0.05 * rs.standard_normal(len(d))), n)
     x = torch.from_numpy(truth.reshape(-1)[None, :] + 0.1 * rs.standard_normal((C, 3 * n))).to(dev)
     ymat = lik.error_model.ymat_device(dev)
+    packed = lik.error_model.ypacked_device(dev)
     q, p = x.clone(), torch.zeros_like(x)
-    settled(lambda: _native.pairdist_leapfrog(q, p, ymat, 4.0, (0.05, 0.0), True, 1e-5, None, L), 60)
+    settled(lambda: _native.pairdist_leapfrog(q, p, ymat, 4.0, (0.05, 0.0), True, 1e-5, None, L,
+                                              packed=packed), 60)
     # C1 shape: the multi-sweep Gibbs launch
     gips = _c1_gibbs(dev, C1_SHAPE['C'])
     settled(lambda: gips.sample_n(C1_SHAPE['sweeps'], record=False), 6, settle_s=0.2)
