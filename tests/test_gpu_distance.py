@@ -399,3 +399,16 @@ def test_sample_with_and_without_the_one_launch_energy(device):
     post = make_post(ys, n)
     assert post.conditional_factory(precision=3.0).native_energy_spec('coordinates') is not None
     assert post.native_energy_spec('coordinates') is None          # precision not fixed
+    # a precision prior with its variable fixed: out of the force, still a term of log_prob
+    from binf_amd.example.priors import GammaPrior
+    lik = make_distance_likelihood(ys, n)
+    pri = IsotropicGaussian(0.05, 0.0, name='coordinates_prior', variable_name='coordinates')
+    gam = GammaPrior(2.0, 0.5)
+    cond = Posterior({lik.name: lik}, {pri.name: pri, gam.name: gam}).conditional_factory(precision=3.0)
+    assert cond.native_leapfrog_spec('coordinates') is not None
+    assert cond.native_energy_spec('coordinates') is None
+    s = HMCSampler(cond, dev_t(x, device), 0.002, 4, variable_name='coordinates', rng=DeviceRNG(5, device),
+                   record_energies=True)
+    s.sample()
+    lp = cond.log_prob(coordinates=s.state)
+    assert torch.isfinite(s.last_e_after).all() and torch.isfinite(lp).all()
