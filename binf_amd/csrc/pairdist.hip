@@ -240,7 +240,7 @@ __device__ inline void block_sum_rows(const F &f, int D, int H, BlockSumScratch 
     const int group = threadIdx.x >> 3;
     const int nchunks = D <= 0 ? 1 : (D + NPY_BUFSIZE - 1) / NPY_BUFSIZE;
     const int R = GROUPS >= npaths ? GROUPS / npaths : 1;        // chunks per round
-    const int passes = GROUPS >= npaths ? 1 : npaths / GROUPS;   // passes per chunk
+    const int passes = GROUPS >= npaths ? 1 : (npaths + GROUPS - 1) / GROUPS;   // passes per chunk
 #pragma unroll
     for (int q = 0; q < ROWS; ++q) total[q] = 0.0;
     for (int c0 = 0; c0 < nchunks; c0 += R, ++round) {
@@ -249,7 +249,7 @@ __device__ inline void block_sum_rows(const F &f, int D, int H, BlockSumScratch 
             const int item = ps * GROUPS + group;                // (chunk of the round, path)
             const int cr = item >> H, path = item & (npaths - 1);
             const int chunk = c0 + cr;
-            const bool act = cr < R && chunk < nchunks;
+            const bool act = cr < R && chunk < nchunks && item < R * npaths;
             const int cbase = act ? chunk * NPY_BUFSIZE : 0;
             const int n = (D - cbase < NPY_BUFSIZE) ? D - cbase : NPY_BUFSIZE;
             const Leaf L = pairwise_leaf(n, H, act ? path : 0);
