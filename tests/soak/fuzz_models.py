@@ -101,6 +101,27 @@ for case in range(n_cases):
         outs.append((o.cpu().numpy(), s.last_e_after.cpu().numpy()))
     if not (np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])):
         report('pairdist fused leapfrog', n=n, C=C, L=L, prior=with_prior)
+    # one-launch energy (+ memo, packed targets) vs the per-step energy: three consecutive
+    # transitions with steps long enough to reject, adapted step sizes
+    if n <= 2048:
+        runs = []
+        step = float(rs.choice([0.002, 0.8, 1.6, 2.6])) / np.sqrt(3.0 * n) if rs.randint(2) else 0.002
+        draws = [(t(rs.standard_normal((C, 3 * n))), t(rs.uniform(size=C))) for _ in range(3)]
+        for fused in (True, False):
+            s = HMCSampler(cond, t(x), step, 4, timestep_adaption_limit=3, variable_name='coordinates',
+                           record_energies=True)
+            s.fused_energy = fused
+            o = [s.sample(p0=a, u=b).clone() for a, b in draws]
+            runs.append((torch.stack(o), s.last_e_before.clone(), s.last_e_after.clone(), s.n_accepted.clone(),
+                         s.timestep.clone()))
+        if not all(torch.equal(a, b) for a, b in zip(runs[0], runs[1])):
+            report('pairdist one-launch energy', n=n, C=C, prior=with_prior, step=step)
+        if 32 <= n <= 256:
+            em = lik.error_model
+            ym, pk = em.ymat_device(dev), em.ypacked_device(dev)
+            if not torch.equal(_native.pairdist_gauss_grad(t(x), ym, 2.0, packed=pk),
+                               _native.pairdist_gauss_grad(t(x), ym, 2.0)):
+                report('pairdist packed targets', n=n, C=C)
 
     # ---- MFMA gradient ------------------------------------------------------
     K = int(rs.randint(1, 65))
