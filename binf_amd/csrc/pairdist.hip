@@ -18,6 +18,12 @@
 //                   target distances read from a symmetric [n x n] matrix.
 // Each has a force-only kernel and a fused leapfrog (the whole _leapfrog() of
 // binf/samplers/hmc.py:92-125 in one launch) that are bit-identical to each other.
+//
+// Energy side (bit-identical to numpy: correctly rounded sqrt, np.sum's pairwise order):
+//   pairdist_chi2_rows_kernel  chi^2 of one or two chains per workgroup, distances formed on
+//                              the fly, with the per-chain two-entry memo of rowsum.hpp;
+//   pairdist_energy_kernel     HMCSampler's E = 0.5 sum p^2 - log_prob for likelihood + one
+//                              isotropic Gaussian prior in one launch (memo check included).
 #include <stdlib.h>
 #include <atomic>
 #include "rowsum.hpp"
