@@ -10,7 +10,9 @@ from binf_amd.pdf.posteriors import Posterior
 from binf_amd.samplers.hmc import HMCSampler
 from binf_amd.samplers.rng import DeviceRNG
 dev = torch.device('cuda:0')
-n, C, L = 256, 256, 20
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+C = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+L = 20
 rs = np.random.RandomState(0)
 truth = rs.standard_normal((n, 3)) * 2.0
 I, J = np.triu_indices(n, 1)
