@@ -126,7 +126,7 @@ SIGNATURES = {
     'binf_pairdist_pack_targets_f64': (_i32, [_vp, _vp, _i64, _vp]),
     'binf_pairdist_gauss_grad_packed_f64': (_i32, [_vp, _vp, _vp, _f64, _vp, _vp, _i64,
                                                    _i64, _vp]),
-    'binf_pairdist_leapfrog_packed_f64': (_i32, [_vp, _vp, _vp, _vp, _f64, _vp, _i32, _f64,
+    'binf_pairdist_leapfrog_packed_f64': (_i32, [_vp, _vp, _vp, _vp, _vp, _f64, _vp, _i32, _f64,
                                                  _f64, _i32, _f64, _vp, _i32, _i64,
                                                  _i64, _i32, _vp]),
     'binf_rng_uniform_f64': (_i32, [_vp, _i64, ctypes.c_uint64, ctypes.c_uint64,
@@ -1129,9 +1129,10 @@ def rng_fill(kind, out, seed, offset, shape=None, elem_offset=0):
 
 @_launcher
 def pairdist_leapfrog(q, p, ymat, precision, prior, prior_first, timestep,
-                      dt_chain, nsteps, mode=MODE_EXACT, packed=None):
+                      dt_chain, nsteps, mode=MODE_EXACT, packed=None, q_from=None):
     """In-place leapfrog of (q, p) for the restraint posterior; prior is None
-    or (k, x0) of an isotropic Gaussian on the coordinates."""
+    or (k, x0) of an isotropic Gaussian on the coordinates.  ``q_from``: start positions
+    read from there instead of ``q`` (which then only receives the end positions)."""
     C, D = _cd(q)
     if D % 3:
         raise ValueError('coordinates must be [n_chains, 3 * n_beads]')
@@ -1139,7 +1140,8 @@ def pairdist_leapfrog(q, p, ymat, precision, prior, prior_first, timestep,
     tau, tau_chain = _precision_args(precision, C, q.device)
     k, x0 = prior if prior is not None else (0.0, 0.0)
     rc = lib().binf_pairdist_leapfrog_packed_f64(
-        dptr(q, numel=C * D, name='q'), dptr(p, numel=C * D, name='p'),
+        dptr(q, numel=C * D, name='q'), dptr(q_from, numel=C * D, name='q_from'),
+        dptr(p, numel=C * D, name='p'),
         dptr(ymat, numel=n * n, name='ymat'), _packed_ptr(packed, n), tau,
         dptr(tau_chain, numel=C, name='precision'), int(prior is not None),
         float(k), float(x0), int(bool(prior_first)), float(timestep),

@@ -681,6 +681,7 @@ pairdist_grad_kernel(const double *x, const double *ymat, double tau,
 // ---------------------------------------------------------------------------
 struct PairLeapArgs {
     double *q;               // [C x 3n] in/out
+    const double *q_from;    // [C x 3n] start positions when they are not to be read from q, or null
     double *p;               // [C x 3n] in/out
     const double *ymat;      // [n x n]
     const double *ypk;       // sym kernels: the targets in lane order (sym_pack_targets_kernel), or null
@@ -704,6 +705,7 @@ __global__ void __launch_bounds__(256 * LANES) pairdist_leapfrog_kernel(const Pa
     const int n = a.n_beads;
     const int64_t c = blockIdx.x;
     double *qc = a.q + c * 3 * (int64_t)n;
+    const double *qs = (a.q_from ? a.q_from : a.q) + c * 3 * (int64_t)n;
     double *pc = a.p + c * 3 * (int64_t)n;
     const double tau = a.tau_chain ? a.tau_chain[c] : a.tau;
     const double dt = a.dt_chain ? a.dt_chain[c] : a.timestep;
@@ -724,7 +726,7 @@ __global__ void __launch_bounds__(256 * LANES) pairdist_leapfrog_kernel(const Pa
         const int i = slot + 256 * b;
 #pragma unroll
         for (int ax = 0; ax < 3; ++ax) {
-            q[b][ax] = (i < n) ? qc[3 * i + ax] : 0.0;
+            q[b][ax] = (i < n) ? qs[3 * i + ax] : 0.0;
             const double pv = (i < n) ? pc[3 * i + ax] : 0.0;
             if (PLDS) { if (i < n) sp[3 * i + ax] = pv; }
             else p[b][ax] = pv;
@@ -1093,6 +1095,7 @@ __global__ void __launch_bounds__(1024) pairdist_leapfrog_sym_kernel(const PairL
     sym_load_targets<NBLK, PK>(y, live, sh, a.ymat, a.ypk, n, ro);
     for (int64_t c = blockIdx.x; c < a.n_chains; c += gridDim.x) {
         double *qc = a.q + c * 3 * (int64_t)n;
+        const double *qs = (a.q_from ? a.q_from : a.q) + c * 3 * (int64_t)n;
         double *pc = a.p + c * 3 * (int64_t)n;
         const double tau = a.tau_chain ? a.tau_chain[c] : a.tau;
         const double dt = a.dt_chain ? a.dt_chain[c] : a.timestep;
@@ -1100,7 +1103,7 @@ __global__ void __launch_bounds__(1024) pairdist_leapfrog_sym_kernel(const PairL
         double q[3] = {0.0, 0.0, 0.0}, p[3] = {0.0, 0.0, 0.0};
         if (owner) {
 #pragma unroll
-            for (int ax = 0; ax < 3; ++ax) { q[ax] = qc[3 * t + ax]; p[ax] = pc[3 * t + ax]; }
+            for (int ax = 0; ax < 3; ++ax) { q[ax] = qs[3 * t + ax]; p[ax] = pc[3 * t + ax]; }
         }
         if (t < 64 * NBLK) sym_publish<NBLK>(sh, t, q);
         __syncthreads();
@@ -1494,12 +1497,13 @@ extern "C" int32_t binf_pairdist_leapfrog_f64(double *q, double *p, const double
                                               const double *dt_chain, int32_t nsteps, int64_t C,
                                               int64_t n_beads, int32_t mode, void *stream)
 {
-    return binf_pairdist_leapfrog_packed_f64(q, p, ymat, nullptr, precision, precision_chain, has_prior,
-                                             prior_k, prior_x0, prior_first, timestep, dt_chain, nsteps,
-                                             C, n_beads, mode, stream);
+    return binf_pairdist_leapfrog_packed_f64(q, nullptr, p, ymat, nullptr, precision, precision_chain,
+                                             has_prior, prior_k, prior_x0, prior_first, timestep, dt_chain,
+                                             nsteps, C, n_beads, mode, stream);
 }
 
-extern "C" int32_t binf_pairdist_leapfrog_packed_f64(double *q, double *p, const double *ymat,
+extern "C" int32_t binf_pairdist_leapfrog_packed_f64(double *q, const double *q_from, double *p,
+                                                     const double *ymat,
                                                      const double *packed, double precision,
                                                      const double *precision_chain,
                                                      int32_t has_prior, double prior_k, double prior_x0,
@@ -1517,7 +1521,8 @@ extern "C" int32_t binf_pairdist_leapfrog_packed_f64(double *q, double *p, const
         return fail(BINF_E_UNSUPPORTED, "pairdist_leapfrog: n_beads=%lld > 1024 not covered by the fused kernel", (long long)n_beads);
     if (C > 0x7fffffffLL) return fail(BINF_E_UNSUPPORTED, "pairdist_leapfrog: too many chains");
     PairLeapArgs a;
-    a.q = q; a.p = p; a.ymat = ymat; a.ypk = packed; a.tau_chain = precision_chain; a.dt_chain = dt_chain;
+    a.q = q; a.q_from = (q_from == q) ? nullptr : q_from; a.p = p; a.ymat = ymat; a.ypk = packed;
+    a.tau_chain = precision_chain; a.dt_chain = dt_chain;
     a.tau = precision; a.timestep = timestep; a.prior_k = prior_k; a.prior_x0 = prior_x0;
     a.has_prior = has_prior ? 1 : 0; a.prior_first = prior_first ? 1 : 0;
     a.nsteps = nsteps; a.n_beads = (int32_t)n_beads; a.n_chains = C;

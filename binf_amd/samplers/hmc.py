@@ -555,11 +555,14 @@ class HMCSampler(object):
         return q_out
 
     # -- generic tier --------------------------------------------------------
-    def _leapfrog(self, q, p, timestep, nsteps):
+    def _leapfrog(self, q, p, timestep, nsteps, q_from=None):
         """Velocity-Verlet integration, IN PLACE on ``q`` and ``p`` (reference
         ``hmc.py:92-125``: half kick, ``nsteps - 1`` x [drift, kick], drift,
         half kick; ``nsteps + 1`` gradient calls).  ``timestep`` is a float or
-        a ``[C]`` tensor of per-chain step sizes.  Returns ``(q, p)``."""
+        a ``[C]`` tensor of per-chain step sizes.  Returns ``(q, p)``.
+        ``q_from`` (not in the reference): the start positions, when ``q`` is only to
+        receive the end positions -- ``sample()`` then needs no copy of its state
+        (``hmc.py:140-141``) where a fused kernel can read the start from elsewhere."""
         name = self._variable_name
         pdf = self.pdf
         mode = _MODES[self.mode]
@@ -580,10 +583,20 @@ class HMCSampler(object):
             # the whole integration in one launch (bit-identical to the loop)
             _, em, precision, prior, prior_first = leap
             packed = getattr(em, 'ypacked_device', None)
+            qf = None
+            if q_from is not None:
+                qf = _as2d(q_from)
+                if not (qf.is_contiguous() and qf.shape == q2.shape and qf.dtype == q2.dtype
+                        and qf.device == q2.device):
+                    q2.copy_(qf)
+                    qf = None
             _native.pairdist_leapfrog(q2, p2, em.ymat_device(q2.device), precision,
                                       prior, prior_first, dt, dtc, nsteps, mode,
-                                      packed=packed(q2.device) if packed is not None else None)
+                                      packed=packed(q2.device) if packed is not None else None,
+                                      q_from=qf)
             return q, p
+        if q_from is not None:
+            q2.copy_(_as2d(q_from))
         if leap is not None and leap[0] == 'poly' and q2.is_cuda and q2.shape[1] <= 64:
             # gradient, partial-sum reduction, kick and drift of every step in one launch
             # each (bit-identical to the loop below)
@@ -620,11 +633,18 @@ class HMCSampler(object):
             _, em, precision, prior, prior_first, lik = espec
             E = lambda x, mom: _dist.native_hmc_energy(lik, x, mom, precision, prior, prior_first)
 
-        q = q0.clone()
         p = p0 if own_p else p0.clone()
-        e_before = E(q, p)
-        self._leapfrog(q.view(shape), p.view(shape),
-                       self._timestep if dtc is None else dtc, self.nsteps)
+        e_before = E(q0, p)
+        step = self._timestep if dtc is None else dtc
+        if type(self)._leapfrog is HMCSampler._leapfrog:
+            # the trajectory starts from q0 and ends in q: no copy of the state first where the
+            # fused leapfrog reads its start from q0 itself
+            q = torch.empty_like(q0)
+            self._leapfrog(q.view(shape), p.view(shape), step, self.nsteps, q_from=q0.view(shape))
+        else:
+            # a subclass's integrator has the reference's signature (hmc.py:92): in place on a copy
+            q = q0.clone()
+            self._leapfrog(q.view(shape), p.view(shape), step, self.nsteps)
         e_after = E(q, p)
         _native.accept_select(q, q0, e_before, e_after, u, q, accepted,
                               self.n_accepted, dtc, adapt,

@@ -758,8 +758,12 @@ int32_t binf_pairdist_leapfrog_f64(double *q, double *p, const double *ymat,
                                    int32_t prior_first, double timestep,
                                    const double *dt_chain, int32_t nsteps, int64_t C,
                                    int64_t n_beads, int32_t mode, void *stream);
-/* the same with the packed targets (null: as binf_pairdist_leapfrog_f64) */
-int32_t binf_pairdist_leapfrog_packed_f64(double *q, double *p, const double *ymat,
+/* the same with the packed targets (null: as binf_pairdist_leapfrog_f64) and, optionally,
+ * the start positions read from q_from [C * 3n] instead of q (q then only receives the end
+ * positions: the copy of the state HMCSampler.sample() makes before integrating,
+ * hmc.py:140-141, is not needed); q_from null or == q: in place. */
+int32_t binf_pairdist_leapfrog_packed_f64(double *q, const double *q_from, double *p,
+                                          const double *ymat,
                                           const double *packed, double precision,
                                           const double *precision_chain, int32_t has_prior,
                                           double prior_k, double prior_x0, int32_t prior_first,

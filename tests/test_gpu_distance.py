@@ -412,3 +412,24 @@ def test_sample_with_and_without_the_one_launch_energy(device):
     s.sample()
     lp = cond.log_prob(coordinates=s.state)
     assert torch.isfinite(s.last_e_after).all() and torch.isfinite(lp).all()
+
+
+@pytest.mark.parametrize('n,C', [(48, 7), (256, 5), (300, 3), (700, 2), (20, 4)])
+def test_leapfrog_reading_its_start_from_another_buffer(device, n, C):
+    """binf_pairdist_leapfrog_packed_f64 with q_from: the trajectory of the in-place call on a
+    copy of the start, the start left untouched -- what lets sample() skip the copy of its
+    state (every force kernel: one wave per block pair, one-sided loops, with and without
+    the packed targets)."""
+    ys, x = synth(n, C, 5 * n)
+    em = make_distance_likelihood(ys, n).error_model
+    ymat, packed = em.ymat_device(device), em.ypacked_device(device)
+    rs = np.random.RandomState(n)
+    x0 = dev_t(x, device)
+    p0 = dev_t(rs.standard_normal((C, 3 * n)), device)
+    for pk in (None, packed):
+        qa, pa = x0.clone(), p0.clone()
+        _native.pairdist_leapfrog(qa, pa, ymat, 2.0, (0.05, 0.1), False, 2e-3, None, 4, packed=pk)
+        keep = x0.clone()
+        qb, pb = torch.full_like(x0, float('nan')), p0.clone()
+        _native.pairdist_leapfrog(qb, pb, ymat, 2.0, (0.05, 0.1), False, 2e-3, None, 4, packed=pk, q_from=x0)
+        assert torch.equal(qa, qb) and torch.equal(pa, pb) and torch.equal(x0, keep)
