@@ -133,6 +133,8 @@ SIGNATURES = {
                                     _i64, _vp]),
     'binf_rng_normal_f64': (_i32, [_vp, _i64, ctypes.c_uint64, ctypes.c_uint64,
                                    _i64, _vp]),
+    'binf_rng_normal_zig_uniform_f64': (_i32, [_vp, _i64, _vp, _i64, ctypes.c_uint64, ctypes.c_uint64,
+                                               ctypes.c_uint64, _i64, _i64, _vp]),
     'binf_rng_normal_zig_f64': (_i32, [_vp, _i64, ctypes.c_uint64,
                                        ctypes.c_uint64, _i64, _vp]),
     'binf_rng_gamma_f64': (_i32, [_vp, _i64, _f64, ctypes.c_uint64,
@@ -1125,6 +1127,20 @@ def rng_fill(kind, out, seed, offset, shape=None, elem_offset=0):
         raise ValueError('unknown draw kind %r' % (kind,))
     check(rc, 'binf_rng_%s_f64' % kind)
     return out
+
+
+@_launcher
+def rng_fill_normal_zig_uniform(normals, uniforms, seed, offset_normals, offset_uniforms,
+                                elem_offset_normals=0, elem_offset_uniforms=0):
+    """binf_rng_normal_zig_uniform_f64: ``rng_fill('normal_zig', normals, ...)`` and
+    ``rng_fill('uniform', uniforms, ...)`` in one launch."""
+    m = 2 ** 64 - 1
+    rc = lib().binf_rng_normal_zig_uniform_f64(
+        dptr(normals, numel=normals.numel(), name='normals'), normals.numel(),
+        dptr(uniforms, numel=uniforms.numel(), name='uniforms'), uniforms.numel(),
+        int(seed) & m, int(offset_normals) & m, int(offset_uniforms) & m,
+        int(elem_offset_normals), int(elem_offset_uniforms), stream_handle(normals.device))
+    check(rc, 'binf_rng_normal_zig_uniform_f64')
 
 
 @_launcher

@@ -51,9 +51,28 @@ rng_normal_kernel(double *out, int64_t n, uint64_t seed, uint64_t offset, int64_
     }
 }
 
-__global__ void __launch_bounds__(256)
-rng_normal_zig_kernel(double *out, int64_t n, uint64_t seed, uint64_t offset, int64_t e0)
+// The uniform draws of an HMC transition ride along (rng_normal_zig_uniform_kernel): [C]
+// acceptance draws next to [C x D] momenta are not worth a launch of their own.
+struct UniformTail {
+    double *out;
+    int64_t n;
+    uint64_t offset;
+    int64_t e0;
+};
+
+template <bool TAIL>
+__device__ inline void normal_zig_body(double *out, int64_t n, uint64_t seed, uint64_t offset, int64_t e0,
+                                       const UniformTail u)
 {
+    if (TAIL) {
+        const int64_t g0 = u.e0 >> 1;
+        const int64_t np = ((u.e0 + u.n + 1) >> 1) - g0;
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < np; i += (int64_t)gridDim.x * 256) {
+            double a, b;
+            uniforms2(g0 + i, seed, u.offset, a, b);
+            store_pair(u.out, u.n, u.e0, g0 + i, a, b);
+        }
+    }
     __shared__ double zx[ZIG_C + 1];
     __shared__ double zr[ZIG_C];
     for (int k = threadIdx.x; k <= ZIG_C; k += 256) zx[k] = ZIG_X[k];
@@ -116,6 +135,19 @@ rng_normal_zig_kernel(double *out, int64_t n, uint64_t seed, uint64_t offset, in
 }
 
 __global__ void __launch_bounds__(256)
+rng_normal_zig_kernel(double *out, int64_t n, uint64_t seed, uint64_t offset, int64_t e0)
+{
+    normal_zig_body<false>(out, n, seed, offset, e0, UniformTail{nullptr, 0, 0, 0});
+}
+
+__global__ void __launch_bounds__(256)
+rng_normal_zig_uniform_kernel(double *out, int64_t n, uint64_t seed, uint64_t offset, int64_t e0,
+                              const UniformTail u)
+{
+    normal_zig_body<true>(out, n, seed, offset, e0, u);
+}
+
+__global__ void __launch_bounds__(256)
 rng_gamma_kernel(double *out, int64_t n, double shape, uint64_t seed, uint64_t offset, int64_t e0)
 {
     for (int64_t l = (int64_t)blockIdx.x * 256 + threadIdx.x; l < n;
@@ -167,6 +199,32 @@ extern "C" int32_t binf_rng_normal_f64(double *out, int64_t n, uint64_t seed,
                                                                                      elem_offset);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "rng_normal launch");
+    return 0;
+}
+
+extern "C" int32_t binf_rng_normal_zig_uniform_f64(double *normals, int64_t n_normals,
+                                                   double *uniforms, int64_t n_uniforms,
+                                                   uint64_t seed, uint64_t offset_normals,
+                                                   uint64_t offset_uniforms,
+                                                   int64_t elem_offset_normals,
+                                                   int64_t elem_offset_uniforms, void *stream)
+{
+    if (n_normals < 0 || n_uniforms < 0 || elem_offset_normals < 0 || elem_offset_uniforms < 0)
+        return fail(BINF_E_ARG, "rng_normal_zig_uniform: negative size / offset");
+    if (offset_normals >> 48) return fail(BINF_E_ARG, "rng_normal_zig_uniform: offset must be < 2^48");
+    if (offset_normals == offset_uniforms)
+        return fail(BINF_E_ARG, "rng_normal_zig_uniform: the two streams need different offsets");
+    if (n_normals == 0 && n_uniforms == 0) return 0;
+    if ((n_normals > 0 && !normals) || (n_uniforms > 0 && !uniforms))
+        return fail(BINF_E_ARG, "rng_normal_zig_uniform: null buffer");
+    if (n_normals == 0)
+        return binf_rng_uniform_f64(uniforms, n_uniforms, seed, offset_uniforms, elem_offset_uniforms, stream);
+    UniformTail u;
+    u.out = uniforms; u.n = n_uniforms; u.offset = offset_uniforms; u.e0 = elem_offset_uniforms;
+    rng_normal_zig_uniform_kernel<<<dim3(rng_grid((n_normals + 9) / 8)), 256, 0, (hipStream_t)stream>>>(
+        normals, n_normals, seed, offset_normals, elem_offset_normals, u);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "rng_normal_zig_uniform launch");
     return 0;
 }
 

@@ -157,7 +157,11 @@ class HMCSampler(object):
             if _native.gauss_persist_covers(D):
                 return self._sample_n_fused_rng(1)
             return self._sample_long_fused_rng(name, q0, shape)
-        if p0 is None:
+        both = getattr(self.rng, 'normal_uniform', None)
+        if p0 is None and u is None and both is not None:
+            p0, u = both((C, D), C, dev)           # one launch for the transition's two draws
+            own_p = True
+        elif p0 is None:
             p0 = self.rng.normal((C, D), dev)
             own_p = True
         else:

@@ -124,6 +124,20 @@ class DeviceRNG(object):
     def uniform(self, n, device):
         return self._fill('uniform', (int(n),), device, 1)
 
+    def normal_uniform(self, shape, n, device):
+        """``(normal(shape, device), uniform(n, device))`` -- the two draws of one HMC
+        transition, in that order (hmc.py:146,151) -- from ONE launch; the same values,
+        the same stream positions as the two calls."""
+        if self._normal_kind != 'normal_zig':
+            return self.normal(shape, device), self.uniform(n, device)
+        from binf_amd import _native
+        p = torch.empty(tuple(shape), dtype=torch.float64, device=device)
+        u = torch.empty((int(n),), dtype=torch.float64, device=device)
+        _native.rng_fill_normal_zig_uniform(p, u, self.seed, self.offset, self.offset + 1,
+                                            self._elem_offset(shape), self._elem_offset((int(n),)))
+        self.offset += 2
+        return p, u
+
     def gamma(self, shape, n, device):
         """Gamma(shape, 1) variates, one per chain (GammaSampler's ``gamma=``)."""
         return self._fill('gamma', (int(n),), device, 128, shape=shape)

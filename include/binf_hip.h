@@ -39,7 +39,7 @@ extern "C" {
  *    binf_hmc_sample_n_gauss_big_f64 / _rng_f64.
  * 4: binf_pairdist_packed_targets_bytes, binf_pairdist_pack_targets_f64,
  *    binf_pairdist_gauss_grad_packed_f64, binf_pairdist_leapfrog_packed_f64,
- *    binf_pairdist_hmc_energy_f64; the chi^2
+ *    binf_pairdist_hmc_energy_f64, binf_rng_normal_zig_uniform_f64; the chi^2
  *    memos of binf_poly_gauss_logp_memo_f64 / binf_pairdist_gauss_logp_memo_f64 hold two
  *    entries per chain (their buffers are twice the ABI 3 size). */
 #define BINF_ABI_VERSION 4
@@ -790,6 +790,16 @@ int32_t binf_rng_normal_f64(double *out, int64_t n, uint64_t seed, uint64_t offs
 int32_t binf_rng_normal_zig_f64(double *out, int64_t n, uint64_t seed, uint64_t offset,
                                 int64_t elem_offset, void *stream);  /* 1024-layer
                                                    ziggurat; offset < 2^48          */
+/* The two draws of one HMC transition (hmc.py:146,151) in one launch: what
+ * binf_rng_normal_zig_f64(normals, n_normals, seed, offset_normals, elem_offset_normals) and
+ * binf_rng_uniform_f64(uniforms, n_uniforms, seed, offset_uniforms, elem_offset_uniforms)
+ * write, bit for bit (the streams are those of the separate calls; their offsets must
+ * differ). */
+int32_t binf_rng_normal_zig_uniform_f64(double *normals, int64_t n_normals, double *uniforms,
+                                        int64_t n_uniforms, uint64_t seed,
+                                        uint64_t offset_normals, uint64_t offset_uniforms,
+                                        int64_t elem_offset_normals,
+                                        int64_t elem_offset_uniforms, void *stream);
 int32_t binf_rng_gamma_f64(double *out, int64_t n, double shape, uint64_t seed,
                            uint64_t offset, int64_t elem_offset,
                            void *stream);                         /* Marsaglia-Tsang  */

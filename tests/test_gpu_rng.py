@@ -339,3 +339,24 @@ def test_long_chain_generator_equals_sampling_from_its_own_dump(device, C, D, L,
         assert abs(z.mean()) < 5 / np.sqrt(z.size) and abs(z.var() - 1.0) < 8 / np.sqrt(z.size)
     uu = u.cpu().numpy()
     assert (0.0 <= uu).all() and (uu < 1.0).all()
+
+
+@pytest.mark.parametrize('C,D,coff', [(1, 1, 0), (3, 7, 0), (5, 768, 0), (256, 768, 0), (4096, 1024, 0), (7, 33, 11)])
+def test_the_two_draws_of_a_transition_in_one_launch(device, C, D, coff):
+    """DeviceRNG.normal_uniform / binf_rng_normal_zig_uniform_f64: the values and stream
+    positions of normal() followed by uniform(), for shards too; a Box-Muller generator
+    falls back to the two calls; the C entry point refuses equal offsets."""
+    a, b = DeviceRNG(5, device, chain_offset=coff), DeviceRNG(5, device, chain_offset=coff)
+    a.offset = b.offset = 9
+    for _ in range(2):
+        p1, u1 = a.normal((C, D), device), a.uniform(C, device)
+        p2, u2 = b.normal_uniform((C, D), C, device)
+        assert torch.equal(p1, p2) and torch.equal(u1, u2) and a.offset == b.offset
+    bm1, bm2 = DeviceRNG(5, device, normal='box_muller'), DeviceRNG(5, device, normal='box_muller')
+    p1, u1 = bm1.normal((C, D), device), bm1.uniform(C, device)
+    p2, u2 = bm2.normal_uniform((C, D), C, device)
+    assert torch.equal(p1, p2) and torch.equal(u1, u2) and bm1.offset == bm2.offset
+    buf = torch.empty(4, dtype=torch.float64, device=device)
+    rc = _native.lib().binf_rng_normal_zig_uniform_f64(buf.data_ptr(), 4, buf.data_ptr(), 4, 1, 3, 3, 0, 0,
+                                                       _native.stream_handle(device))
+    assert rc == _native.E_ARG
