@@ -141,6 +141,39 @@ def native_log_prob(likelihood, fwm, em, fwm_vars, em_vars):
     return _native.pairdist_gauss_logp(x2, I, J, ys, em_vars['precision'])
 
 
+def make_restraint_gibbs_sampler(posterior, timestep, nsteps, start_state, **hmc_kwargs):
+    """Gibbs-within-HMC for the restraint posterior, wired like the example's
+    ``make_hmc_sampler`` (reference scheme ``binf/example/samplers.py:94-111``): HMC on the
+    coordinates given the precision, the conjugate Gamma draw of the precision given the
+    coordinates (one precision per chain).  ``posterior`` holds the restraint likelihood, a
+    prior on ``coordinates`` and a :class:`GammaPrior` on ``precision``."""
+    from binf_amd.example.samplers import GammaSampler
+    from binf_amd.samplers.gibbs import GibbsSampler
+    from binf_amd.samplers.hmc import HMCSampler
+
+    class RestraintPrecisionSampler(GammaSampler):
+        """The example's GammaSampler with the restraint likelihood's names."""
+
+        def _calculate_shape(self):
+            n = len(self.pdf.likelihoods['restraints'].error_model.ys)
+            return 0.5 * n + self._get_prior().shape - 1
+
+        def _unit_precision_log_prob(self):
+            return self.pdf.likelihoods['restraints'].log_prob(
+                coordinates=self.pdf['coordinates'].value, precision=1.0)
+
+    coords = start_state.variables['coordinates']
+    precision = start_state.variables['precision']
+    rng = hmc_kwargs.get('rng')
+    coords_sampler = HMCSampler(posterior.conditional_factory(precision=precision), coords, timestep,
+                                nsteps, variable_name='coordinates', **hmc_kwargs)
+    precision_sampler = RestraintPrecisionSampler(
+        posterior.conditional_factory(coordinates=coords), precision,
+        rng=rng if hasattr(rng, 'gamma') else None)
+    return GibbsSampler(posterior, start_state, {'coordinates': coords_sampler,
+                                                 'precision': precision_sampler})
+
+
 def native_hmc_energy(likelihood, x2, p2, precision, prior, prior_first):
     """``0.5 * sum(p**2) - log_prob`` of a posterior made of this likelihood and at most one
     isotropic Gaussian prior ``(k, x0)`` (``Posterior.native_energy_spec``), one launch:

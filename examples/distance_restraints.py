@@ -38,6 +38,9 @@ def main(argv=None):
     ap.add_argument('--timestep', type=float, default=0.002)
     ap.add_argument('--precision', type=float, default=4.0)
     ap.add_argument('--seed', type=int, default=0)
+    ap.add_argument('--gibbs', action='store_true',
+                    help='sample the noise precision too (Gibbs: HMC on the coordinates, conjugate '
+                         'Gamma draw of one precision per chain)')
     args = ap.parse_args(argv)
 
     if 'RANK' in os.environ and int(os.environ.get('WORLD_SIZE', '1')) > 1:
@@ -63,12 +66,32 @@ def main(argv=None):
 
     rng = DeviceRNG(args.seed + 1 + 1000 * rank, dev)
     start = torch.from_numpy(truth.reshape(1, -1)).to(dev) + 0.3 * rng.normal((C, 3 * n), dev)
-    sampler = HMCSampler(cond, start, args.timestep, args.nsteps,
-                         variable_name='coordinates', rng=rng)
     n_keep = max(1, (args.iterations + args.thin - 1) // args.thin)
     store = SampleStore(n_keep, C, 3 * n, thin=args.thin, device=dev)
-    for i in range(args.iterations):
-        store.record(sampler.sample())
+    if args.gibbs:
+        # the reference's Gibbs scheme around the same kernels: coordinates | precision by HMC,
+        # precision | coordinates by the conjugate Gamma draw (binf/example/samplers.py:27-51)
+        from binf_amd.example.distance import make_restraint_gibbs_sampler
+        from binf_amd.example.priors import GammaPrior
+        from binf_amd.samplers import BinfState
+        full = Posterior({lik.name: lik}, {prior.name: prior, 'precision_prior': GammaPrior(1.0, 0.2)})
+        state = BinfState({'coordinates': start,
+                           'precision': torch.full((C,), 1.0, dtype=torch.float64, device=dev)})
+        gips = make_restraint_gibbs_sampler(full, args.timestep, args.nsteps, state, rng=rng,
+                                            timestep_adaption_limit=args.iterations // 2)
+        for i in range(args.iterations):
+            st = gips.sample()
+            store.record(st.variables['coordinates'])
+        sampler = gips.subsamplers['coordinates']
+        tau = st.variables['precision']
+        if rank == 0:
+            print('sampled precision          : {:.2f} +- {:.2f} over the chains (data generated '
+                  'with {:.2f})'.format(float(tau.mean()), float(tau.std()), args.precision))
+    else:
+        sampler = HMCSampler(cond, start, args.timestep, args.nsteps,
+                             variable_name='coordinates', rng=rng)
+        for i in range(args.iterations):
+            store.record(sampler.sample())
     kept = store.gather(args.chains)                                 # [n_kept, chains, 3n]
     if rank == 0:
         x = kept[-1].reshape(-1, n, 3)

@@ -121,6 +121,9 @@ def test_example_distance_restraints_keeps_the_structure(device):
         ['--chains', '24', '--beads', '48', '--iterations', '60', '--thin', '10'])
     assert kept.shape == (6, 24, 144)
     assert torch.isfinite(kept).all()
+    kept = _load_example('distance_restraints').main(
+        ['--chains', '8', '--beads', '40', '--iterations', '40', '--thin', '10', '--gibbs'])
+    assert kept.shape == (4, 8, 120) and torch.isfinite(kept).all()
 
 
 def test_example_custom_pdf_samples_both_wells(device):
@@ -174,3 +177,54 @@ def test_gibbs_launches_with_two_different_moves_agree_on_the_posterior(device):
     z = tau * rate                                     # ~ Gamma(10, 1): mean 10, variance 10
     assert abs(z.mean() - 10.0) < 6 * np.sqrt(10.0 / len(z))
     assert abs(z.var() - 10.0) < 6 * 10.0 * np.sqrt(2.0 / len(z) + 0.6 / len(z))
+
+
+@pytest.mark.parametrize('n', [24, 48])
+def test_gibbs_over_coordinates_and_precision_recovers_the_noise_level(device, n):
+    """The restraint model inside the reference's Gibbs scheme (HMC on the coordinates, the
+    conjugate Gamma draw of the precision, one precision per chain): the sampled precision
+    settles at the precision the target distances were generated with -- the plug-in
+    surface, the per-chain precisions of the fused kernels and the chi^2 memo (shared by
+    the HMC energies and the Gamma update) together.  24 beads: one-sided force loops;
+    48: one wave per block pair."""
+    from binf_amd.example.distance import make_distance_likelihood, make_restraint_gibbs_sampler
+    from binf_amd.samplers import BinfState
+    C, tau_true = 64, 25.0
+    rs = np.random.RandomState(n)
+    truth = np.cumsum(rs.standard_normal((n, 3)), axis=0) * 0.6
+    I, J = np.triu_indices(n, 1)
+    d = np.sqrt(((truth[I] - truth[J]) ** 2).sum(1))
+    ys = np.abs(d + rs.standard_normal(d.shape) / np.sqrt(tau_true))
+    lik = make_distance_likelihood(ys, n)
+    post = Posterior({lik.name: lik},
+                     {'coordinates_prior': IsotropicGaussian(0.01, 0.0, name='coordinates_prior',
+                                                             variable_name='coordinates'),
+                      'precision_prior': GammaPrior(1.0, 0.2)})
+    rng = DeviceRNG(7, device)
+    start = BinfState({'coordinates': torch.from_numpy(truth.reshape(1, -1)).to(device)
+                       + 0.05 * rng.normal((C, 3 * n), device),
+                       'precision': torch.full((C,), 1.0, dtype=torch.float64, device=device)})
+    gips = make_restraint_gibbs_sampler(post, 0.01, 10, start, rng=rng, timestep_adaption_limit=150)
+    taus, cond_means = [], []
+    n_pairs = len(ys)
+    # GammaSampler (binf/example/samplers.py:27-51): shape = N/2 + alpha - 1, rate = chi^2/2 + the
+    # CONDITIONAL prior's rate, which is its shape (quirk Q6: GammaPrior.clone)
+    shape, prior_rate = 0.5 * n_pairs + 1.0 - 1.0, 1.0
+    for it in range(400):
+        st = gips.sample()
+        if it >= 200 and it % 5 == 0:
+            taus.append(st.variables['precision'].clone())
+            chi2 = -2.0 * lik.log_prob(coordinates=st.variables['coordinates'], precision=1.0)
+            cond_means.append(shape / (0.5 * chi2 + prior_rate))
+    taus = torch.stack(taus).cpu().numpy()
+    cond_means = torch.stack(cond_means).cpu().numpy()
+    acc = float(gips.subsamplers['coordinates'].acceptance_rate.mean())
+    assert 0.3 < acc <= 1.0
+    # conjugate identity: E[tau] = E[ E[tau | coordinates] ], Monte-Carlo error of the sample mean
+    rel_sd = 1.0 / np.sqrt(shape)
+    n_eff = taus.size
+    assert abs(taus.mean() / cond_means.mean() - 1.0) < 6.0 * rel_sd / np.sqrt(n_eff)
+    # ... and the level itself: the data's precision, pulled down by the prior rate against
+    # chi^2 / 2 ~ N / (2 tau) and up by the 3n coordinates that absorb residuals
+    assert 0.6 * tau_true < taus.mean() < 1.3 * tau_true, taus.mean()
+    assert taus.std(axis=0).mean() < 4.0 * taus.mean() * rel_sd
