@@ -120,8 +120,9 @@ SIGNATURES = {
     'binf_pairdist_leapfrog_f64': (_i32, [_vp, _vp, _vp, _f64, _vp, _i32, _f64,
                                           _f64, _i32, _f64, _vp, _i32, _i64,
                                           _i64, _i32, _vp]),
-    'binf_pairdist_hmc_energy_f64': (_i32, [_vp, _vp, _vp, _vp, _vp, _f64, _vp, _i32, _f64, _f64,
-                                            _i32, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp]),
+    'binf_pairdist_hmc_energy_f64': (_i32, [_vp, _vp, _vp, _vp, _vp, _f64, _vp, _f64, _f64, _i32,
+                                            ctypes.POINTER(_i32), _vp, _f64, _vp, _f64,
+                                            _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp]),
     'binf_pairdist_packed_targets_bytes': (_i64, [_i64]),
     'binf_pairdist_pack_targets_f64': (_i32, [_vp, _vp, _i64, _vp]),
     'binf_pairdist_gauss_grad_packed_f64': (_i32, [_vp, _vp, _vp, _f64, _vp, _vp, _i64,
@@ -1001,17 +1002,39 @@ def pairdist_gauss_logp_memo(x, pair_i, pair_j, ys, precision, memo):
 @_launcher
 @_launcher
 def pairdist_hmc_energy(x, p, pair_i, pair_j, ys, precision, prior, prior_first, memo=None,
-                        want_log_prob=False):
+                        want_log_prob=False, terms=None):
     """binf_pairdist_hmc_energy_f64: ``0.5 * sum(p**2) - log_prob`` of the restraint
-    posterior (likelihood + optional isotropic Gaussian prior ``(k, x0)``) in one launch;
-    ``memo = new_chi2_memo(C, 3 * n_beads, device)`` or None.  Returns the energy, or
-    ``(energy, log_prob)``."""
+    posterior in one launch.  ``prior`` = ``(k, x0)`` of an isotropic Gaussian or None;
+    the components are added in the order ``terms`` gives -- a list of ``'prior'``,
+    ``'lik'`` and up to two constants of the move (``[C]`` device tensors or floats) --
+    default: prior and likelihood as ``prior_first`` says.  ``memo = new_chi2_memo(C,
+    3 * n_beads, device)`` or None.  Returns the energy, or ``(energy, log_prob)``."""
     C, D = _cd(x)
     if D % 3:
         raise ValueError('coordinates must be [n_chains, 3 * n_beads]')
     P = pair_i.numel()
     tau, tau_chain = _precision_args(precision, C, x.device)
     k, x0 = prior if prior is not None else (0.0, 0.0)
+    if terms is None:
+        terms = ['lik'] if prior is None else (['prior', 'lik'] if prior_first else ['lik', 'prior'])
+    kinds, extras = [], []
+    for t in terms:
+        if isinstance(t, str):
+            if t not in ('prior', 'lik') or (t == 'prior' and prior is None):
+                raise ValueError('pairdist_hmc_energy: unknown term %r' % (t,))
+            kinds.append(0 if t == 'prior' else 1)
+        else:
+            if len(extras) == 2:
+                raise ValueError('pairdist_hmc_energy: at most two constant terms')
+            kinds.append(2 + len(extras))
+            extras.append(t)
+    ptrs, scalars = [None, None], [0.0, 0.0]
+    for n_, e in enumerate(extras):
+        if isinstance(e, torch.Tensor) and e.dim() > 0:
+            ptrs[n_] = dptr(e, numel=C, name='constant term')
+        else:
+            scalars[n_] = float(e)
+    kind_arr = (_i32 * 4)(*(kinds + [1] * (4 - len(kinds))))
     mx, ms, st = memo if memo is not None else (None, None, None)
     energy = torch.empty(C, dtype=torch.float64, device=x.device)
     lp = torch.empty(C, dtype=torch.float64, device=x.device) if want_log_prob else None
@@ -1019,7 +1042,8 @@ def pairdist_hmc_energy(x, p, pair_i, pair_j, ys, precision, prior, prior_first,
         dptr(x, numel=C * D, name='x'), dptr(p, numel=C * D, name='p'),
         dptr(pair_i, torch.int32, P, 'pair_i'), dptr(pair_j, torch.int32, P, 'pair_j'),
         dptr(ys, numel=P, name='ys'), tau, dptr(tau_chain, numel=C, name='precision'),
-        int(prior is not None), float(k), float(x0), int(bool(prior_first)), dptr(energy), dptr(lp),
+        float(k), float(x0), len(kinds), kind_arr, ptrs[0], scalars[0], ptrs[1], scalars[1],
+        dptr(energy), dptr(lp),
         dptr(mx, numel=2 * C * D, name='memo_x'), dptr(ms, numel=2 * C, name='memo_chi2'),
         dptr(st, torch.uint8, 2 * C, 'memo_state'), C, D // 3, P, stream_handle(x.device))
     check(rc, 'binf_pairdist_hmc_energy_f64')

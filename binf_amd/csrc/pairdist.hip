@@ -359,7 +359,10 @@ struct PairEnergyArgs {
     double prior_scale;      // -0.5 k
     double prior_x0;
     int32_t has_prior;
-    int32_t prior_first;
+    int32_t n_terms;         // the Posterior's components in its order (<= 4):
+    int32_t term_kind[4];    //   0 the prior, 1 the likelihood, 2 / 3 a constant of the move
+    const double *extra[2];  // constants per chain [C], or null: extra_scalar
+    double extra_scalar[2];
     int32_t n_beads;
     int32_t H_d;             // tree height of a 3n-element sum
 };
@@ -477,10 +480,14 @@ pairdist_energy_kernel(const PairEnergyArgs a, const RowGeom g)
                 a.memo_state[g.C + row] = (uint8_t)way[q];
             }
             const double lp_lik = row_result(g, row, chi2[q]);
-            double lp = lp_lik;
-            if (a.has_prior) {
-                const double lp_prior = a.prior_scale * prior[q];
-                lp = a.prior_first ? lp_prior + lp_lik : lp_lik + lp_prior;
+            const double lp_prior = a.prior_scale * prior[q];
+            double lp = 0.0;                     // ((t0 + t1) + t2) + ..., binf_sum_terms_f64
+            for (int k = 0; k < a.n_terms; ++k) {
+                const int kind = a.term_kind[k];
+                const double v = kind == 0 ? lp_prior
+                               : kind == 1 ? lp_lik
+                               : (a.extra[kind - 2] ? a.extra[kind - 2][row] : a.extra_scalar[kind - 2]);
+                lp = (k == 0) ? v : lp + v;
             }
             if (a.log_prob) a.log_prob[row] = lp;
             a.energy[row] = 0.5 * kin[q] - lp;
@@ -1368,14 +1375,28 @@ static int32_t pairdist_logp_run(const double *x, const int32_t *pair_i, const i
 extern "C" int32_t binf_pairdist_hmc_energy_f64(const double *x, const double *p,
                                                 const int32_t *pair_i, const int32_t *pair_j,
                                                 const double *ys, double precision,
-                                                const double *precision_chain, int32_t has_prior,
-                                                double prior_k, double prior_x0, int32_t prior_first,
+                                                const double *precision_chain, double prior_k,
+                                                double prior_x0, int32_t n_terms,
+                                                const int32_t *term_kind, const double *extra0,
+                                                double extra0_scalar, const double *extra1,
+                                                double extra1_scalar,
                                                 double *energy, double *log_prob, double *memo_x,
                                                 double *memo_chi2, uint8_t *memo_state, int64_t C,
                                                 int64_t n_beads, int64_t n_pairs, void *stream)
 {
     if (C < 0 || n_beads < 1 || n_pairs < 0)
         return fail(BINF_E_ARG, "pairdist_hmc_energy: bad sizes");
+    if (n_terms < 1 || n_terms > 4 || !term_kind)
+        return fail(BINF_E_ARG, "pairdist_hmc_energy: 1 to 4 terms, with their kinds");
+    int has_prior = 0, seen = 0;
+    for (int k = 0; k < n_terms; ++k) {
+        const int kind = term_kind[k];
+        if (kind < 0 || kind > 3 || (seen & (1 << kind)))
+            return fail(BINF_E_ARG, "pairdist_hmc_energy: term kinds are 0..3, each at most once");
+        seen |= 1 << kind;
+        if (kind == 0) has_prior = 1;
+    }
+    if (!(seen & 2)) return fail(BINF_E_ARG, "pairdist_hmc_energy: the likelihood (kind 1) must be a term");
     if (C == 0) return 0;
     if (!x || !p || !energy || (n_pairs > 0 && (!pair_i || !pair_j || !ys)))
         return fail(BINF_E_ARG, "pairdist_hmc_energy: null buffer");
@@ -1396,7 +1417,9 @@ extern "C" int32_t binf_pairdist_hmc_energy_f64(const double *x, const double *p
     a.x = x; a.p = p; a.I = pair_i; a.J = pair_j; a.ys = ys; a.memo_x = memo_x; a.memo_state = memo_state;
     a.energy = energy; a.log_prob = log_prob;
     a.prior_scale = -0.5 * prior_k; a.prior_x0 = prior_x0;
-    a.has_prior = has_prior ? 1 : 0; a.prior_first = prior_first ? 1 : 0;
+    a.has_prior = has_prior; a.n_terms = n_terms;
+    for (int k = 0; k < 4; ++k) a.term_kind[k] = k < n_terms ? term_kind[k] : 1;
+    a.extra[0] = extra0; a.extra[1] = extra1; a.extra_scalar[0] = extra0_scalar; a.extra_scalar[1] = extra1_scalar;
     a.n_beads = (int32_t)n_beads; a.H_d = npsum_tree_height(3 * n_beads);
     if (g.H > 7 || a.H_d > 7)
         return fail(BINF_E_UNSUPPORTED, "pairdist_hmc_energy: pairwise tree height %d", g.H > a.H_d ? g.H : a.H_d);

@@ -174,9 +174,10 @@ def make_restraint_gibbs_sampler(posterior, timestep, nsteps, start_state, **hmc
                                                  'precision': precision_sampler})
 
 
-def native_hmc_energy(likelihood, x2, p2, precision, prior, prior_first):
-    """``0.5 * sum(p**2) - log_prob`` of a posterior made of this likelihood and at most one
-    isotropic Gaussian prior ``(k, x0)`` (``Posterior.native_energy_spec``), one launch:
+def native_hmc_energy(likelihood, x2, p2, precision, prior, terms):
+    """``0.5 * sum(p**2) - log_prob`` of a posterior made of this likelihood, at most one
+    isotropic Gaussian prior ``(k, x0)`` and up to two constants of the move, added in the
+    order of ``terms`` (``Posterior.native_energy_spec``), one launch:
     binf_pairdist_hmc_energy_f64.  Shares the chi^2 memo with ``native_log_prob``."""
     fwm, em = likelihood.forward_model, likelihood.error_model
     I, J = fwm.pair_index(x2.device)
@@ -184,7 +185,7 @@ def native_hmc_energy(likelihood, x2, p2, precision, prior, prior_first):
     memo = None
     if USE_CHI2_MEMO and ys.numel() >= 2048 and x2.numel() * 8 <= (1 << 28):
         memo = _chi2_memo(I, ys, x2.shape)
-    return _native.pairdist_hmc_energy(x2, p2, I, J, ys, precision, prior, prior_first, memo)
+    return _native.pairdist_hmc_energy(x2, p2, I, J, ys, precision, prior, False, memo, terms=terms)
 
 
 USE_CHI2_MEMO = True

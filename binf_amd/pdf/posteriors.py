@@ -188,8 +188,12 @@ class Posterior(AbstractBinfPDF):
         """Descriptor of a fused kernel for ``HMCSampler.sample()``'s energy
         ``0.5 * sum(p**2) - log_prob`` under THIS posterior, or None.  As
         ``native_leapfrog_spec`` for the restraint posterior, but EVERY component
-        must be the likelihood or the one prior: a component without differentiable
-        variables drops out of the force, not out of ``log_prob``."""
+        counts: a component without differentiable variables drops out of the force,
+        not out of ``log_prob``.  Besides the likelihood and the one prior, up to two
+        components whose variables are ALL fixed (constants of the move, e.g. the
+        GammaPrior of the precision inside a Gibbs sweep) are recorded in place:
+        the last entry of the tuple lists ``'prior'`` / ``'lik'`` / such a component
+        in the Posterior's order."""
         return self._native_pairdist_spec(variable_name, strict=True)
 
     def _native_pairdist_spec(self, variable_name, strict):
@@ -197,10 +201,15 @@ class Posterior(AbstractBinfPDF):
         from binf_amd.pdf.likelihoods import Likelihood
         lik = prior = None
         order = []
+        terms = []          # strict: every component in the Posterior's order
         for f in self._ordered_components():
             if not (len(f.variables) > 0 and len(f.differentiable_variables) > 0):
                 if strict:
-                    return None
+                    # out of the force, not out of log_prob: a component with every variable
+                    # fixed is a constant of the move the energy kernel can add in its place
+                    if len(f.variables) > 0 or sum(1 for t in terms if not isinstance(t, str)) == 2:
+                        return None
+                    terms.append(f)
                 continue
             if isinstance(f, Likelihood):
                 fs = getattr(f.forward_model, 'native_spec', lambda: None)()
@@ -212,11 +221,13 @@ class Posterior(AbstractBinfPDF):
                     return None
                 lik = f
                 order.append('lik')
+                terms.append('lik')
             elif isinstance(f, IsotropicGaussian):
                 if prior is not None or f.native_hmc_spec(variable_name) is None:
                     return None
                 prior = f
                 order.append('prior')
+                terms.append('prior')
             else:
                 return None
         if lik is None:
@@ -225,4 +236,4 @@ class Posterior(AbstractBinfPDF):
         spec = ('pairdist', em, em['precision'].value,
                 None if prior is None else (float(prior['k'].value), float(prior['x0'].value)),
                 order[0] == 'prior')
-        return spec + (lik,) if strict else spec
+        return spec + (lik, terms) if strict else spec

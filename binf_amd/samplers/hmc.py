@@ -634,8 +634,10 @@ class HMCSampler(object):
             # prior row sum, chi^2 (with its memo), term sum and kinetic energy in one launch
             # (bit-identical to the calls above)
             from binf_amd.example import distance as _dist
-            _, em, precision, prior, prior_first, lik = espec
-            E = lambda x, mom: _dist.native_hmc_energy(lik, x, mom, precision, prior, prior_first)
+            _, em, precision, prior, prior_first, lik, terms = espec
+            # constants of the move (components with every variable fixed): once per sample()
+            terms = [t if isinstance(t, str) else t.log_prob() for t in terms]
+            E = lambda x, mom: _dist.native_hmc_energy(lik, x, mom, precision, prior, terms)
 
         p = p0 if own_p else p0.clone()
         e_before = E(q0, p)

@@ -693,23 +693,27 @@ int32_t binf_pairdist_gauss_logp_memo_f64(const double *x, const int32_t *pair_i
 /* HMCSampler.sample()'s energy (binf/samplers/hmc.py:143,148,150) for the restraint
  * posterior in ONE launch:
  *   energy[c]   = 0.5 * np.sum(p[c]**2) - log_prob[c]
- *   log_prob[c] = the Posterior's components added in their order
- *                 (binf/pdf/posteriors.py:147-151): the restraint likelihood
- *                 -0.5 chi^2 precision_c + n_pairs/2 log precision_c  (as
- *                 binf_pairdist_gauss_logp_f64) and, if has_prior, the isotropic Gaussian
- *                 prior (-0.5 prior_k) * np.sum((x[c] - prior_x0)**2), added before the
- *                 likelihood term if prior_first, after it otherwise.
+ *   log_prob[c] = the Posterior's components added in their order, ((t0 + t1) + t2) + ...
+ *                 (binf/pdf/posteriors.py:147-151).  term_kind[0 .. n_terms) (host array,
+ *                 1 <= n_terms <= 4, each kind at most once) names them:
+ *                   1  the restraint likelihood, -0.5 chi^2 precision_c + n_pairs/2 log
+ *                      precision_c (as binf_pairdist_gauss_logp_f64) -- must be present;
+ *                   0  an isotropic Gaussian prior, (-0.5 prior_k) * np.sum((x[c] - prior_x0)**2);
+ *                   2, 3  a component whose variables are all fixed -- a constant of the
+ *                      move, evaluated by the caller: extra0 / extra1 [C], or null and the
+ *                      scalar (e.g. the GammaPrior of the precision inside a Gibbs sweep).
  * Replaces the per-step tier's row sum for the prior, memo check, chi^2 reduction,
  * binf_sum_terms_f64 and binf_hmc_energy_f64 (six launches) and is bit-identical to
- * them: every sum in numpy's order, every scalar operation in theirs.  A posterior with
- * any other component is not this function's (the caller must check).  x, p: device
+ * them: every sum in numpy's order, every scalar operation in theirs.  x, p: device
  * [C x 3 n_beads]; energy [C]; log_prob [C] or null.  memo_x / memo_chi2 / memo_state: the
  * two-entry chi^2 memo of binf_pairdist_gauss_logp_memo_f64 (same buffers, same contents:
  * the two functions may share one memo), or all three null.  n_beads <= 2048. */
 int32_t binf_pairdist_hmc_energy_f64(const double *x, const double *p, const int32_t *pair_i,
                                      const int32_t *pair_j, const double *ys, double precision,
-                                     const double *precision_chain, int32_t has_prior,
-                                     double prior_k, double prior_x0, int32_t prior_first,
+                                     const double *precision_chain, double prior_k,
+                                     double prior_x0, int32_t n_terms, const int32_t *term_kind,
+                                     const double *extra0, double extra0_scalar,
+                                     const double *extra1, double extra1_scalar,
                                      double *energy, double *log_prob, double *memo_x,
                                      double *memo_chi2, uint8_t *memo_state, int64_t C,
                                      int64_t n_beads, int64_t n_pairs, void *stream);

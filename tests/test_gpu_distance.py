@@ -375,6 +375,18 @@ def test_one_launch_energy_is_the_per_step_tier_bit_for_bit(device, n, C):
             _native.pairdist_gauss_logp_memo(x2, I, J, ty, prec, memo)            # second entry
             assert torch.equal(_native.pairdist_hmc_energy(tx, tp, I, J, ty, prec, prior, first, memo), want)
             assert bool(memo[2][0].all())
+    # constants of the move in the Posterior's order: a value per chain and a scalar
+    cvec, cs = dev_t(rs.standard_normal(C), device), -1.75
+    lp_lik = _native.pairdist_gauss_logp(tx, I, J, ty, taus)
+    lp_prior = _native.row_sum(tx, _native.ROW_SUMSQ_SHIFT, shift=0.1, scale=-0.5 * 0.05)
+    for terms in (['lik', cvec], [cs, 'lik', cvec], ['prior', cvec, 'lik'], [cvec, 'prior', cs, 'lik'],
+                  ['lik', 'prior', cs]):
+        vals = [lp_lik if t == 'lik' else lp_prior if t == 'prior' else t for t in terms
+                if True]
+        lp = _native.sum_terms(vals)
+        got, got_lp = _native.pairdist_hmc_energy(tx, tp, I, J, ty, taus, (0.05, 0.1), False, terms=terms,
+                                                  want_log_prob=True)
+        assert torch.equal(got_lp, lp) and torch.equal(got, _native.hmc_energy(tp, lp))
 
 
 def test_sample_with_and_without_the_one_launch_energy(device):
@@ -404,14 +416,26 @@ def test_sample_with_and_without_the_one_launch_energy(device):
     lik = make_distance_likelihood(ys, n)
     pri = IsotropicGaussian(0.05, 0.0, name='coordinates_prior', variable_name='coordinates')
     gam = GammaPrior(2.0, 0.5)
-    cond = Posterior({lik.name: lik}, {pri.name: pri, gam.name: gam}).conditional_factory(precision=3.0)
-    assert cond.native_leapfrog_spec('coordinates') is not None
-    assert cond.native_energy_spec('coordinates') is None
-    s = HMCSampler(cond, dev_t(x, device), 0.002, 4, variable_name='coordinates', rng=DeviceRNG(5, device),
-                   record_energies=True)
-    s.sample()
-    lp = cond.log_prob(coordinates=s.state)
-    assert torch.isfinite(s.last_e_after).all() and torch.isfinite(lp).all()
+    taus = dev_t(np.random.RandomState(3).uniform(1.0, 4.0, size=C), device)
+    for prec in (3.0, taus):                                   # the constant: a float / one value per chain
+        cond = Posterior({lik.name: lik}, {pri.name: pri, gam.name: gam}).conditional_factory(precision=prec)
+        assert cond.native_leapfrog_spec('coordinates') is not None
+        spec = cond.native_energy_spec('coordinates')
+        assert spec is not None and [t if isinstance(t, str) else 'const' for t in spec[-1]] == \
+            ['prior', 'const', 'lik']                           # coordinates_prior < precision_prior < restraints
+        runs = []
+        for fused in (True, False):
+            s = HMCSampler(cond, dev_t(x, device), 0.002, 4, variable_name='coordinates', rng=DeviceRNG(5, device),
+                           record_energies=True)
+            s.fused_energy = fused
+            out = [s.sample().clone() for _ in range(3)]
+            runs.append((torch.stack(out), s.last_e_before.clone(), s.last_e_after.clone(), s.n_accepted.clone()))
+        assert all(torch.equal(a, b) for a, b in zip(runs[0], runs[1]))
+        lp = cond.log_prob(coordinates=s.state)
+        assert torch.isfinite(s.last_e_after).all() and torch.isfinite(lp).all()
+    # a component with a variable still open (not a constant of the move) keeps the per-step energy
+    both = Posterior({lik.name: lik}, {pri.name: pri, gam.name: gam})
+    assert both.native_energy_spec('coordinates') is None
 
 
 @pytest.mark.parametrize('n,C', [(48, 7), (256, 5), (300, 3), (700, 2), (20, 4)])
