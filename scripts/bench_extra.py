@@ -148,6 +148,35 @@ def c5_distance(dev, C=256, n=256, L=20):
             'acceptance': float(s.acceptance_rate.mean())}
 
 
+def c5_gibbs(dev, C=256, n=256, L=20):
+    """C5's model inside the reference's Gibbs scheme: HMC on the coordinates + the conjugate
+    Gamma draw of one precision per chain (example/distance.py: make_restraint_gibbs_sampler)."""
+    from binf_amd.example.distance import make_distance_likelihood, make_restraint_gibbs_sampler
+    from binf_amd.example.priors import GammaPrior
+    from binf_amd.pdf import IsotropicGaussian
+    from binf_amd.pdf.posteriors import Posterior
+    from binf_amd.samplers import BinfState
+    from binf_amd.samplers.rng import DeviceRNG
+    rs = np.random.RandomState(0)
+    truth = rs.standard_normal((n, 3)) * 2.0
+    I, J = np.triu_indices(n, 1)
+    ys = np.abs(np.sqrt(np.sum((truth[I] - truth[J]) ** 2, axis=1)) + 0.5 * rs.standard_normal(len(I)))
+    lik = make_distance_likelihood(ys, n)
+    post = Posterior({lik.name: lik},
+                     {'coordinates_prior': IsotropicGaussian(0.05, 0.0, name='coordinates_prior',
+                                                             variable_name='coordinates'),
+                      'precision_prior': GammaPrior(1.0, 0.2)})
+    start = BinfState({'coordinates': torch.from_numpy(truth.reshape(-1)[None, :] +
+                                                       0.1 * rs.standard_normal((C, 3 * n))).to(dev),
+                       'precision': torch.full((C,), 4.0, dtype=torch.float64, device=dev)})
+    gips = make_restraint_gibbs_sampler(post, 0.002, L, start, rng=DeviceRNG(0, dev))
+    t = _timed(gips.sample, 30, warm=5, settle_s=0.1)
+    return {'workload': 'C5 share, Gibbs-within-HMC: %d beads x 3, %d chains, L=%d, one precision per chain'
+                        % (n, C, L),
+            'gibbs_sweep_ms': t * 1e3, 'chain_leapfrog_steps_per_s': C * L / t,
+            'precision_mean': float(gips.state.variables['precision'].mean())}
+
+
 def c2_device_rng(dev, C=4096, D=1024, L=20, F=64):
     """C2 with the momentum / uniform draws generated on the device INSIDE the
     timed region (hmc.py:146,151 are part of sample())."""
@@ -302,6 +331,7 @@ def run_all(dev, kstats=None):
     res = {}
     for name, fn in (('C3', c3_polynomial), ('C4', c4_gibbs), ('C5', c5_distance),
                      ('C5_2048_chains', lambda d: c5_distance(d, C=2048)),
+                     ('C5_gibbs', c5_gibbs),
                      ('C1_gibbs', c1_gibbs),
                      ('C2_device_rng', c2_device_rng),
                      ('C2_strong_scaling_shares', c2_strong_scaling_shares)):
