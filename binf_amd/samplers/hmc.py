@@ -637,7 +637,20 @@ class HMCSampler(object):
             _, em, precision, prior, prior_first, lik, terms = espec
             # constants of the move (components with every variable fixed): once per sample()
             terms = [t if isinstance(t, str) else t.log_prob() for t in terms]
-            E = lambda x, mom: _dist.native_hmc_energy(lik, x, mom, precision, prior, terms)
+
+            def kernel_term(t):
+                if isinstance(t, str):
+                    return True
+                if isinstance(t, torch.Tensor):
+                    return t.dim() == 0 or (t.is_cuda and t.dtype == torch.float64 and
+                                            t.is_contiguous() and t.numel() == q0.shape[0])
+                try:                                # a Python / numpy scalar
+                    float(t)
+                    return True
+                except (TypeError, ValueError):
+                    return False
+            if all(kernel_term(t) for t in terms):
+                E = lambda x, mom: _dist.native_hmc_energy(lik, x, mom, precision, prior, terms)
 
         p = p0 if own_p else p0.clone()
         e_before = E(q0, p)
