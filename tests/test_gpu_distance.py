@@ -339,7 +339,7 @@ def test_bead_counts_without_a_packed_form(device):
 
 
 @pytest.mark.parametrize('n,C', [(5, 3), (17, 9), (64, 5), (100, 1030), (128, 4), (256, 7), (300, 3),
-                                 (40, 2051), (131, 2048), (700, 2)])
+                                 (40, 2051), (131, 2048), (700, 2), (1500, 2), (2048, 1)])
 def test_one_launch_energy_is_the_per_step_tier_bit_for_bit(device, n, C):
     """binf_pairdist_hmc_energy_f64 against the calls it replaces (prior row sum, chi^2,
     binf_sum_terms_f64, binf_hmc_energy_f64) for every component order, with and without
