@@ -63,7 +63,15 @@ def parse(argv=None):
                          'chip needs ~50 ms of sustained load before its clock / power '
                          'controller settles (the first ~20 launches of a cold run take up to '
                          '1.5x the settled time; profiles/r02_settle_notes.md); 0 = none')
-    ap.add_argument('--chains', type=int, default=4096, help='chains per GPU')
+    ap.add_argument('--chains', type=int, default=4096,
+                    help='chains per GPU (--scaling weak) / chains in all (--scaling strong)')
+    ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'],
+                    help='weak (primary, SURVEY 8(e)): --chains per GPU, the job grows with N; '
+                         'strong (secondary): --chains in all, sharded over the N ranks '
+                         '(4096 -> 512 per GPU at N = 8, a chain spread over several waves); '
+                         'the C4 / C5 legs then shard their BASELINE totals (32768 / 2048 chains)')
+    ap.add_argument('--no-legs', action='store_true',
+                    help='with --gpus N > 1: skip the sharded C4 / C5 legs')
     ap.add_argument('--dims', type=int, default=1024)
     ap.add_argument('--nsteps', type=int, default=20, help='leapfrog steps')
     ap.add_argument('--timestep', type=float, default=0.05)
@@ -307,15 +315,27 @@ def dry_run(args, rank, world):
         tmax = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax[0])
-        _, count = shard_chains(args.chains * world, rank, world)
+        total = args.chains * world if args.scaling == 'weak' else args.chains
+        _, count = shard_chains(total, rank, world)
         state = torch.full((count, 4), float(rank), dtype=torch.float64)
-        gathered = gather_chains(state)
+        gathered = gather_chains(state, total)
         dist.barrier()
+    # the sharded legs' control flow (scripts/bench_legs.py: barrier-bracketed sweeps,
+    # SampleStore recording, MAX over ranks, gather to rank 0, per-rank self-check
+    # fields) with a stand-in leg on host tensors
+    from scripts import bench_legs
+    comm = bench_legs.Comm(dist if world > 1 else None, 'gloo' if world > 1 else None,
+                           torch.device('cpu'))
+    start, count = shard_chains(args.chains if args.scaling == 'strong' else args.chains * world,
+                                rank, world)
+    leg = bench_legs.StandInLeg(comm, chains_per_gpu=args.chains, scaling=args.scaling)
+    legs = {'stand_in': bench_legs.run_leg(leg, comm, sweeps=6, warm=1, thin=2, settle_s=0.0)}
     if rank == 0:
         print(json.dumps({'dry_run': True, 'n_gpus': world, 'steps': args.steps,
                           'warmup': args.warmup, 'max_elapsed': elapsed,
                           'gathered_rows': None if gathered is None else int(gathered.shape[0]),
-                          'value': None}), flush=True)
+                          'scaling': args.scaling, 'shard': [start, count],
+                          'extra': legs, 'value': None}), flush=True)
     if world > 1:
         dist.destroy_process_group()
 
@@ -334,7 +354,14 @@ def main():
         return dry_run(args, rank, world)
     ensure_library()
 
-    C, D, L, dt = args.chains, args.dims, args.nsteps, args.timestep
+    from binf_amd.dist import shard_chains
+    D, L, dt = args.dims, args.nsteps, args.timestep
+    # weak: --chains per GPU; strong: --chains in all, this rank's contiguous block
+    C_total = args.chains * world if args.scaling == 'weak' else args.chains
+    chain_offset, C = shard_chains(C_total, rank, world)
+    if C < 1:
+        sys.exit('bench.py: --scaling strong with %d chains leaves rank %d without a chain'
+                 % (C_total, rank))
     K, W = max(1, args.steps), max(0, args.warmup)
     F = max(1, args.fuse)
     thin = min(max(1, args.thin), F)
@@ -388,8 +415,13 @@ def main():
     # (rank r adds 100000 r to every seed) -- generated on the host before the timed
     # region; the other buffers are filled on the device (host generation of a buffer
     # takes ~6 s).  --survey-draws 0: all buffers on the device.
-    q0 = torch.from_numpy(
-        np.random.RandomState(1234 + 100000 * rank).standard_normal((C, D))).to(dev)
+    if args.scaling == 'weak':
+        q0 = torch.from_numpy(
+            np.random.RandomState(1234 + 100000 * rank).standard_normal((C, D))).to(dev)
+    else:       # one job whatever N: the rows of the whole start state this rank owns
+        q0 = torch.from_numpy(np.ascontiguousarray(
+            np.random.RandomState(1234).standard_normal((C_total, D))[chain_offset:chain_offset + C]
+        )).to(dev)
     gen = torch.Generator(device=dev)
     gen.manual_seed(1000 + rank)
     p_bufs, u_bufs = [], []
@@ -552,14 +584,23 @@ def main():
         mine = {'rank': rank, 'world_size_seen': dist.get_world_size(), 'backend': dist.get_backend(),
                 'device': '%s:%d' % (torch.cuda.get_device_name(dev_index), dev_index),
                 'elapsed_s': my_elapsed, 'dev_ms': dev_ms,
-                'chain_offset': int(rank) * C,
+                'chain_offset': chain_offset, 'chains': C,
+                'value': C * L * K * F / my_elapsed,
                 'sustained_value': None if sustained is None else sustained['value_per_gpu']}
         per_rank = [None] * world
         dist.all_gather_object(per_rank, mine)
 
+    # The sharded C4 / C5 legs (every rank: they hold barriers and the sample gather).
+    legs = None
+    if world > 1 and not args.no_legs and not args.no_extra:
+        del p_bufs, u_bufs, rec_bufs
+        torch.cuda.empty_cache()
+        from scripts import bench_legs
+        legs = bench_legs.run_legs(dev, bench_legs.Comm(dist, backend, dev), scaling=args.scaling)
+
     if rank == 0:
         transitions = K * F
-        steps_total = float(world) * C * L * transitions
+        steps_total = float(C_total) * L * transitions
         value = steps_total / elapsed
         launch_s = dev_ms * 1e-3 / K                      # per kernel launch (= step)
         trans_s = launch_s / F
@@ -623,20 +664,23 @@ def main():
             'n_gpus': world, 'steps': K, 'warmup': W,
             'ms_per_step': elapsed / K * 1e3,
             'higher_is_better': True,
-            'scaling': 'weak',
+            'scaling': args.scaling,
             'vs_baseline': None,
             'dtype': 'f64',
             'data': 'synthetic',
             'config': {'workload': 'C2: %d-d isotropic Gaussian (k=1, x0=0), '
-                                   '%d chains/GPU, %d leapfrog steps, dt=%g, '
+                                   '%s, %d leapfrog steps, dt=%g, '
                                    'fused HMC transition, mode=%s; 1 step = 1 launch = %d '
                                    'transition(s) (sample() calls), %s state recorded; q0 and '
                                    'draw buffer(s) 0..%d from the SURVEY.md 8(d) seeds (host), '
                                    'the other %d filled by torch.randn on the device'
-                                   % (D, C, L, dt, args.mode, F,
+                                   % (D, ('%d chains/GPU' % C) if args.scaling == 'weak' else
+                                      ('%d chains in all, %d on rank 0 (strong scaling)'
+                                       % (C_total, C)), L, dt, args.mode, F,
                                       'every' if thin == 1 else 'every %d.' % thin,
                                       n_survey - 1, NB - n_survey),
-                       'chains_per_gpu': C, 'n_dims': D, 'leapfrog_steps': L,
+                       'chains_per_gpu': C, 'chains_total': C_total,
+                       'n_dims': D, 'leapfrog_steps': L,
                        'transitions_per_step': F,
                        'parallelism': 'chains sharded x%d, no data-path '
                                       'collective' % world,
@@ -674,6 +718,10 @@ def main():
                 res['extra']['roofline_kernel_trace'] = kstats_src
             except Exception as e:              # sub-results never break the headline
                 res['extra'] = {'error': '%s: %s' % (type(e).__name__, e)}
+        if legs is not None:
+            # the polynomial (C4) and pair-distance (C5) legs of this N-GPU run, each with
+            # its own sample gather and per-rank figures (scripts/bench_legs.py)
+            res['extra'] = legs
         if world == 1 and not args.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline(D, L, dt, args.cpu_chains,
                                                args.cpu_calls)

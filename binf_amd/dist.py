@@ -142,16 +142,40 @@ class SampleStore(object):
         self.n_kept = 0
 
     def record(self, x):
-        """Returns True if the draw was kept."""
+        """Returns True if the draw was kept.  ``x`` is the ``[C_local x D]`` state, or
+        a tuple of per-chain tensors (``[C_local x d_i]`` / ``[C_local]``) whose widths
+        add up to D -- the variables of a Gibbs state, laid side by side in the slot
+        (coefficients ``[C x K]`` + precision ``[C]`` -> ``[C x (K + 1)]``) without an
+        intermediate concatenation."""
         i = self.n_seen
         self.n_seen += 1
         if i < self.burn_in or (i - self.burn_in) % self.thin != 0:
             return False
         if self.n_kept >= self.buffer.shape[0]:
             raise IndexError('SampleStore is full (%d draws)' % self.n_kept)
-        self.buffer[self.n_kept].copy_(x.reshape(self.buffer.shape[1:]))
+        slot = self.buffer[self.n_kept]
+        if isinstance(x, (tuple, list)):
+            col = 0
+            for part in x:
+                part = part.reshape(slot.shape[0], -1)
+                slot[:, col:col + part.shape[1]].copy_(part)
+                col += part.shape[1]
+            if col != slot.shape[1]:
+                raise ValueError('SampleStore.record: parts are %d wide, the store %d'
+                                 % (col, slot.shape[1]))
+        else:
+            slot.copy_(x.reshape(slot.shape))
         self.n_kept += 1
         return True
+
+    def to(self, device):
+        """A store on ``device`` holding the draws kept so far (a host copy is what
+        the ``gloo`` backend can move; RCCL gathers straight from HBM)."""
+        other = SampleStore.__new__(SampleStore)
+        other.thin, other.burn_in = self.thin, self.burn_in
+        other.buffer = self.buffer.to(device)
+        other.n_seen, other.n_kept = self.n_seen, self.n_kept
+        return other
 
     def extend(self, block, n_sweeps=None):
         """Append a block of already thinned draws ``[m, C_local, D]`` -- what
@@ -176,7 +200,12 @@ class SampleStore(object):
         kept = self.local()
         back = lambda g: None if g is None else g.transpose(0, 1).contiguous()
         if kept.shape[0] == 0:
-            return PendingGather(None, kept, lambda t: t) if async_op else kept
+            # nothing kept yet: no collective; the contract of ``dst`` still holds
+            # (None on every rank but ``dst``)
+            rank, ws = world() if group is None else (_dist().get_rank(group),
+                                                      _dist().get_world_size(group))
+            empty = kept if (dst is None or ws == 1 or rank == int(dst)) else None
+            return PendingGather(None, empty, lambda t: t) if async_op else empty
         # chains to dim 0 for the collective, back afterwards
         g = gather_chains(kept.transpose(0, 1).contiguous(), n_chains_total, group,
                           async_op=async_op, dst=dst)

@@ -74,41 +74,23 @@ def c3_polynomial(dev, C=8192, K=33, N=16384, L=20):
             'acceptance': float(s.acceptance_rate.mean())}
 
 
-def c4_gibbs(dev, C=4096, K=33, N=16384, L=20):
+def c4_gibbs(dev, C=4096):
     """C4 per-GPU share (32768 chains over 8 GPUs): Gibbs-within-HMC, HMC on the
-    coefficients + the conjugate precision update, through the class stack."""
-    from binf_amd.example.likelihood import POLYVAL, make_likelihood
-    from binf_amd.example.priors import GammaPrior, GaussianPrior
-    from binf_amd.example.samplers import make_hmc_sampler
-    from binf_amd.pdf.posteriors import Posterior
-    from binf_amd.samplers import BinfState
-    from binf_amd.samplers.rng import DeviceRNG
-    xs = np.linspace(-1, 1, N)
-    c_true = np.random.RandomState(7).standard_normal(K)
-    ys = POLYVAL(xs, c_true) + np.random.RandomState(9).standard_normal(N) / np.sqrt(2.5)
-    q0 = torch.from_numpy(np.random.RandomState(8).standard_normal((C, K))).to(dev)
-    lik = make_likelihood(xs, ys, POLYVAL)
-    post = Posterior({lik.name: lik},
-                     {'precision_prior': GammaPrior(1.0, 0.2),
-                      'coefficients_prior': GaussianPrior(np.zeros(K), np.ones(K) * 5)})
-    start = BinfState(dict(coefficients=q0,
-                           precision=torch.full((C,), 2.5, dtype=torch.float64, device=dev)))
-    grng = DeviceRNG(5, dev)
-    gips = make_hmc_sampler(post, 2e-4, L, start, rng=DeviceRNG(2, dev), gamma=grng.gamma)
-    t = _timed(gips.sample, 10, warm=3)
-    return {'workload': 'C4 share: Gibbs-within-HMC, polynomial K=%d, N=%d, %d chains (32768 / 8), '
-                        'L=%d' % (K, N, C, L),
-            'gibbs_sweep_ms': t * 1e3, 'chain_leapfrog_steps_per_s': C * L / t}
+    coefficients + the conjugate precision update, through the class stack -- the
+    SAME leg `bench.py --gpus N` runs on every rank (scripts/bench_legs.py: sharded
+    start state and generators, every 5th state into a SampleStore), here with one rank."""
+    from scripts import bench_legs
+    comm = bench_legs.Comm(device=dev)
+    r = bench_legs.run_leg(bench_legs.C4Leg(dev, comm, chains_per_gpu=C), comm, 20, thin=5)
+    r['gibbs_sweep_ms'] = r['sweep_ms']
+    return r
 
 
 def c5_distance(dev, C=256, n=256, L=20):
     """C5: 3 x 256 coordinates; 256 chains = the per-GPU share of its 2048 chains on 8 GPUs
     (2048: the whole configuration on one GPU)."""
+    from binf_amd import _native
     from binf_amd.example.distance import make_distance_likelihood
-    from binf_amd.pdf import IsotropicGaussian
-    from binf_amd.pdf.posteriors import Posterior
-    from binf_amd.samplers.hmc import HMCSampler
-    from binf_amd.samplers.rng import DeviceRNG
     rs = np.random.RandomState(0)
     truth = rs.standard_normal((n, 3)) * 2.0
     I, J = np.triu_indices(n, 1)
@@ -117,9 +99,6 @@ def c5_distance(dev, C=256, n=256, L=20):
     x = torch.from_numpy(truth.reshape(-1)[None, :] +
                          0.1 * rs.standard_normal((C, 3 * n))).to(dev)
     lik = make_distance_likelihood(ys, n)
-    prior = IsotropicGaussian(0.05, 0.0, name='coordinates_prior', variable_name='coordinates')
-    cond = Posterior({lik.name: lik}, {prior.name: prior}).conditional_factory(precision=4.0)
-    from binf_amd import _native
     t_g = _timed(lambda: lik.gradient(coordinates=x, precision=4.0), 20, settle_s=0.1)
     # one force evaluation INSIDE the fused trajectory kernel: launch time against the
     # trajectory length (the target distances reach registers once per launch)
@@ -131,8 +110,13 @@ def c5_distance(dev, C=256, n=256, L=20):
         t_l[nst] = _timed(lambda: _native.pairdist_leapfrog(q, p, ymat, 4.0, (0.05, 0.0), True,
                                                             1e-5, None, nst, packed=packed), 40, warm=5)
     t_e = (t_l[L] - t_l[1]) / (L - 1)
-    s = HMCSampler(cond, x, 0.002, L, variable_name='coordinates', rng=DeviceRNG(0, dev))
-    t_h = _timed(s.sample, 30, warm=3, settle_s=0.1)
+    del q, p
+    # the sampling itself: the leg `bench.py --gpus N` runs on every rank, with one rank
+    from scripts import bench_legs
+    comm = bench_legs.Comm(device=dev)
+    leg = bench_legs.run_leg(bench_legs.C5Leg(dev, comm, chains_per_gpu=C, n=n, L=L), comm,
+                             100 if C <= 256 else 30, thin=20)
+    t_h = leg['sweep_ms'] * 1e-3
     pairs = float(C) * n * (n - 1)                # ordered pairs per force evaluation
     return {'workload': 'C5%s: %d beads x 3, %d chains, L=%d' % (' share' if C < 2048 else ' on one GPU', n, C, L),
             'force_kernel_ms': t_g * 1e3,
@@ -144,8 +128,10 @@ def c5_distance(dev, C=256, n=256, L=20):
             # lane and clock)
             'valu_frac': 24.0 * 0.5 * pairs / t_e / VALU_PEAK_LANEOPS,
             'hmc_sample_ms': t_h * 1e3,
-            'chain_leapfrog_steps_per_s': C * L / t_h,
-            'acceptance': float(s.acceptance_rate.mean())}
+            'chain_leapfrog_steps_per_s': leg['chain_leapfrog_steps_per_s'],
+            'acceptance': leg['ranks'][0]['self_check']['acceptance'],
+            'record_every': leg['record_every'], 'sweeps_timed': leg['sweeps_timed'],
+            'timing': leg['timing']}
 
 
 def c5_gibbs(dev, C=256, n=256, L=20):
