@@ -1,0 +1,78 @@
+"""The oracle's integrator against outputs of THE REFERENCE'S OWN ``_leapfrog``.
+
+``tests/golden/ref_leapfrog_*.npz`` were produced in the build container by
+``oracle/gen_ref_leapfrog.py``: the reference's ``HMCSampler`` class compiled from
+``binf/samplers/hmc.py`` itself with its one csb import statement dropped (csb is
+absent; nothing was substituted for it), ``__init__`` and ``_leapfrog``
+(``hmc.py:17-62,92-125``) called with duck-typed numpy PDFs.  This pins SURVEY 8(a)
+row a2 -- the kick-drift-kick sequence, its roundings, the in-place update -- by
+reference output; ``sample()``'s accept test and the csb ``exp`` clip stay "parity
+unpinned" (nothing here touches them).
+
+CPU: the numpy restatement (``RefHMCSampler._leapfrog``) and the C restatement
+(``oracle_c.c``) reproduce those bits.  The HIP kernels are held to the same files
+in ``tests/test_gpu_ref_leapfrog.py``."""
+import numpy as np
+import pytest
+
+from conftest import golden_files, load_golden
+from oracle import c_oracle
+from oracle import ref_distance
+from oracle import ref_numpy as R
+
+FILES = golden_files('ref_leapfrog_')
+
+
+def test_fixture_set_is_complete_and_says_where_it_comes_from():
+    kinds = {}
+    for f in FILES:
+        g = load_golden(f)
+        kinds.setdefault(str(g['kind']), []).append(f)
+        prov = str(g['provenance'])
+        assert 'REFERENCE' in prov and 'hmc.py:92-125' in prov and 'csb' in prov
+        assert g['q_out'].shape == g['q0'].shape == g['p_out'].shape == g['p0'].shape
+        assert not np.array_equal(g['q_out'], g['q0'])
+    assert len(kinds['gauss']) >= 9 and len(kinds['poly']) == 2 and len(kinds['dist']) == 3
+
+
+def _pdf(g):
+    kind = str(g['kind'])
+    if kind == 'gauss':
+        return R.GaussianPDF(float(g['k']), float(g['x0']), variable_name='x'), 'x'
+    if kind == 'poly':
+        K = g['q0'].shape[1]
+        return R.PolyCoefficientsConditional(g['xs'], g['ys'], float(g['precision']), np.zeros(K),
+                                             np.ones(K), 1.0, 0.2), 'coefficients'
+    return ref_distance.DistancePosterior(g['ys'], float(g['precision']), int(g['n_beads']),
+                                          prior_k=float(g['prior_k'])), 'coordinates'
+
+
+@pytest.mark.parametrize('path', FILES, ids=lambda p: p.split('ref_leapfrog_')[-1][:-4])
+def test_numpy_restatement_reproduces_the_reference_integrator_bitwise(path):
+    g = load_golden(path)
+    pdf, name = _pdf(g)
+    dts = np.broadcast_to(np.asarray(g['timestep'], dtype=np.float64), (g['q0'].shape[0],))
+    for c in range(g['q0'].shape[0]):
+        s = R.RefHMCSampler(pdf, g['q0'][c].copy(), float(dts[c]), int(g['nsteps']), variable_name=name)
+        q, p = g['q0'][c].copy(), g['p0'][c].copy()
+        s._leapfrog(q, p, s.timestep, s.nsteps)
+        assert np.array_equal(q, g['q_out'][c]), (path, c)
+        assert np.array_equal(p, g['p_out'][c]), (path, c)
+
+
+@pytest.mark.parametrize('path', [f for f in FILES if 'gauss' in f],
+                         ids=lambda p: p.split('ref_leapfrog_')[-1][:-4])
+def test_c_restatement_reproduces_the_reference_integrator_bitwise(path):
+    """oracle_c.c runs a whole transition; with u = 0 every proposal is accepted, so
+    q_out IS the integrator's end position, and E_after = V(q) + 0.5 sum(p**2) pins the
+    end momentum through numpy's own sum."""
+    g = load_golden(path)
+    C = g['q0'].shape[0]
+    k, x0 = float(g['k']), float(g['x0'])
+    out = c_oracle.hmc_sample_gauss(g['q0'], g['p0'], np.zeros(C), g['timestep'], int(g['nsteps']),
+                                    k=k, x0=x0)
+    assert out['accepted'].all()
+    assert np.array_equal(out['q_out'], g['q_out'])
+    for c in range(C):
+        want = 0.5 * k * np.sum((g['q_out'][c] - x0) ** 2) + 0.5 * np.sum(g['p_out'][c] ** 2)
+        assert out['e_after'][c] == want
