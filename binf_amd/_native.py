@@ -147,6 +147,7 @@ SIGNATURES = {
     'binf_gibbs_poly_sample_n_f64': (_i32, [_vp, _vp]),
     'binf_jacobian_contract_f64': (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _i32, _vp]),
     'binf_sum_terms_f64': (_i32, [_vp, _vp, _i32, _vp, _i64, _vp]),
+    'binf_sum_terms_bcast_f64': (_i32, [_vp, _vp, _vp, _i32, _vp, _i64, _vp]),
     'binf_rng_philox4x32_10': (_i32, [ctypes.POINTER(ctypes.c_uint32),
                                       ctypes.POINTER(ctypes.c_uint32),
                                       ctypes.POINTER(ctypes.c_uint32)]),
@@ -156,7 +157,7 @@ SIGNATURES = {
                                   ctypes.POINTER(_i32), ctypes.POINTER(_i32)]),
 }
 
-ABI_VERSION = 4        # keep in step with BINF_ABI_VERSION (include/binf_hip.h)
+ABI_VERSION = 5        # keep in step with BINF_ABI_VERSION (include/binf_hip.h)
 
 
 def lib():
@@ -660,29 +661,41 @@ def jacobian_contract(jacobian, emgrad):
 
 
 @_launcher
-def sum_terms(terms):
-    """``((t0 + t1) + t2) + ...`` in one launch; a term is a device tensor (all of
-    one shape) or a Python / numpy scalar."""
+def sum_terms(terms, like=None):
+    """``((t0 + t1) + t2) + ...`` in one launch (at most 16 terms); a term is a device
+    vector (all of one shape), a 0-dim device tensor (ONE device double, broadcast --
+    never read back to the host) or a Python / numpy scalar.  ``like``: a tensor of the
+    result's shape when no vector is among the terms."""
     tens = [t for t in terms if isinstance(t, torch.Tensor) and t.dim() > 0]
-    if not tens:
-        raise TypeError('sum_terms: no device tensor among the terms')
-    ref = tens[0]
+    if not tens and like is None:
+        raise TypeError('sum_terms: no device vector among the terms')
+    ref = tens[0] if tens else like
     n = ref.numel()
     T = len(terms)
     ptrs = (_vp * T)()
     scal = (_f64 * T)()
+    bc = (ctypes.c_uint8 * T)()
+    any_bc = False
     for i, t in enumerate(terms):
         if isinstance(t, torch.Tensor) and t.dim() > 0:
             if t.shape != ref.shape:
                 raise ValueError('sum_terms: term shapes differ (%s, %s)'
                                  % (tuple(t.shape), tuple(ref.shape)))
             ptrs[i] = dptr(t, numel=n, name='term %d' % i)
+        elif isinstance(t, torch.Tensor):
+            ptrs[i] = dptr(t, numel=1, name='term %d' % i)
+            bc[i] = 1
+            any_bc = True
         else:
             ptrs[i] = None
             scal[i] = float(t)
     out = torch.empty_like(ref)
-    rc = lib().binf_sum_terms_f64(ptrs, scal, T, dptr(out), n, stream_handle(ref.device))
-    check(rc, 'binf_sum_terms_f64')
+    if any_bc:
+        rc = lib().binf_sum_terms_bcast_f64(ptrs, scal, bc, T, dptr(out), n, stream_handle(ref.device))
+        check(rc, 'binf_sum_terms_bcast_f64')
+    else:
+        rc = lib().binf_sum_terms_f64(ptrs, scal, T, dptr(out), n, stream_handle(ref.device))
+        check(rc, 'binf_sum_terms_f64')
     return out
 
 

@@ -23,6 +23,15 @@ int32_t hip_fail(hipError_t e, const char *what);
         if (e_ != hipSuccess) return binf::hip_fail(e_, #expr); \
     } while (0)
 
+// ---- buffer aliasing (host) ------------------------------------------------
+// true if [a, a + a_elems) and [b, b + b_elems) (doubles) share a byte
+inline bool overlap_f64(const void *a, int64_t a_elems, const void *b, int64_t b_elems)
+{
+    if (!a || !b || a_elems <= 0 || b_elems <= 0) return false;
+    const char *pa = (const char *)a, *pb = (const char *)b;
+    return pa < pb + b_elems * (int64_t)sizeof(double) && pb < pa + a_elems * (int64_t)sizeof(double);
+}
+
 // ---- numpy pairwise-summation geometry -------------------------------------
 // np.add.reduce on a contiguous f64 vector: blocks of <=128 elements ("leaves")
 // are summed with 8 strided accumulators, blocks are joined by a binary tree

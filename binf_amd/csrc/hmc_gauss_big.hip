@@ -539,6 +539,20 @@ static int32_t big_run_n(const char *what, const double *q0, const double *p0, c
         return fail(BINF_E_ARG, "%s: needs %lld bytes of workspace, got %lld", what,
                     (long long)binf_hmc_sample_n_gauss_big_workspace_bytes(C, D), (long long)workspace_bytes);
     const int64_t CD = C * D;
+    // Every proposal is written straight to where it is kept (a `samples` slot, q_out or the
+    // scratch state) and a rejected chain is restored from the buffer its transition read:
+    // the record buffer must not touch q0, q_out, the [n x C x D] momenta or the workspace,
+    // and no momentum block (not only the first, which big_check looks at) may touch q_out.
+    const int64_t nrec = samples ? n / thin : 0;
+    if (nrec > 0 && (overlap_f64(samples, nrec * CD, q0, CD) || overlap_f64(samples, nrec * CD, q_out, CD) ||
+                     (p0 && overlap_f64(samples, nrec * CD, p0, (int64_t)n * CD)) ||
+                     overlap_f64(samples, nrec * CD, workspace, (workspace_bytes + 7) / 8)))
+        return fail(BINF_E_ALIAS, "%s: samples overlaps q0, q_out, p0 or the workspace", what);
+    if (p0 && overlap_f64(q_out, CD, p0, (int64_t)n * CD))
+        return fail(BINF_E_ALIAS, "%s: q_out overlaps the [n x C x D] momenta", what);
+    if (overlap_f64(q0, CD, workspace, (workspace_bytes + 7) / 8) ||
+        overlap_f64(q_out, CD, workspace, (workspace_bytes + 7) / 8))
+        return fail(BINF_E_ALIAS, "%s: q0 / q_out overlap the workspace", what);
     double *scratch = (double *)((char *)workspace + binf_hmc_sample_gauss_big_workspace_bytes(C, D));
     // unrecorded transitions alternate between q_out and the scratch state so that
     // the LAST unrecorded one of a run lands in q_out

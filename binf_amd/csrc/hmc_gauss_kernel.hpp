@@ -81,11 +81,14 @@ hmc_gauss_persist_kernel(const GaussNArgs a)
     // i.e. by WHICH elements the lane owns, not by where it runs (nor by which
     // rank's shard the chain sits in: chain_offset); the redundant groups of a
     // ragged tree share the stream of the leaf they recompute
+    // Transition s of a launch draws from stream position rng_offset + s, exactly what
+    // a single-transition launch at that position draws: sample_n(n) and n sample()
+    // calls see the same chains (as on the long-chain path, hmc_gauss_big.hip).
     Xo128 gen = {0u, 0u, 0u, 0u};
+    uint64_t gen_stream = 0;
     if (RNG != GAUSS_RNG_HBM) {
         const int cgrp = grp & ~((1 << (H - leafdepth)) - 1);
-        gen = xo_seed((uint64_t)(chain + a.chain_offset) * (uint64_t)(8 << H) + (uint64_t)(cgrp * 8 + j),
-                      a.rng_seed, a.rng_offset);
+        gen_stream = (uint64_t)(chain + a.chain_offset) * (uint64_t)(8 << H) + (uint64_t)(cgrp * 8 + j);
     }
     if (a.stagger > 0) {
         // De-phase the waves that share a SIMD: a launch puts every wave in the
@@ -140,6 +143,7 @@ hmc_gauss_persist_kernel(const GaussNArgs a)
 
     for (int s = 0; s < a.n; ++s) {
         const double hdt = 0.5 * dt;
+        if (RNG != GAUSS_RNG_HBM) gen = xo_seed(gen_stream, a.rng_seed, a.rng_offset + (uint64_t)s);
         // state before the transition -> LDS (read back only on rejection)
         if (RNG != GAUSS_RNG_DUMP && stash_lds) {
 #pragma unroll

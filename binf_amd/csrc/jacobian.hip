@@ -127,14 +127,16 @@ constexpr int SUM_TERMS_MAX = 16;
 struct SumTermsArgs {
     const double *ptr[SUM_TERMS_MAX];
     double scalar[SUM_TERMS_MAX];
+    uint8_t bcast[SUM_TERMS_MAX];      // ptr[t] is ONE device double, the same for every i
     int32_t T;
 };
 
 __global__ void __launch_bounds__(256) sum_terms_kernel(const SumTermsArgs a, double *out, int64_t n)
 {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        double s = a.ptr[0] ? a.ptr[0][i] : a.scalar[0];
-        for (int t = 1; t < a.T; ++t) s = s + (a.ptr[t] ? a.ptr[t][i] : a.scalar[t]);
+        double s = a.ptr[0] ? a.ptr[0][a.bcast[0] ? 0 : i] : a.scalar[0];
+        for (int t = 1; t < a.T; ++t)
+            s = s + (a.ptr[t] ? a.ptr[t][a.bcast[t] ? 0 : i] : a.scalar[t]);
         out[i] = s;
     }
 }
@@ -177,20 +179,27 @@ extern "C" int32_t binf_jacobian_contract_f64(const double *jacobian, const doub
     return 0;
 }
 
-extern "C" int32_t binf_sum_terms_f64(const double *const *terms, const double *scalars,
-                                      int32_t n_terms, double *out, int64_t n, void *stream)
+static int32_t sum_terms_launch(const char *what, const double *const *terms, const double *scalars,
+                                const uint8_t *broadcast, int32_t n_terms, double *out, int64_t n,
+                                void *stream)
 {
     if (n_terms < 1 || n_terms > SUM_TERMS_MAX)
-        return fail(BINF_E_ARG, "sum_terms: 1 .. %d terms, got %d", SUM_TERMS_MAX, n_terms);
-    if (n < 0) return fail(BINF_E_ARG, "sum_terms: negative size");
+        return fail(BINF_E_ARG, "%s: 1 .. %d terms, got %d", what, SUM_TERMS_MAX, n_terms);
+    if (n < 0) return fail(BINF_E_ARG, "%s: negative size", what);
     if (n == 0) return 0;
-    if (!terms || !out) return fail(BINF_E_ARG, "sum_terms: null pointer");
+    if (!terms || !out) return fail(BINF_E_ARG, "%s: null pointer", what);
     SumTermsArgs a;
     a.T = n_terms;
+    for (int t = 0; t < SUM_TERMS_MAX; ++t) a.bcast[t] = 0;
     for (int t = 0; t < n_terms; ++t) {
         a.ptr[t] = terms[t];
-        if (!terms[t] && !scalars) return fail(BINF_E_ARG, "sum_terms: term %d has neither a vector nor a scalar", t);
+        if (!terms[t] && !scalars) return fail(BINF_E_ARG, "%s: term %d has neither a vector nor a scalar", what, t);
         a.scalar[t] = scalars ? scalars[t] : 0.0;
+        a.bcast[t] = (broadcast && broadcast[t]) ? 1 : 0;
+        // a broadcast term overlapping out would be overwritten by element 0's sum while
+        // other elements still read it
+        if (a.bcast[t] && terms[t] && overlap_f64(terms[t], 1, out, n))
+            return fail(BINF_E_ALIAS, "%s: broadcast term %d lies inside out", what, t);
     }
     int64_t blocks = (n + 255) / 256;
     if (blocks > 65536) blocks = 65536;
@@ -198,4 +207,17 @@ extern "C" int32_t binf_sum_terms_f64(const double *const *terms, const double *
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "sum_terms launch");
     return 0;
+}
+
+extern "C" int32_t binf_sum_terms_f64(const double *const *terms, const double *scalars,
+                                      int32_t n_terms, double *out, int64_t n, void *stream)
+{
+    return sum_terms_launch("sum_terms", terms, scalars, nullptr, n_terms, out, n, stream);
+}
+
+extern "C" int32_t binf_sum_terms_bcast_f64(const double *const *terms, const double *scalars,
+                                            const uint8_t *broadcast, int32_t n_terms, double *out,
+                                            int64_t n, void *stream)
+{
+    return sum_terms_launch("sum_terms_bcast", terms, scalars, broadcast, n_terms, out, n, stream);
 }

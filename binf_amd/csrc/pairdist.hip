@@ -1268,8 +1268,14 @@ extern "C" int32_t binf_pairdist_gauss_logp_memo_f64(const double *x, const int3
     if (C == 0) return 0;
     if (!x || !memo_x || !memo_chi2 || !skip)
         return fail(BINF_E_ARG, "pairdist_gauss_logp_memo: null buffer");
-    const int32_t rc = row_memo_check(x, memo_x, skip, C, 3 * n_beads, (hipStream_t)stream,
-                                      "pairdist_gauss_logp_memo check launch");
+    // every refusal of the reduction BEFORE the memo is touched (row_memo_check rewrites the
+    // stored coordinates of a missed chain; their chi^2 is stored by the reduction after it)
+    if (!out || (n_pairs > 0 && (!pair_i || !pair_j || !ys)))
+        return fail(BINF_E_ARG, "pairdist_gauss_logp_memo: null buffer");
+    int32_t rc = row_reduce_check(C, n_pairs, "pairdist_gauss_logp_memo");
+    if (rc) return rc;
+    rc = row_memo_check(x, memo_x, skip, C, 3 * n_beads, (hipStream_t)stream,
+                        "pairdist_gauss_logp_memo check launch");
     if (rc) return rc;
     return pairdist_logp_run(x, pair_i, pair_j, ys, precision, precision_chain, out, skip, memo_chi2,
                              C, n_beads, n_pairs, stream);
@@ -1543,6 +1549,14 @@ extern "C" int32_t binf_pairdist_leapfrog_packed_f64(double *q, const double *q_
     if (n_beads > 1024)
         return fail(BINF_E_UNSUPPORTED, "pairdist_leapfrog: n_beads=%lld > 1024 not covered by the fused kernel", (long long)n_beads);
     if (C > 0x7fffffffLL) return fail(BINF_E_UNSUPPORTED, "pairdist_leapfrog: too many chains");
+    // q_from may be q itself (in place) or a separate buffer; a PARTIAL overlap -- with q, or with
+    // the momenta the launch updates -- would have chains read what others already wrote
+    if (q_from && q_from != q && (overlap_f64(q_from, C * 3 * n_beads, q, C * 3 * n_beads) ||
+                                  overlap_f64(q_from, C * 3 * n_beads, p, C * 3 * n_beads)))
+        return fail(BINF_E_ALIAS, "pairdist_leapfrog: q_from may be exactly q or a separate buffer, "
+                    "not a partial overlap with q or p");
+    if (overlap_f64(q, C * 3 * n_beads, p, C * 3 * n_beads))
+        return fail(BINF_E_ALIAS, "pairdist_leapfrog: q and p overlap");
     PairLeapArgs a;
     a.q = q; a.q_from = (q_from == q) ? nullptr : q_from; a.p = p; a.ymat = ymat; a.ypk = packed;
     a.tau_chain = precision_chain; a.dt_chain = dt_chain;

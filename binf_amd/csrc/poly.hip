@@ -312,6 +312,216 @@ __global__ void __launch_bounds__(256) poly_grad_mfma_kernel(const GradArgs a)
     }
 }
 
+// ---------------------------------------------------------------------------
+// The same product for data sets made of WHOLE tiles (N % 16 == 0, K * N below
+// 2^28 entries -- BASELINE C3 / C4: N = 16384): what the loop above spends beside
+// its MFMAs is taken out of it.
+//
+// Why it matters (scripts/mfma64_duty.hip, profiles/r04_b_mfma64_duty.jsonl): on
+// gfx950 NOTHING issues beside a v_mfma_f64_16x16x4_f64 for free.  A bare loop of
+// them sustains 70.8 TFLOP/s (71 cycles per MFMA and SIMD at 2.39 GHz, 0.90 of the
+// 78.6 datasheet figure); every VALU instruction a wave adds -- FP64, FP32, integer,
+// v_mov alike -- costs the SIMD's matrix pipe another 3.4 - 5.9 cycles, whereas idle
+// cycles and ds_read are hidden.  The general kernel issues ~130 VALU instructions
+// per 32 MFMAs (address arithmetic for the prefetch and both LDS buffers, AGPR
+// read-back of the forward accumulators, tail selects): 56 - 59 TFLOP/s.  Here:
+//   * the tile loop is unrolled over the two LDS buffers, so every LDS address is a
+//     per-thread base plus an immediate offset (no VALU);
+//   * the prefetch addresses are a uniform tile pointer (SGPRs) plus a per-thread
+//     32-bit offset computed once (no VALU, no clamp: every tile is whole);
+//   * no validity selects (there is no partial tile; rows of A beyond K are copies of
+//     row K - 1 that only ever meet zero coefficients or unstored output rows);
+//   * the file is compiled with -amdgpu-mfma-vgpr-form: accumulators live in VGPRs,
+//     the 16 v_accvgpr_read per tile between the two products are gone.
+// The MFMA sequence, the split of the data range and the order of every sum are
+// those of the general kernel: the two return the same bits.
+// ---------------------------------------------------------------------------
+template <int B> struct BufC { static constexpr int value = B; };
+
+// Workgroups per CU the register allocator is held to: 3 (12 waves per CU, <= 168
+// VGPRs) where the kernel fits without spilling inside the tile loop -- K <= 33, the
+// K <= 36 and K <= 48 shapes -- else 2.
+constexpr int grad_full_wgs(int KS, int KV)
+{
+    return ((KS <= 8 && KV <= 1) || KS == 9 || (KS == 12 && KV == 0)) ? 3 : 2;
+}
+
+template <int KS, int RT, int KV, int CT>
+__global__ void __launch_bounds__(256, grad_full_wgs(KS, KV)) poly_grad_mfma_full_kernel(const GradArgs a)
+{
+    constexpr int KB = 4 * KS;
+    constexpr int ROWS0 = (4 * KS > 16 * RT) ? 4 * KS : 16 * RT;
+    constexpr int ROWS = ROWS0 + KV;
+    constexpr int PASSES = (ROWS + 15) / 16;
+    static_assert(KV == 0 || 4 * KS == 16 * RT, "VALU tail needs 4*KS == 16*RT");
+    __shared__ double sA[2][ROWS][LDA];
+    __shared__ double sY[2][16];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int lc = lane & 15;
+    const int lk = lane >> 4;
+    const int K = a.K, N = a.N;
+
+    int64_t chain[CT];
+    bool cvalid[CT];
+    double th[CT][KS];
+    double thv[CT][KV > 0 ? KV : 1], gv[CT][KV > 0 ? KV : 1];
+    double tau[CT];
+    v4d G[CT][RT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+        chain[c] = ((int64_t)blockIdx.x * 4 + wave) * (16 * CT) + 16 * c + lc;
+        cvalid[c] = chain[c] < a.C;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int k = 4 * s + lk;
+            th[c][s] = (cvalid[c] && k < K) ? a.theta[chain[c] * K + k] : 0.0;
+        }
+#pragma unroll
+        for (int v = 0; v < KV; ++v) {
+            thv[c][v] = (cvalid[c] && KB + v < K) ? a.theta[chain[c] * K + KB + v] : 0.0;
+            gv[c][v] = 0.0;
+        }
+        tau[c] = cvalid[c] ? (a.tau_chain ? a.tau_chain[chain[c]] : a.tau) : 0.0;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) G[c][rt] = (v4d){0.0, 0.0, 0.0, 0.0};
+    }
+
+    const int t0 = blockIdx.y * a.tiles_per_split;
+    int t1 = t0 + a.tiles_per_split;
+    const int ntiles = N / 16;
+    if (t1 > ntiles) t1 = ntiles;
+
+    // staging: thread (srow, scol) moves A[16*pass + srow][16 t + scol]; its offset inside
+    // the tile's column block is fixed, the tile pointer is uniform
+    const int srow = tid >> 4, scol = tid & 15;
+    unsigned voff[PASSES];                     // BYTE offsets (K N <= 2^28 entries: 31 bits)
+#pragma unroll
+    for (int ps = 0; ps < PASSES; ++ps) {
+        const int k = 16 * ps + srow;
+        voff[ps] = ((unsigned)(k < K ? k : K - 1) * (unsigned)N + (unsigned)scol) * 8u;
+    }
+    const unsigned yoff = (unsigned)scol * 8u;
+    // buffer resources over A and ys: an address is resource (SGPRs) + per-thread byte
+    // offset (one VGPR, fixed) + tile offset (an SGPR the scalar unit advances) -- the
+    // prefetch costs no VALU instruction (global_load needs a 64-bit VGPR address per
+    // load, which loop strength reduction keeps as four induction pointers).
+    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)a.A, 0, (unsigned)((int64_t)K * N * 8), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rY = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)a.ys, 0, (unsigned)((int64_t)N * 8), 0x00020000);
+    double pre[PASSES];
+    double prey = 0.0;
+    auto fetch = [&](int t) {
+        const int soff = t * 128;               // 16 doubles per tile
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ++ps)
+            pre[ps] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rA, voff[ps], soff, 0));
+        prey = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rY, yoff, soff, 0));
+    };
+    auto stash = [&](auto bc) {
+        constexpr int buf = decltype(bc)::value;
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ++ps) {
+            const int k = 16 * ps + srow;
+            if (16 * ps + 15 < ROWS || k < ROWS) sA[buf][k][scol] = pre[ps];
+        }
+        if (tid < 16) sY[buf][tid] = prey;
+    };
+    auto tile = [&](auto bc, int t) {
+        constexpr int buf = decltype(bc)::value;
+        fetch(t + 1 < t1 ? t + 1 : t);         // in flight during the MFMAs
+        __builtin_amdgcn_sched_barrier(0);
+        // forward: M^T[n][c] = sum_k A[k][n] theta[c][k]
+        v4d acc[CT];
+#pragma unroll
+        for (int c = 0; c < CT; ++c) acc[c] = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const double av = sA[buf][4 * s + lk][lc];
+#pragma unroll
+            for (int c = 0; c < CT; ++c)
+                acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, th[c][s], acc[c], 0, 0, 0);
+        }
+#pragma unroll
+        for (int v = 0; v < KV; ++v)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double av = sA[buf][KB + v][lk + 4 * r];
+#pragma unroll
+                for (int c = 0; c < CT; ++c)
+                    acc[c][r] = __builtin_fma(thv[c][v], av, acc[c][r]);
+            }
+        // error-model gradient in place: r[n][c] = (mock - y[n]) * tau_c
+        double rr[CT][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const double yv = sY[buf][lk + 4 * r];
+#pragma unroll
+            for (int c = 0; c < CT; ++c) rr[c][r] = (acc[c][r] - yv) * tau[c];
+        }
+        // backward: G^T[i][c] += sum_n A[i][n] r[n][c]
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const double av = sA[buf][16 * rt + lc][4 * s + lk];
+#pragma unroll
+                for (int c = 0; c < CT; ++c)
+                    G[c][rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, rr[c][s], G[c][rt], 0, 0, 0);
+            }
+#pragma unroll
+        for (int v = 0; v < KV; ++v)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double av = sA[buf][KB + v][lk + 4 * r];
+#pragma unroll
+                for (int c = 0; c < CT; ++c)
+                    gv[c][v] = __builtin_fma(av, rr[c][r], gv[c][v]);
+            }
+        if (t + 1 < t1) stash(BufC<buf ^ 1>());
+        __syncthreads();
+    };
+
+    if (t0 < t1) {
+        fetch(t0);
+        stash(BufC<0>());
+    }
+    __syncthreads();
+    int t = t0;
+    for (; t + 1 < t1; t += 2) {
+        tile(BufC<0>(), t);
+        tile(BufC<1>(), t + 1);
+    }
+    if (t < t1) tile(BufC<0>(), t);
+
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+#pragma unroll
+        for (int v = 0; v < KV; ++v) {
+            gv[c][v] = gv[c][v] + shfl_xor_f64(gv[c][v], 16);
+            gv[c][v] = gv[c][v] + shfl_xor_f64(gv[c][v], 32);
+        }
+        if (cvalid[c]) {
+            double *dst = a.part + ((int64_t)blockIdx.y * a.C + chain[c]) * K;
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = 16 * rt + lk + 4 * r;
+                    if (i < K) dst[i] = G[c][rt][r];
+                }
+            if (lk == 0) {
+#pragma unroll
+                for (int v = 0; v < KV; ++v)
+                    if (KB + v < K) dst[KB + v] = gv[c][v];
+            }
+        }
+    }
+}
+
 // out[j] = part[0][j] + part[1][j] + ... in split order (deterministic)
 __global__ void split_reduce_kernel(const double *part, double *out, int64_t n,
                                     int32_t ns)
@@ -377,11 +587,27 @@ static int grad_splits(int64_t C, int64_t N)
     return (int)ns;
 }
 
+static bool grad_whole_tiles(const GradArgs &a)
+{
+    // every tile whole and every staging offset inside 32 bits: the trimmed kernel
+    static int general = -1;
+    if (general < 0) {
+        const char *e = getenv("BINF_POLY_GRAD_GENERAL");   // development aid: A/B the two kernels
+        general = (e && atoi(e)) ? 1 : 0;
+    }
+    return !general && a.N >= 16 && a.N % 16 == 0 && (int64_t)a.K * a.N < (1LL << 28);
+}
+
 template <int KS, int RT, int KV>
 static hipError_t grad_launch(const GradArgs &a, int ct, dim3 grid, hipStream_t st)
 {
-    if (ct == 2) poly_grad_mfma_kernel<KS, RT, KV, 2><<<grid, 256, 0, st>>>(a);
-    else         poly_grad_mfma_kernel<KS, RT, KV, 1><<<grid, 256, 0, st>>>(a);
+    if (grad_whole_tiles(a)) {
+        if (ct == 2) poly_grad_mfma_full_kernel<KS, RT, KV, 2><<<grid, 256, 0, st>>>(a);
+        else         poly_grad_mfma_full_kernel<KS, RT, KV, 1><<<grid, 256, 0, st>>>(a);
+    } else {
+        if (ct == 2) poly_grad_mfma_kernel<KS, RT, KV, 2><<<grid, 256, 0, st>>>(a);
+        else         poly_grad_mfma_kernel<KS, RT, KV, 1><<<grid, 256, 0, st>>>(a);
+    }
     return hipGetLastError();
 }
 
@@ -514,6 +740,10 @@ extern "C" int32_t binf_poly_gauss_logp_memo_f64(const double *coeffs, const dou
     if (!coeffs || ((!xs || !ys) && N > 0) || !out || !memo_coeffs || !memo_chi2 || !skip)
         return fail(BINF_E_ARG, "poly_gauss_logp_memo: null buffer");
     hipStream_t st = (hipStream_t)stream;
+    // every refusal of the reduction BEFORE the memo is touched (its check kernel rewrites
+    // the stored coefficients of a missed row; their chi^2 is stored by the reduction)
+    rc = row_reduce_check(C, N, "poly_gauss_logp_memo");
+    if (rc) return rc;
     // which chains still have the coefficients their stored chi^2 belongs to (rowsum.hpp)
     rc = row_memo_check(coeffs, memo_coeffs, skip, C, K, st, "poly_gauss_logp_memo check launch");
     if (rc) return rc;

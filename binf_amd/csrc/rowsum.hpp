@@ -194,6 +194,24 @@ row_reduce_block_kernel(const ARGS args, const RowGeom g, double *out)
     }
 }
 
+// The shapes row_reduce_launch accepts, as a check of its own: a caller that changes
+// state BEFORE the reduction (the chi^2 memos: row_memo_check rewrites the memo's
+// arguments) must know the reduction will not be refused afterwards -- an entry whose
+// arguments match but whose sum was never stored would be a silent wrong hit.
+static int32_t row_reduce_check(int64_t C, int64_t D, const char *what, int32_t *height = nullptr)
+{
+    if (C > 0x7fffffffLL || D > 0x7fffffffLL)
+        return fail(BINF_E_UNSUPPORTED, "%s: too large", what);
+    int32_t H = pairwise_tree_height(D < NPY_BUFSIZE ? D : NPY_BUFSIZE);
+    if (D > NPY_BUFSIZE && D % NPY_BUFSIZE != 0) {
+        const int32_t h_last = pairwise_tree_height(D % NPY_BUFSIZE);
+        if (h_last > H) H = h_last;
+    }
+    if (H > 7) return fail(BINF_E_UNSUPPORTED, "%s: pairwise tree height %d", what, H);
+    if (height) *height = H;
+    return 0;
+}
+
 template <class FM, class ARGS, bool STAGED = false>
 static int32_t row_reduce_launch(const ARGS &args, int64_t C, int64_t D,
                                  double scale, double *out, hipStream_t st,
@@ -202,20 +220,16 @@ static int32_t row_reduce_launch(const ARGS &args, int64_t C, int64_t D,
                                  const GaussFinish *fin = nullptr,
                                  const uint8_t *memo_state = nullptr, double *memo_sum = nullptr)
 {
-    if (C > 0x7fffffffLL || D > 0x7fffffffLL)
-        return fail(BINF_E_UNSUPPORTED, "%s: too large", what);
+    int32_t height = 0;
+    const int32_t rc_shape = row_reduce_check(C, D, what, &height);
+    if (rc_shape) return rc_shape;
     RowGeom g;
     g.C = C; g.D = (int32_t)D; g.scale = scale;
     if (fin) g.fin = *fin;
     else { g.fin.on = 0; g.fin.tau = 1.0; g.fin.tau_chain = nullptr; g.fin.n_data = 0.0; g.fin.minus = nullptr; }
     // honoured by the block kernel (force_block); memo_state = [skip [C], way [C]]
     g.skip = memo_state; g.way = memo_state ? memo_state + C : nullptr; g.memo_sum = memo_sum;
-    g.H = pairwise_tree_height(D < NPY_BUFSIZE ? D : NPY_BUFSIZE);
-    if (D > NPY_BUFSIZE && D % NPY_BUFSIZE != 0) {
-        const int32_t h_last = pairwise_tree_height(D % NPY_BUFSIZE);
-        if (h_last > g.H) g.H = h_last;
-    }
-    if (g.H > 7) return fail(BINF_E_UNSUPPORTED, "%s: pairwise tree height %d", what, g.H);
+    g.H = height;
     if constexpr (STAGED) {
         if (wide)
             row_reduce_block_kernel<FM, ARGS, true, 1024><<<dim3((unsigned)C), 1024, staged_bytes, st>>>(args, g, out);

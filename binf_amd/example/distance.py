@@ -189,19 +189,11 @@ def native_hmc_energy(likelihood, x2, p2, precision, prior, terms):
 
 
 USE_CHI2_MEMO = True
-_memos = {}
 
 
 def _chi2_memo(I, ys, shape):
-    C, D = shape
-    key = (id(I), id(ys), C, D, _native.stream_handle(ys.device))
-    m = _memos.get(key)
-    if m is None or m[0] is not I or m[1] is not ys:
-        m = (I, ys, _native.new_chi2_memo(C, D, ys.device))
-        while len(_memos) >= 8:
-            _memos.pop(next(iter(_memos)))
-        _memos[key] = m
-    return m[2]
+    from binf_amd import memo
+    return memo.chi2_memo(ys, I, shape, ys.device, _native.new_chi2_memo)
 
 
 def native_gradient(likelihood, fwm, em, fwm_vars, em_vars):

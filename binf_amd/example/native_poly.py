@@ -43,22 +43,14 @@ def log_prob(likelihood, pair, fwm_vars, em_vars):
 
 USE_CHI2_MEMO = True
 CHI2_MEMO_MIN_DATA = 2048       # below, the pass is a few microseconds
-_memos = {}
 
 
 def _chi2_memo(xs, ys, shape):
-    """(memo_coeffs, memo_chi2, memo_state) for this data set, batch shape and stream; the
-    key holds the data tensors themselves (clones of a model share them), so new data
-    get a new memo."""
-    C, K = shape
-    key = (id(xs), id(ys), C, K, _native.stream_handle(xs.device))
-    m = _memos.get(key)
-    if m is None or m[0] is not xs or m[1] is not ys:
-        m = (xs, ys, _native.new_chi2_memo(C, K, xs.device))
-        while len(_memos) >= 8:
-            _memos.pop(next(iter(_memos)))
-        _memos[key] = m
-    return m[2]
+    """(memo_coeffs, memo_chi2, memo_state) for this data set, batch shape and stream
+    (binf_amd/memo.py: weakly keyed by the data, capped by bytes; clones of a model share
+    their device copies and therefore their memo, new data get a new one)."""
+    from binf_amd import memo
+    return memo.chi2_memo(ys, xs, shape, xs.device, _native.new_chi2_memo)
 
 
 def gradient(likelihood, pair, fwm_vars, em_vars):
@@ -229,6 +221,10 @@ def gibbs_sample_n(gibbs, n, thin, record):
     gamma_shape = 0.5 * len(em.ys) + gprior.shape - 1              # samplers.py:27-32
 
     # ---- draw sources -------------------------------------------------------
+    # Nothing is consumed for good before the launch has been accepted: the device
+    # generators' positions are advanced after it, and a failed launch puts the host
+    # stream back where it was (a retry, or the per-variable loop, then draws what
+    # the unfused run draws).
     rng_c = _device_rng_of(cs.rng) if cs.rng is not None else None
     rng_g = _device_rng_of(ps.gamma) if ps.gamma is not None else None
     host_c = (cs.rng is None) if not hmc else type(cs.rng) is HostLegacyRNG
@@ -236,6 +232,8 @@ def gibbs_sample_n(gibbs, n, thin, record):
     p0 = u = g = streams = None
     zig = True
     coff = 0
+    advance = []                    # (generator, positions) to take once the launch is in
+    host_state = None
     if rng_c is not None and rng_g is not None:
         if gamma_shape < 1.0 or rng_c.chain_offset != rng_g.chain_offset:
             return False, None
@@ -244,14 +242,14 @@ def gibbs_sample_n(gibbs, n, thin, record):
         if rng_c is rng_g:
             o = rng_c.offset             # per sweep: momentum / step, acceptance, gamma (+128)
             streams = ((rng_c.seed, o, 130), (rng_c.seed, o + 1, 130), (rng_c.seed, o + 2, 130))
-            rng_c.offset += 130 * n
+            advance = [(rng_c, 130 * n)]
         else:
             streams = ((rng_c.seed, rng_c.offset, 2), (rng_c.seed, rng_c.offset + 1, 2),
                        (rng_g.seed, rng_g.offset, 128))
-            rng_c.offset += 2 * n
-            rng_g.offset += 128 * n
+            advance = [(rng_c, 2 * n), (rng_g, 128 * n)]
     elif host_c and host_g:
         # the global legacy stream in the order n sweeps consume it
+        host_state = np.random.get_state()
         hp = np.empty((n, C, K))
         hu = np.empty((n, C))
         hg = np.empty((n, C))
@@ -290,16 +288,23 @@ def gibbs_sample_n(gibbs, n, thin, record):
         if not isinstance(cs._n_accepted_moves, torch.Tensor):
             cs._n_accepted_moves = torch.zeros(C, dtype=torch.int64, device=dev)
         kw = dict(move=_native.MOVE_RWMC, stepsize=cs.stepsize, n_accepted=cs._n_accepted_moves)
-    _native.gibbs_poly_sample_n(
-        theta.contiguous(), tau.contiguous(), theta_out, tau_out, fwm.xs_device(dev),
-        em.ys_device(dev), n, thin,
-        prior_means=prior._vec('means', dev) if prior is not None else None,
-        prior_vars=prior._vec('variances', dev) if prior is not None else None,
-        prior_first=prior_first, gp_where=gp_where,
-        gp_shape=gp.shape if gp is not None else 1.0, gp_rate=gp.rate if gp is not None else 0.0,
-        gamma_shape=gamma_shape, gamma_rate=gprior.rate, rec_coefficients=rec_c,
-        rec_precision=rec_t, accepted=accepted, p0=p0, u=u, g=g, streams=streams,
-        chain_offset=coff, zig=zig, **kw)
+    try:
+        _native.gibbs_poly_sample_n(
+            theta.contiguous(), tau.contiguous(), theta_out, tau_out, fwm.xs_device(dev),
+            em.ys_device(dev), n, thin,
+            prior_means=prior._vec('means', dev) if prior is not None else None,
+            prior_vars=prior._vec('variances', dev) if prior is not None else None,
+            prior_first=prior_first, gp_where=gp_where,
+            gp_shape=gp.shape if gp is not None else 1.0, gp_rate=gp.rate if gp is not None else 0.0,
+            gamma_shape=gamma_shape, gamma_rate=gprior.rate, rec_coefficients=rec_c,
+            rec_precision=rec_t, accepted=accepted, p0=p0, u=u, g=g, streams=streams,
+            chain_offset=coff, zig=zig, **kw)
+    except Exception:
+        if host_state is not None:
+            np.random.set_state(host_state)
+        raise
+    for gen, positions in advance:
+        gen.offset += positions
 
     # ---- what n single sweeps would have left behind ---------------------------
     flags = accepted.view(torch.bool)
@@ -353,16 +358,19 @@ def hmc_sample_n(sampler, spec, n, thin, p0, u, record, out, q0):
     streams = None
     zig = True
     coff = 0
+    take = 0
+    host_state = None
     if p0 is not None and u is not None:
         p0 = p0.reshape(n, C, K).contiguous()
         u = u.reshape(n, C).contiguous()
     elif p0 is None and u is None and dev_rng is not None:
         o = dev_rng.offset                      # per sample(): normal, then uniform
         streams = ((dev_rng.seed, o, 2), (dev_rng.seed, o + 1, 2), (0, 0, 0))
-        dev_rng.offset += 2 * n
+        take = 2 * n                            # ... taken once the launch is in (see gibbs_sample_n)
         zig = dev_rng._normal_kind == 'normal_zig'
         coff = dev_rng.chain_offset
     elif p0 is None and u is None and type(rng) is HostLegacyRNG:
+        host_state = np.random.get_state()
         hp, hu = np.empty((n, C, K)), np.empty((n, C))
         for i in range(n):
             hp[i] = np.random.normal(size=(C, K))                  # hmc.py:146
@@ -384,18 +392,25 @@ def hmc_sample_n(sampler, spec, n, thin, p0, u, record, out, q0):
     eb = torch.empty((n, C), dtype=torch.float64, device=dev)
     ea = torch.empty((n, C), dtype=torch.float64, device=dev)
     q_out = torch.empty_like(q0)
-    _native.gibbs_poly_sample_n(
-        q0, tau, q_out, torch.empty_like(tau), fwm.xs_device(dev), em.ys_device(dev), n, thin,
-        move=_native.MOVE_HMC, mode=_MODES[sampler.mode], nsteps=sampler.nsteps,
-        timestep=sampler._timestep, dt_chain=sampler._dt_chain, n_adapt=n_adapt,
-        uprate=sampler.adaption_uprate, downrate=sampler.adaption_downrate,
-        prior_means=prior._vec('means', dev) if prior is not None else None,
-        prior_vars=prior._vec('variances', dev) if prior is not None else None,
-        prior_first=prior_first, gp_where=0 if gp is None else (1 if pre else 2),
-        gp_shape=gp.shape if gp is not None else 1.0, gp_rate=gp.rate if gp is not None else 0.0,
-        rec_coefficients=samples, accepted=accepted, n_accepted=sampler.n_accepted,
-        e_before=eb, e_after=ea, p0=p0, u=u, streams=streams, chain_offset=coff, zig=zig,
-        keep_precision=True)
+    try:
+        _native.gibbs_poly_sample_n(
+            q0, tau, q_out, torch.empty_like(tau), fwm.xs_device(dev), em.ys_device(dev), n, thin,
+            move=_native.MOVE_HMC, mode=_MODES[sampler.mode], nsteps=sampler.nsteps,
+            timestep=sampler._timestep, dt_chain=sampler._dt_chain, n_adapt=n_adapt,
+            uprate=sampler.adaption_uprate, downrate=sampler.adaption_downrate,
+            prior_means=prior._vec('means', dev) if prior is not None else None,
+            prior_vars=prior._vec('variances', dev) if prior is not None else None,
+            prior_first=prior_first, gp_where=0 if gp is None else (1 if pre else 2),
+            gp_shape=gp.shape if gp is not None else 1.0, gp_rate=gp.rate if gp is not None else 0.0,
+            rec_coefficients=samples, accepted=accepted, n_accepted=sampler.n_accepted,
+            e_before=eb, e_after=ea, p0=p0, u=u, streams=streams, chain_offset=coff, zig=zig,
+            keep_precision=True)
+    except Exception:
+        if host_state is not None:
+            np.random.set_state(host_state)
+        raise
+    if take:
+        dev_rng.offset += take
     flags = accepted.view(torch.bool)
     sampler.last_e_before, sampler.last_e_after = eb, ea
     sampler._last_move_accepted = flags[-1]

@@ -17,10 +17,19 @@ part of the energy but not of the force.
 from binf_amd.pdf import AbstractBinfPDF
 
 
+SUM_TERMS_MAX = 16        # terms of one binf_sum_terms launch (include/binf_hip.h)
+
+
 def _sum_in_order(terms):
-    """``((t0 + t1) + t2) + ...``: per-chain device tensors in ONE launch of
-    ``binf_sum_terms_f64`` (Python-float terms ride along as scalars); host values
-    (the reference's own unit-test cases) with Python's ``+``."""
+    """``((t0 + t1) + t2) + ...``: per-chain device tensors in launches of
+    ``binf_sum_terms_bcast_f64`` (one launch for up to 16 terms, the running sum
+    carried into the next launch beyond that: the same left-to-right order);
+    Python floats ride along as scalars, 0-dim device tensors as broadcast device
+    scalars (never read back to the host).  Host values (the reference's own
+    unit-test cases) are added with Python's ``+``.  There is no PyTorch
+    arithmetic here: device terms the kernel cannot take -- host tensors mixed
+    with device tensors, other dtypes, non-contiguous or differently shaped
+    vectors -- are refused with a ``TypeError`` / ``ValueError``."""
     if len(terms) == 1:
         return terms[0]
     try:
@@ -28,18 +37,77 @@ def _sum_in_order(terms):
     except ImportError:  # pragma: no cover
         torch = None
 
-    def vector(t):
-        return torch is not None and isinstance(t, torch.Tensor) and t.dim() > 0
+    def tensor(t):
+        return torch is not None and isinstance(t, torch.Tensor)
 
-    vectors = [t for t in terms if vector(t)]
-    if vectors and len(terms) <= 16 and len(set(tuple(t.shape) for t in vectors)) == 1 and \
-            all(t.is_cuda and t.dtype == torch.float64 and t.is_contiguous() for t in vectors):
-        from binf_amd import _native
-        return _native.sum_terms([t if vector(t) else float(t) for t in terms])
-    total = terms[0]
-    for t in terms[1:]:
-        total = total + t
-    return total
+    if not any(tensor(t) for t in terms):
+        total = terms[0]
+        for t in terms[1:]:
+            total = total + t
+        return total
+    vectors = [t for t in terms if tensor(t) and t.dim() > 0]
+    if not vectors:
+        # only 0-dim tensors and floats: a one-element "vector" carries the sum
+        first = next(t for t in terms if tensor(t))
+        vectors = [first.reshape(1)]
+        terms = [t.reshape(1) if t is first else t for t in terms]
+        squeeze = True
+    else:
+        squeeze = False
+    ref = vectors[0]
+    for t in terms:
+        if not tensor(t):
+            continue
+        if not t.is_cuda or t.dtype != torch.float64:
+            raise TypeError('Posterior: component terms must be fp64 device tensors (or Python '
+                            'floats), got %s on %s' % (t.dtype, t.device))
+        if t.dim() > 0 and (tuple(t.shape) != tuple(ref.shape) or not t.is_contiguous()):
+            raise ValueError('Posterior: component terms must be contiguous and of one shape, got '
+                             '%s (contiguous: %s) beside %s' % (tuple(t.shape), t.is_contiguous(),
+                                                                tuple(ref.shape)))
+    from binf_amd import _native
+    total = None
+    rest = list(terms)
+    while rest:
+        take = SUM_TERMS_MAX - (0 if total is None else 1)
+        chunk, rest = rest[:take], rest[take:]
+        total = _native.sum_terms(([] if total is None else [total]) + chunk, like=ref)
+    return total.reshape(()) if squeeze else total
+
+
+def _zero_force(values, all_values=()):
+    """The reference's ``numpy.zeros(sum(len(v) for differentiable v passed))``
+    (``posteriors.py:177-180``) for chain-batched values: device tensors ``[C x d_i]``
+    (or ``[d_i]``, one chain) give a zero tensor ``[C x sum d_i]`` (``[sum d_i]``) on
+    their device -- the shape a gradient of those variables has; host values give the
+    reference's numpy vector.  With NO differentiable variable among those passed the
+    reference's vector is EMPTY (and its ``HMCSampler._leapfrog`` then fails to
+    broadcast it, ``hmc.py:116``): batched, that is ``[C x 0]``."""
+    try:
+        import torch
+    except ImportError:  # pragma: no cover
+        torch = None
+    is_t = lambda v: torch is not None and isinstance(v, torch.Tensor)
+    tens = [v for v in values if is_t(v)]
+    if not values:
+        like = next((v for v in all_values if is_t(v)), None)
+        if like is None:
+            import numpy
+            return numpy.zeros(0)
+        lead = tuple(like.shape[:-1]) if like.dim() > 1 else ()
+        return torch.zeros(lead + (0,), dtype=like.dtype, device=like.device)
+    if not tens:
+        import numpy
+        return numpy.zeros(sum(len(v) if hasattr(v, '__len__') else 1 for v in values))
+    if len(tens) != len(values):
+        raise TypeError('Posterior.gradient: device tensors and host values mixed')
+    first = tens[0]
+    if len(tens) == 1:
+        return torch.zeros_like(first)
+    if any(t.dim() != first.dim() or t.shape[:-1] != first.shape[:-1] for t in tens):
+        raise ValueError('Posterior.gradient: differentiable variables of different batch shape')
+    width = sum(int(t.shape[-1]) if t.dim() > 0 else 1 for t in tens)
+    return torch.zeros(tuple(first.shape[:-1]) + (width,), dtype=first.dtype, device=first.device)
 
 
 class Posterior(AbstractBinfPDF):
@@ -115,13 +183,11 @@ class Posterior(AbstractBinfPDF):
                 grads.append(f.gradient(**{x: variables[x] for x in variables
                                            if x in f.variables}))
         if not grads:
-            # no differentiable component: the reference returns its zero
-            # vector, one entry per element of the differentiable variables
-            # passed in (reference :177-180)
-            import numpy
-            return numpy.zeros(sum(len(variables[v]) if hasattr(variables[v], '__len__')
-                                   else 1 for v in variables
-                                   if v in self.differentiable_variables))
+            # no differentiable component: the reference returns its zero vector, one
+            # entry per element of the differentiable variables passed in (reference
+            # :177-180) -- batched: [C x (sum of their widths)] on the variables' device
+            diff = [variables[v] for v in variables if v in self.differentiable_variables]
+            return _zero_force(diff, list(variables.values()))
         return _sum_in_order(grads)
 
     # -- copies --------------------------------------------------------------

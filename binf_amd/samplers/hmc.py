@@ -198,9 +198,9 @@ class HMCSampler(object):
         of the reference's ``example_script.py:33-34``), returning the recorded
         states ``[n // thin, C, D]`` -- the state after transitions ``thin,
         2*thin, ...`` -- or None if ``record`` is false.  Results are
-        bit-identical to calling ``sample()`` n times with the same draws
-        (with a generator that draws inside the kernel, one launch takes one
-        stream position, so n single calls see other -- equally valid -- draws).
+        bit-identical to calling ``sample()`` n times -- with supplied draws, and
+        with a generator that draws inside the kernel too (transition i of the
+        launch takes the stream position the i-th single call would take).
 
         For PDFs with a fused kernel this is ONE launch of the persistent
         kernel (state kept in registers between transitions); otherwise it
@@ -229,8 +229,9 @@ class HMCSampler(object):
             # a small batch: the split kernel with the draws in HBM is the faster
             # launch, so the SAME lane-stream draws are written out first (a seed
             # identifies the draws whatever the batch size)
-            p0, u = _native.hmc_gauss_rng_draws(n, C, D, self.rng.seed, self.rng.next_offset(),
+            p0, u = _native.hmc_gauss_rng_draws(n, C, D, self.rng.seed, self.rng.offset,
                                                 dev, chain_offset=self._chain_offset())
+            self._take_positions(n)             # taken once the launch is in
             fused_rng = False
         if persist and not fused_rng and (p0 is None or u is None):
             # the draws of n sample() calls in the order those calls consume the
@@ -313,8 +314,9 @@ class HMCSampler(object):
                                            self.nsteps, n, thin, k, x0, n_adapt,
                                            self.adaption_uprate, self.adaption_downrate,
                                            _MODES[self.mode], self.rng.seed,
-                                           self.rng.next_offset(),
+                                           self.rng.offset,
                                            chain_offset=self._chain_offset())
+            self._take_positions(n)             # taken once the launch is in
         else:
             _native.hmc_sample_n_gauss(q0, p0.contiguous(), u.contiguous(), q_out,
                                        samples, accepted, self.n_accepted, eb, ea,
@@ -359,6 +361,14 @@ class HMCSampler(object):
     def _chain_offset(self):
         return int(getattr(self.rng, 'chain_offset', 0))
 
+    def _take_positions(self, n):
+        """Reserve the lane streams' positions of ``n`` transitions -- one per
+        ``sample()`` call, whatever the call shape: ``sample_n(n)`` draws what n
+        ``sample()`` calls draw.  Returns the first."""
+        first = self.rng.offset
+        self.rng.offset += int(n)
+        return first
+
     def _sample_long_fused_rng(self, name, q0, shape):
         """sample() for chains beyond the persistent kernel's reach with the
         draws generated in the kernels (csrc/hmc_gauss_big.hip)."""
@@ -381,8 +391,9 @@ class HMCSampler(object):
                                          self._timestep, self._dt_chain, self.nsteps, k, x0,
                                          adapt, self.adaption_uprate, self.adaption_downrate,
                                          _MODES[self.mode], self.rng.seed,
-                                         self.rng.next_offset(),
+                                         self.rng.offset,
                                          chain_offset=self._chain_offset())
+        self._take_positions(1)
         self.last_e_before, self.last_e_after = eb, ea
         self._last_move_accepted = accepted.view(torch.bool)
         self.counter += 1
@@ -416,11 +427,10 @@ class HMCSampler(object):
         args = (self._timestep, self._dt_chain, self.nsteps)
         tail = (k, x0, n_adapt, self.adaption_uprate, self.adaption_downrate, _MODES[self.mode])
         if p0 is None and u is None and self._fused_rng(self._variable_name, D, spec):
-            off = self.rng.offset
-            self.rng.offset += n                    # n sample() calls take n stream positions
             _native.hmc_sample_n_gauss_big(q0, None, None, q_out, samples, accepted, self.n_accepted,
                                            eb, ea, *args, n, thin, *tail,
-                                           rng=(self.rng.seed, off, self._chain_offset()))
+                                           rng=(self.rng.seed, self.rng.offset, self._chain_offset()))
+            self._take_positions(n)                 # n sample() calls take n stream positions
         elif p0 is not None and u is not None:
             _native.hmc_sample_n_gauss_big(q0, p0.reshape(n, C, D).contiguous(),
                                            u.reshape(n, C).contiguous(), q_out, samples, accepted,
@@ -578,7 +588,18 @@ class HMCSampler(object):
             dt, dtc = 0.0, timestep.reshape(-1).contiguous()
         else:
             dt, dtc = float(timestep), None
-        grad = lambda x: _as2d(pdf.gradient(**{name: x.view(shape)})).contiguous()
+        def grad(x):
+            g = pdf.gradient(**{name: x.view(shape)})
+            if not isinstance(g, torch.Tensor) or g.numel() != x.numel():
+                # e.g. a posterior none of whose components is differentiable in `name`:
+                # the reference's zero vector has one entry per DIFFERENTIABLE element
+                # (posteriors.py:177-180) -- none -- and its `p -= ... * gradient(q)`
+                # (hmc.py:116) fails to broadcast; the same error here
+                raise ValueError('pdf.gradient(%s=...) returned %s for a state of shape %s '
+                                 '(is the variable differentiable in any component?)'
+                                 % (name, tuple(getattr(g, 'shape', ())) or type(g).__name__,
+                                    tuple(shape)))
+            return _as2d(g).contiguous()
 
         leap = getattr(pdf, 'native_leapfrog_spec', None)
         leap = leap(name) if (leap is not None and self.fused_leapfrog) else None

@@ -58,9 +58,9 @@ class DeviceRNG(object):
       draws whatever the batch size.
 
     ``fused=False`` uses the Philox kernels for everything; ``fused='always'``
-    generates in the sampling kernel whenever the shape is covered.  One
-    ``sample_n(n)`` launch takes ONE stream position where n ``sample()`` calls
-    take n: the two loops see different (equally valid) draws.
+    generates in the sampling kernel whenever the shape is covered.  Every
+    transition takes one stream position, so ``sample_n(n)`` draws exactly what n
+    ``sample()`` calls draw (persistent kernel and long-chain path alike).
     """
 
     def __init__(self, seed=0, device='cuda', normal='ziggurat', fused=True, chain_offset=0):

@@ -41,8 +41,12 @@ extern "C" {
  *    binf_pairdist_gauss_grad_packed_f64, binf_pairdist_leapfrog_packed_f64,
  *    binf_pairdist_hmc_energy_f64, binf_rng_normal_zig_uniform_f64; the chi^2
  *    memos of binf_poly_gauss_logp_memo_f64 / binf_pairdist_gauss_logp_memo_f64 hold two
- *    entries per chain (their buffers are twice the ABI 3 size). */
-#define BINF_ABI_VERSION 4
+ *    entries per chain (their buffers are twice the ABI 3 size).
+ * 5: binf_sum_terms_bcast_f64 (terms that are ONE device double, broadcast: a 0-dim
+ *    tensor never has to be read back to the host); binf_hmc_sample_n_gauss_rng_f64 /
+ *    binf_hmc_gauss_rng_draws_f64 take one stream position per TRANSITION (offset + i),
+ *    as the long-chain entry points always did. */
+#define BINF_ABI_VERSION 5
 
 #define BINF_E_ARG        (-1)  /* null pointer / negative size / bad flag    */
 #define BINF_E_UNSUPPORTED (-2) /* shape outside what the kernels cover       */
@@ -245,8 +249,11 @@ int32_t binf_hmc_gauss_big_rng_draws_f64(double *p0_out, double *u_out, int64_t 
  * deterministic in (seed, offset, global chain, D), independent of the launch
  * geometry, of the batch size C and of how a run is sharded over GPUs (a rank that
  * owns chains [s, s + C) passes chain_offset = s); NOT numpy's MT19937 stream
- * (parity runs inject host draws through binf_hmc_sample_n_gauss_f64).  A caller
- * advances `offset` by one per launch.
+ * (parity runs inject host draws through binf_hmc_sample_n_gauss_f64).  Transition
+ * i of a launch draws from stream position offset + i -- what a single-transition
+ * launch at that position draws, so n transitions in one launch equal n launches of
+ * one (ABI 5; before, a launch ran on from ONE position) -- and a caller advances
+ * `offset` by n per launch.
  * Arguments as binf_hmc_sample_n_gauss_f64 without p0 / u.
  * Supported: the shapes of binf_hmc_sample_n_gauss_f64 (D <= 8192, pairwise
  * tree height <= 6); otherwise BINF_E_UNSUPPORTED (use the stand-alone
@@ -513,6 +520,15 @@ int32_t binf_jacobian_contract_f64(const double *jacobian, const double *emgrad,
  * is a Python float).  out may be one of the terms. */
 int32_t binf_sum_terms_f64(const double *const *terms, const double *scalars,
                            int32_t n_terms, double *out, int64_t n, void *stream);
+
+/* The same sum with a third kind of term: broadcast[t] != 0 (HOST array of n_terms
+ * flags, or null = none) marks terms[t] as a pointer to ONE device double used for
+ * every element -- a component whose log-prob is a 0-dim device tensor (e.g. the
+ * GammaPrior of a precision shared by all chains) enters the sum without a device ->
+ * host read-back.  A broadcast term must not lie inside out (BINF_E_ALIAS). */
+int32_t binf_sum_terms_bcast_f64(const double *const *terms, const double *scalars,
+                                 const uint8_t *broadcast, int32_t n_terms, double *out,
+                                 int64_t n, void *stream);
 
 /* ------------------------------------------------------------------------
  * n sweeps of the example's Gibbs loop in ONE launch:

@@ -29,15 +29,21 @@
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 
-template <int NCH, int NOP, int VF>
+// KIND of the VF filler instructions after every MFMA: 0 v_fma_f64, 1 v_fma_f32, 2 v_mov_b32,
+// 3 v_add_u32, 4 v_cndmask_b32, 5 ds_read_b64 (LDS), 6 v_add_f64, 7 v_mul_f64
+template <int NCH, int NOP, int VF, int KIND = 0>
 __global__ void __launch_bounds__(256)
 duty_kernel(double *out, unsigned long long *stamps, const double *ops, int iters)
 {
     extern __shared__ double pin[];            // only to bound the workgroups per CU
     v4d acc[NCH];
     double a[8], b[8];
-    double f[VF > 0 ? VF : 1];
+    constexpr int VFN = VF > 0 ? VF : 1;
+    double f[VFN];
+    float g32[VFN];
+    unsigned i32[VFN];
     const int tid = threadIdx.x;
+    const unsigned ldsaddr = (unsigned)(tid * 8);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         a[j] = ops[(j * 2 + 0) * 256 + tid];
@@ -46,8 +52,13 @@ duty_kernel(double *out, unsigned long long *stamps, const double *ops, int iter
 #pragma unroll
     for (int c = 0; c < NCH; ++c) acc[c] = (v4d){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int v = 0; v < (VF > 0 ? VF : 1); ++v) f[v] = a[v & 7];
-    if (tid == 1 << 20) pin[0] = 0.0;          // keeps the LDS request alive
+    for (int v = 0; v < VFN; ++v) {
+        f[v] = a[v & 7];
+        g32[v] = (float)b[v & 7];
+        i32[v] = (unsigned)tid + v;
+    }
+    pin[tid] = a[0];                           // keeps the LDS request alive (and readable)
+    __syncthreads();
 
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
     const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
@@ -60,10 +71,27 @@ duty_kernel(double *out, unsigned long long *stamps, const double *ops, int iter
                 acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[j], b[j], acc[c], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int n = 0; n < NOP; ++n) asm volatile("s_nop 7");
+                for (int n = 0; n < NOP; ++n) asm volatile("s_nop 1");      // 8 cycles each
 #pragma unroll
-                for (int v = 0; v < VF; ++v)
-                    asm volatile("v_fma_f64 %0, %1, %2, %0" : "+v"(f[v]) : "v"(a[j]), "v"(b[(j + v) & 7]));
+                for (int v = 0; v < VF; ++v) {
+                    if (KIND == 0)
+                        asm volatile("v_fma_f64 %0, %1, %2, %0" : "+v"(f[v]) : "v"(a[j]), "v"(b[(j + v) & 7]));
+                    else if (KIND == 6)
+                        asm volatile("v_add_f64 %0, %1, %0" : "+v"(f[v]) : "v"(a[j]));
+                    else if (KIND == 7)
+                        asm volatile("v_mul_f64 %0, %1, %0" : "+v"(f[v]) : "v"(b[(j + v) & 7]));
+                    else if (KIND == 1)
+                        asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(g32[v]) : "v"(g32[(v + 1) % VFN]), "v"(g32[(v + 2) % VFN]));
+                    else if (KIND == 2)
+                        asm volatile("v_mov_b32 %0, %1" : "=v"(g32[v]) : "v"(g32[(v + 1) % VFN]));
+                    else if (KIND == 3)
+                        asm volatile("v_add_u32 %0, %1, %0" : "+v"(i32[v]) : "v"(i32[(v + 1) % VFN]));
+                    else if (KIND == 4)
+                        asm volatile("v_cndmask_b32 %0, %1, %2, vcc" : "=v"(i32[v]) : "v"(i32[(v + 1) % VFN]), "v"(i32[(v + 2) % VFN]) : );
+                    else if (KIND == 5)
+                        asm volatile("ds_read_b64 %0, %1" : "=v"(f[v]) : "v"(ldsaddr));
+                }
+                if (KIND == 5 && VF > 0) asm volatile("s_waitcnt lgkmcnt(0)");
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -76,7 +104,7 @@ duty_kernel(double *out, unsigned long long *stamps, const double *ops, int iter
 #pragma unroll
     for (int c = 0; c < NCH; ++c) s += acc[c][0] + acc[c][1] + acc[c][2] + acc[c][3];
 #pragma unroll
-    for (int v = 0; v < VF; ++v) s += f[v];
+    for (int v = 0; v < VF; ++v) s += f[v] + (double)g32[v] + (double)i32[v];
     out[(size_t)blockIdx.x * 256 + tid] = s;
     if (tid == 0) {                            // stamps go to a buffer nothing else reads
         stamps[(size_t)blockIdx.x * 2 + 0] = t1 - t0;
@@ -90,7 +118,10 @@ static double median(std::vector<double> v)
     return v.empty() ? 0.0 : v[v.size() / 2];
 }
 
-template <int NCH, int NOP, int VF>
+static const char *KIND_NAME[] = {"v_fma_f64", "v_fma_f32", "v_mov_b32", "v_add_u32", "v_cndmask_b32",
+                                  "ds_read_b64", "v_add_f64", "v_mul_f64"};
+
+template <int NCH, int NOP, int VF, int KIND = 0>
 static void run(int wps, const char *data, const double *ops_dev, double settle_s)
 {
     const int blocks = 256 * wps;              // one workgroup (4 waves) per CU and wave slot
@@ -100,7 +131,7 @@ static void run(int wps, const char *data, const double *ops_dev, double settle_
     unsigned long long *stamps;
     (void)hipMalloc(&out, sizeof(double) * blocks * 256);
     (void)hipMalloc(&stamps, sizeof(unsigned long long) * blocks * 2);
-    auto kern = duty_kernel<NCH, NOP, VF>;
+    auto kern = duty_kernel<NCH, NOP, VF, KIND>;
     (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     // ~4 ms per launch at full duty: iters x 8 x NCH MFMAs x 64 cycles x wps at ~2 GHz
     const int iters = std::max(64, (int)(4e-3 * 2.0e9 / (8.0 * NCH * 64.0 * wps)));
@@ -133,12 +164,14 @@ static void run(int wps, const char *data, const double *ops_dev, double settle_
     const double t = ms * 1e-3 / reps;
     const double mfma_wave = (double)iters * 8 * NCH;
     const double tf = mfma_wave * 2048.0 * 4.0 * blocks / t * 1e-12;
-    const double cyc_per_mfma_simd = median(cyc) / (mfma_wave * wps);            // matrix-pipe period
+    // matrix-pipe period of a SIMD: wall time x in-kernel clock / MFMAs per SIMD
+    const double cyc_per_mfma_simd = t * median(clk) * 1e9 / (mfma_wave * blocks * 4.0 / 1024.0);
+    const double wave_cyc_per_mfma = median(cyc) / mfma_wave;   // what one wave saw (its own stamps)
     printf("{\"data\": \"%s\", \"chains_per_wave\": %d, \"waves_per_simd\": %d, \"nop8_per_mfma\": %d, "
-           "\"vfma_per_mfma\": %d, \"launch_us\": %.1f, \"TFLOPs\": %.2f, \"frac_of_78.6\": %.3f, "
+           "\"filler\": \"%s\", \"wave_cycles_per_mfma\": %.1f, \"fillers_per_mfma\": %d, \"launch_us\": %.1f, \"TFLOPs\": %.2f, \"frac_of_78.6\": %.3f, "
            "\"clock_GHz_in_kernel\": %.3f, \"cycles_per_mfma_per_simd\": %.1f, \"matrix_pipe_duty\": %.3f, "
            "\"TFLOPs_at_2.4GHz_same_cycles\": %.2f, \"settle_launches\": %d, \"iters\": %d, \"hip_error\": %d}\n",
-           data, NCH, wps, NOP, VF, t * 1e6, tf, tf / 78.6, median(clk), cyc_per_mfma_simd,
+           data, NCH, wps, NOP, KIND_NAME[KIND], wave_cyc_per_mfma, VF, t * 1e6, tf, tf / 78.6, median(clk), cyc_per_mfma_simd,
            64.0 / cyc_per_mfma_simd, 78.6 * 64.0 / cyc_per_mfma_simd, settled, iters, (int)err);
     fflush(stdout);
     (void)hipFree(out);
@@ -164,30 +197,29 @@ int main(int argc, char **argv)
 
     // bare loops: chains per wave and waves per SIMD, random data
     run<1, 0, 0>(1, "random", d_rnd, settle);
-    run<2, 0, 0>(1, "random", d_rnd, settle);
     run<4, 0, 0>(1, "random", d_rnd, settle);
     run<4, 0, 0>(2, "random", d_rnd, settle);
     run<4, 0, 0>(3, "random", d_rnd, settle);
-    // the same on zeros: the clock the chip holds when the data cost nothing
-    run<4, 0, 0>(1, "zero", d_zero, settle);
-    run<4, 0, 0>(3, "zero", d_zero, settle);
-    // duty sweep, one wave per SIMD (the pad is idle time of the matrix pipe once it
-    // exceeds the 64 cycles the MFMA holds it)
+    run<4, 0, 0>(4, "random", d_rnd, settle);
+    run<4, 0, 0>(2, "zero", d_zero, settle);
+    // idle pads (8 cycles each): where does the matrix pipe start to starve?
+    run<4, 4, 0>(1, "random", d_rnd, settle);
+    run<4, 6, 0>(1, "random", d_rnd, settle);
     run<4, 7, 0>(1, "random", d_rnd, settle);
     run<4, 8, 0>(1, "random", d_rnd, settle);
-    run<4, 9, 0>(1, "random", d_rnd, settle);
     run<4, 10, 0>(1, "random", d_rnd, settle);
-    run<4, 11, 0>(1, "random", d_rnd, settle);
-    run<4, 12, 0>(1, "random", d_rnd, settle);
-    run<4, 14, 0>(1, "random", d_rnd, settle);
-    run<4, 16, 0>(1, "random", d_rnd, settle);
-    // pads of FP64 VALU work instead of idle cycles (what a real kernel puts beside its MFMAs;
-    // the gradient kernel issues ~4.2 VALU instructions per MFMA)
-    run<4, 0, 4>(1, "random", d_rnd, settle);
-    run<4, 0, 8>(1, "random", d_rnd, settle);
-    run<4, 0, 4>(3, "random", d_rnd, settle);
-    run<4, 0, 12>(1, "random", d_rnd, settle);
-    run<4, 0, 16>(1, "random", d_rnd, settle);
-    run<4, 4, 8>(1, "random", d_rnd, settle);
+    // what does ONE filler instruction beside an FP64 MFMA cost, by kind?  4 and 8 per MFMA,
+    // one and three waves per SIMD
+#define KINDS(W)                                                                         \
+    run<4, 0, 4, 0>(W, "random", d_rnd, settle); run<4, 0, 8, 0>(W, "random", d_rnd, settle); \
+    run<4, 0, 4, 6>(W, "random", d_rnd, settle); run<4, 0, 8, 6>(W, "random", d_rnd, settle); \
+    run<4, 0, 4, 7>(W, "random", d_rnd, settle); run<4, 0, 8, 7>(W, "random", d_rnd, settle); \
+    run<4, 0, 4, 1>(W, "random", d_rnd, settle); run<4, 0, 8, 1>(W, "random", d_rnd, settle); \
+    run<4, 0, 4, 2>(W, "random", d_rnd, settle); run<4, 0, 8, 2>(W, "random", d_rnd, settle); \
+    run<4, 0, 4, 3>(W, "random", d_rnd, settle); run<4, 0, 8, 3>(W, "random", d_rnd, settle); \
+    run<4, 0, 4, 4>(W, "random", d_rnd, settle); run<4, 0, 8, 4>(W, "random", d_rnd, settle); \
+    run<4, 0, 2, 5>(W, "random", d_rnd, settle); run<4, 0, 4, 5>(W, "random", d_rnd, settle);
+    KINDS(1)
+    KINDS(3)
     return 0;
 }

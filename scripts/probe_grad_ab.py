@@ -8,7 +8,10 @@ from binf_amd import _native
 from binf_amd.example.likelihood import POLYVAL, ForwardModel
 dev = torch.device('cuda:0')
 out = {}
-for C, K, N in ((8192, 33, 16384), (4096, 33, 16384), (130, 33, 1000), (2100, 17, 50), (64, 4, 20), (300, 64, 700)):
+for C, K, N in ((8192, 33, 16384), (4096, 33, 16384), (130, 33, 1000), (2100, 17, 50), (64, 4, 20), (300, 64, 700),
+                # whole tiles (N % 16 == 0): the trimmed kernel unless BINF_POLY_GRAD_GENERAL=1
+                (130, 33, 1024), (2100, 17, 64), (64, 4, 32), (300, 64, 704), (300, 48, 1600), (1500, 50, 320),
+                (8192, 16, 4096), (2050, 34, 16), (5, 36, 48), (8192, 32, 16384), (1024, 33, 16384)):
     xs = np.linspace(-1, 1, N)
     ys = np.random.RandomState(9).standard_normal(N)
     q0 = torch.from_numpy(np.random.RandomState(8).standard_normal((C, K))).to(dev)

@@ -185,3 +185,98 @@ def test_user_forward_model_full_sample_on_the_per_step_tier(device):
         assert np.all(np.abs(out[c] - want['q_out'][c]) <= b['bq'] + 4 * PB.U * np.abs(want['q_out'][c])), c
         assert abs(eb[c] - want['e_before'][c]) <= b['be_before'], c
         assert abs(ea[c] - want['e_after'][c]) <= b['be_after'], c
+
+
+# ---------------------------------------------------------------------------
+# round 4: the Posterior's sums and zero force on the product path, no torch arithmetic
+# ---------------------------------------------------------------------------
+def test_posterior_sum_chunks_beyond_16_terms_and_broadcasts_device_scalars(device):
+    """_sum_in_order: more than 16 terms go through several launches of the term-sum kernel
+    with the running sum carried over (the same left-to-right order, bit for bit); a 0-dim
+    device tensor is a broadcast device scalar (never read back to the host); Python floats
+    ride along.  What the kernel cannot take is refused, not added with torch."""
+    from binf_amd.pdf.posteriors import _sum_in_order
+    rs = np.random.RandomState(4)
+    C = 777
+    vecs = [rs.standard_normal(C) * 10.0 ** rs.randint(-6, 6) for _ in range(37)]
+    terms, want = [], None
+    for i, v in enumerate(vecs):
+        if i % 9 == 4:
+            t, w = float(v[0]), float(v[0])                    # a Python float
+        elif i % 9 == 7:
+            t, w = dev_t(np.array(v[1]), device), v[1]         # a 0-dim device tensor
+            assert t.dim() == 0
+        else:
+            t, w = dev_t(v, device), v
+        terms.append(t)
+        want = w if want is None else want + w
+    got = _sum_in_order(terms)
+    assert got.shape == (C,) and np.array_equal(got.cpu().numpy(), want)
+    # exactly 16 and 17 terms (one launch / two)
+    for T in (16, 17, 31, 32):
+        g = _sum_in_order([dev_t(v, device) for v in vecs[:T]]).cpu().numpy()
+        w = vecs[0]
+        for v in vecs[1:T]:
+            w = w + v
+        assert np.array_equal(g, w), T
+    # only device scalars and floats: a 0-dim device tensor comes back
+    s = _sum_in_order([dev_t(np.array(1.5), device), 2.25, dev_t(np.array(-0.125), device)])
+    assert s.dim() == 0 and s.is_cuda and float(s) == (1.5 + 2.25) + -0.125
+    # [C x D] gradients
+    a, b, c = (rs.standard_normal((5, 7)) for _ in range(3))
+    assert np.array_equal(_sum_in_order([dev_t(a, device), dev_t(b, device), dev_t(c, device)]).cpu().numpy(),
+                          (a + b) + c)
+    # refused: mixed shapes, non-contiguous, host tensors, other dtypes
+    with pytest.raises(ValueError):
+        _sum_in_order([dev_t(a, device), dev_t(a[:3], device)])
+    with pytest.raises(ValueError):
+        _sum_in_order([dev_t(a, device), dev_t(np.zeros((7, 5)), device).t()])
+    with pytest.raises(TypeError):
+        _sum_in_order([dev_t(a, device), torch.zeros((5, 7), dtype=torch.float64)])
+    with pytest.raises(TypeError):
+        _sum_in_order([dev_t(a, device), torch.zeros((5, 7), dtype=torch.float32, device=device)])
+    # the reference's own unit-test values (plain floats / numpy) still add on the host
+    assert _sum_in_order([1.0, 2.0, 3.5]) == 6.5
+    assert np.array_equal(_sum_in_order([np.ones(3), np.arange(3.0)]), np.ones(3) + np.arange(3.0))
+
+
+def test_broadcast_term_inside_the_output_is_refused(device):
+    v = dev_t(np.arange(8.0), device)
+    terms = [v, v[3]]                                  # v[3] is a 0-dim view INTO v
+    out = _native.sum_terms(terms).cpu().numpy()       # separate output: fine
+    assert np.array_equal(out, np.arange(8.0) + 3.0)
+    import ctypes
+    ptrs = (ctypes.c_void_p * 2)(v.data_ptr(), v[3].data_ptr())
+    flags = (ctypes.c_uint8 * 2)(0, 1)
+    rc = _native.lib().binf_sum_terms_bcast_f64(ptrs, None, flags, 2, v.data_ptr(), 8,
+                                                _native.stream_handle(device))
+    assert rc == _native.E_ALIAS
+
+
+def test_posterior_without_a_differentiable_component_has_the_references_empty_force(device):
+    """binf/pdf/posteriors.py:177-180: the zero vector has one entry per element of the
+    DIFFERENTIABLE variables passed.  The example's GaussianPrior registers `coefficients` as
+    non-differentiable (quirk Q4), so a posterior made of priors only has none: the reference
+    returns numpy.zeros(0), and its HMCSampler._leapfrog then fails to broadcast it
+    (`p -= 0.5 * timestep * gradient(q)`, hmc.py:116: ValueError).  Batched: [C x 0] on the
+    device and the same ValueError -- not a length-C host vector."""
+    K, C = 5, 12
+    post = Posterior({}, {'coefficients_prior': GaussianPrior(np.zeros(K), np.ones(K) * 2.0)})
+    assert post.variables == {'coefficients'} and post.differentiable_variables == set()
+    q = dev_t(np.random.RandomState(0).standard_normal((C, K)), device)
+    g = post.gradient(coefficients=q)
+    assert isinstance(g, torch.Tensor) and g.is_cuda and tuple(g.shape) == (C, 0)
+    assert tuple(post.gradient(coefficients=q[0]).shape) == (0,)
+    lp = post.log_prob(coefficients=q)                      # ... while the energy has the prior
+    assert np.allclose(lp.cpu().numpy(), -0.5 * np.sum(q.cpu().numpy() ** 2 / 2.0, axis=1), rtol=1e-13)
+    s = HMCSampler(post, q, 0.1, 3, variable_name='coefficients')
+    with pytest.raises(ValueError, match='differentiable'):
+        s.sample(p0=torch.zeros_like(q), u=torch.zeros(C, dtype=torch.float64, device=device))
+    with pytest.raises(ValueError, match='differentiable'):
+        s._leapfrog(q.clone(), torch.ones_like(q), 0.1, 3)
+    # the helper's other branch: differentiable variables passed but nothing to add (reachable
+    # only through a subclass): zeros of the gradient's shape, on the device
+    from binf_amd.pdf.posteriors import _zero_force
+    z = _zero_force([q, q[:, :2]])
+    assert z.is_cuda and tuple(z.shape) == (C, K + 2) and float(z.abs().sum()) == 0.0
+    assert tuple(_zero_force([q]).shape) == (C, K)

@@ -810,3 +810,49 @@ def test_long_chains_sample_n_draws_what_n_sample_calls_draw(device, fused):
     assert torch.equal(a.state, xs[-1]) and a.rng.offset == b.rng.offset
     assert torch.equal(a.last_e_after[-1], b.last_e_after)
     assert bool(a.accepted_history.any())
+
+
+@pytest.mark.parametrize('C,D,L', [(64, 1024, 5), (4096, 1024, 3), (700, 1024, 4), (3, 9000, 2), (40, 300, 6)])
+def test_sample_n_draws_what_n_sample_calls_draw(device, C, D, L):
+    """A seed identifies the chains whatever the call shape: with a DeviceRNG whose draws are
+    the lane streams of the fused kernels, transition i of sample_n(n) takes the stream
+    position the i-th sample() call would take -- on the persistent kernel (in-kernel draws
+    for large batches, the same draws written out first for small ones) and on the long-chain
+    path (D = 9000) alike.  States, flags and energies equal bit for bit, and the generator
+    ends at the same position."""
+    n = 5
+    rs = np.random.RandomState(C + D)
+    q0 = rs.standard_normal((C, D))
+    runs = []
+    for shape in ('single', 'n', 'mixed'):
+        rng = DeviceRNG(17, device)
+        s = HMCSampler(IsotropicGaussian(1.0, 0.0), dev_t(q0, device), 0.15, L, variable_name='x',
+                       rng=rng, record_energies=True)
+        states, flags, ea = [], [], []
+
+        def one():
+            states.append(s.sample().clone())
+            flags.append(s.last_move_accepted.clone())
+            ea.append(s.last_e_after.reshape(-1).clone())
+
+        def many(m):
+            rec = s.sample_n(m)
+            states.extend(rec[i].clone() for i in range(m))
+            flags.extend(s.accepted_history[i].clone() for i in range(m))
+            ea.extend(s.last_e_after.reshape(m, -1)[i].clone() for i in range(m))
+        if shape == 'single':
+            for _ in range(n):
+                one()
+        elif shape == 'n':
+            many(n)
+        else:
+            one()
+            many(3)
+            one()
+        runs.append((torch.stack(states), torch.stack(flags), torch.stack(ea), rng.offset))
+    for other in runs[1:]:
+        assert torch.equal(runs[0][0], other[0])
+        assert torch.equal(runs[0][1], other[1])
+        assert torch.equal(runs[0][2], other[2])
+        assert runs[0][3] == other[3] == n
+    assert not torch.equal(runs[0][0][0], runs[0][0][1])

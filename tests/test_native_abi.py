@@ -32,6 +32,121 @@ def test_every_declared_symbol_is_exported_and_bound():
     assert sorted(_native.SIGNATURES) == names
 
 
+def header_prototypes():
+    """{name: (return C type, [argument C types])} parsed from include/binf_hip.h: comments
+    stripped, every `type name(args);` at file scope; an argument's type is everything but
+    its (optional) name, normalised (`const double *const *` -> 'const double*const*')."""
+    text = open(os.path.join(ROOT, 'include', 'binf_hip.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    text = re.sub(r'^\s*#.*$', '', text, flags=re.M)
+    protos = {}
+    for m in re.finditer(r'([A-Za-z_][A-Za-z0-9_ \*]*?)\b(binf_[a-z0-9_]+)\s*\(([^;{}]*?)\)\s*;', text, flags=re.S):
+        ret, name, args = m.group(1), m.group(2), m.group(3)
+
+        def norm(t):
+            return re.sub(r'\s+', ' ', t.replace('*', ' * ')).strip().replace(' *', '*').replace('* ', '*')
+        arg_types = []
+        args = args.strip()
+        if args and args != 'void':
+            for a in args.split(','):
+                a = a.strip()
+                arr = re.match(r'^(.*?)([A-Za-z_][A-Za-z0-9_]*)\s*\[\s*\d*\s*\]$', a, flags=re.S)
+                if arr:                                  # `const uint32_t counter[4]` is a pointer
+                    arg_types.append(norm(arr.group(1) + '*'))
+                    continue
+                # drop the parameter name (last identifier, unless the declarator is a bare type)
+                mm = re.match(r'^(.*?[\*\s])([A-Za-z_][A-Za-z0-9_]*)$', a, flags=re.S)
+                base = mm.group(1) if mm and mm.group(2) not in ('int', 'double', 'void', 'char') else a
+                arg_types.append(norm(base))
+        protos[name] = (norm(ret.replace('extern', '').replace('"C"', '')), arg_types)
+    return protos
+
+
+# what each C type must be bound as in binf_amd/_native.py: SIGNATURES
+def _ctype_of(c):
+    if c.endswith('*'):
+        return 'pointer'
+    return {'int32_t': ctypes.c_int32, 'int64_t': ctypes.c_int64, 'uint64_t': ctypes.c_uint64,
+            'uint32_t': ctypes.c_uint32, 'double': ctypes.c_double, 'size_t': ctypes.c_size_t,
+            'int': ctypes.c_int}[c]
+
+
+def _is_pointer_binding(t):
+    return t is ctypes.c_void_p or t is ctypes.c_char_p or (isinstance(t, type) and
+                                                            issubclass(t, ctypes._Pointer))
+
+
+def test_ctypes_signatures_match_the_header_prototypes():
+    """Arity and C type of every argument (and the return type) of every entry in
+    _native.SIGNATURES against the prototype in include/binf_hip.h -- the table is
+    written by hand and a call through a wrong one corrupts arguments silently (an int64
+    passed as int32, a double in an integer register)."""
+    protos = header_prototypes()
+    assert sorted(protos) == sorted(_native.SIGNATURES)
+    assert len(protos) >= 59
+    for name, (ret, args) in sorted(protos.items()):
+        res, bound = _native.SIGNATURES[name]
+        assert res is _ctype_of(ret), '%s: returns %s, bound as %s' % (name, ret, res)
+        assert len(bound) == len(args), '%s: %d arguments in the header, %d bound' % (
+            name, len(args), len(bound))
+        for i, (c, b) in enumerate(zip(args, bound)):
+            want = _ctype_of(c)
+            if want == 'pointer':
+                assert _is_pointer_binding(b), '%s arg %d: %s bound as %s' % (name, i, c, b)
+            else:
+                assert b is want, '%s arg %d: %s bound as %s' % (name, i, c, b)
+    # the parser itself: a prototype it must read exactly
+    assert protos['binf_sum_terms_bcast_f64'] == ('int32_t', [
+        'const double*const*', 'const double*', 'const uint8_t*', 'int32_t', 'double*', 'int64_t', 'void*'])
+    assert protos['binf_abi_version'] == ('int32_t', [])
+
+
+def test_memo_entry_points_refuse_before_touching_the_memo():
+    """A shape the reduction would refuse is refused BEFORE the memo's check kernel runs
+    (it rewrites the stored arguments of a missed row; their chi^2 is stored by the
+    reduction after it -- a refusal in between would leave a matching entry with a stale
+    sum, a silent wrong hit on the next call).  No launch, no dereference: host checks."""
+    L = _native.lib()
+    fake = [i << 40 for i in range(1, 10)]
+    big = (1 << 31) + 5
+    rc = L.binf_poly_gauss_logp_memo_f64(fake[0], fake[1], fake[2], 1.0, None, fake[3], fake[4],
+                                         fake[5], fake[6], big, 4, 20, None)
+    assert rc == _native.E_UNSUPPORTED and 'too large' in _native.last_error()
+    rc = L.binf_pairdist_gauss_logp_memo_f64(fake[0], fake[1], fake[2], fake[3], 1.0, None, fake[4],
+                                             fake[5], fake[6], fake[7], big, 4, 6, None)
+    assert rc == _native.E_UNSUPPORTED and 'too large' in _native.last_error()
+
+
+def test_alias_refusals_without_gpu():
+    """Partial overlaps the kernels cannot survive are refused on the host (BINF_E_ALIAS)."""
+    L = _native.lib()
+    base = 1 << 40
+    C, D, n = 4, 9000, 3
+    CD = C * D * 8
+    q0, p0, u, q_out, samples = base, base + 10 * CD, base + 20 * CD, base + 30 * CD, base + 40 * CD
+    acc, ws = base + 60 * CD, base + 70 * CD
+    need = L.binf_hmc_sample_n_gauss_big_workspace_bytes(C, D)
+
+    def call(samples_, q_out_=q_out, p0_=p0):
+        return L.binf_hmc_sample_n_gauss_big_f64(q0, p0_, u, q_out_, samples_, acc, None, None, None, 0.1,
+                                                 None, C, D, 2, n, 1, 1.0, 0.0, 0, 1.05, 0.95, 0, ws,
+                                                 need, None)
+    for bad in (q0 + 8, q_out - CD + 8, p0 + 2 * CD, ws + 16):        # samples against q0 / q_out / p0 / workspace
+        assert call(bad) == _native.E_ALIAS, hex(bad)
+    assert call(samples, q_out_=p0 + 2 * CD + 8) == _native.E_ALIAS     # q_out inside a later momentum block
+    # the pair-distance leapfrog's start buffer
+    nb = 10
+    q, p, qf, ymat = base, base + (1 << 30), base + (2 << 30), base + (3 << 30)
+    args = lambda qf_, p_=p: (q, qf_, p_, ymat, None, 1.0, None, 0, 0.0, 0.0, 0, 0.01, None, 2, C, nb, 0, None)
+    assert L.binf_pairdist_leapfrog_packed_f64(*args(q + 8)) == _native.E_ALIAS
+    assert L.binf_pairdist_leapfrog_packed_f64(*args(p + 8)) == _native.E_ALIAS
+    assert L.binf_pairdist_leapfrog_packed_f64(*args(qf, p_=q + 16)) == _native.E_ALIAS
+    # a broadcast term inside the output of the term sum
+    terms = (ctypes.c_void_p * 2)(base, base + 4096 + 8)
+    flags = (ctypes.c_uint8 * 2)(0, 1)
+    assert L.binf_sum_terms_bcast_f64(terms, None, flags, 2, base + 4096, 16, None) == _native.E_ALIAS
+
+
 def test_error_codes_and_text_without_gpu():
     L = _native.lib()
     rc = L.binf_hmc_sample_gauss_f64(None, None, None, None, None, None, None,
