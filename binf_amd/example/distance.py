@@ -13,9 +13,12 @@ order.
 import numpy as np
 import torch
 
-from binf_amd import ArrayParameter, _native
+from binf_amd import ArrayParameter, _native, native
 from binf_amd.example.likelihood import GaussianErrorModel
 from binf_amd.model.forwardmodels import AbstractForwardModel
+
+
+KIND = 'pairdist'        # the name this module's hooks are registered under
 
 
 class DistanceForwardModel(AbstractForwardModel):
@@ -209,3 +212,122 @@ def native_gradient(likelihood, fwm, em, fwm_vars, em_vars):
     out = _native.pairdist_gauss_grad(x2.contiguous(), em.ymat_device(x.device),
                                       em_vars['precision'], packed=em.ypacked_device(x.device))
     return out if x.dim() == 2 else out.reshape(-1)
+
+
+# ---------------------------------------------------------------------------
+# recognition of the restraint posterior and the hooks of the kind (binf_amd/native.py)
+# ---------------------------------------------------------------------------
+def _posterior_spec(posterior, variable_name, strict):
+    """Recognised: exactly one restraint likelihood (pair-distance forward model +
+    Gaussian error model with the precision fixed) plus at most one isotropic
+    Gaussian prior on the same variable; components without a differentiable
+    variable do not enter the force anyway (quirk Q4).  The result records the
+    order of the two force terms, which is the Posterior's sorted-component-name
+    order.
+
+    ``strict`` (the energy, where EVERY component counts: a component without
+    differentiable variables drops out of the force, not out of ``log_prob``):
+    besides the likelihood and the one prior, up to two components whose variables
+    are ALL fixed (constants of the move, e.g. the GammaPrior of the precision
+    inside a Gibbs sweep) are recorded in place -- the last entry lists ``'prior'`` /
+    ``'lik'`` / such a component in the Posterior's order."""
+    from binf_amd.pdf import IsotropicGaussian
+    from binf_amd.pdf.likelihoods import Likelihood
+    lik = prior = None
+    order = []
+    terms = []          # strict: every component in the Posterior's order
+    for f in posterior._ordered_components():
+        if not (len(f.variables) > 0 and len(f.differentiable_variables) > 0):
+            if strict:
+                # out of the force, not out of log_prob: a component with every variable
+                # fixed is a constant of the move the energy kernel can add in its place
+                if len(f.variables) > 0 or sum(1 for t in terms if not isinstance(t, str)) == 2:
+                    return None
+                terms.append(f)
+            continue
+        if isinstance(f, Likelihood):
+            fs = getattr(f.forward_model, 'native_spec', lambda: None)()
+            es = getattr(f.error_model, 'native_spec', lambda: None)()
+            if lik is not None or fs is None or es is None or \
+                    fs[0] != 'pairdist' or es[0] != 'gaussian_pairdist' or \
+                    f.variables != {variable_name} or \
+                    'precision' not in es[1].parameters:
+                return None
+            lik = f
+            order.append('lik')
+            terms.append('lik')
+        elif isinstance(f, IsotropicGaussian):
+            if prior is not None or f.native_hmc_spec(variable_name) is None:
+                return None
+            prior = f
+            order.append('prior')
+            terms.append('prior')
+        else:
+            return None
+    if lik is None:
+        return None
+    em = lik.error_model
+    params = (em, em['precision'].value,
+              None if prior is None else (float(prior['k'].value), float(prior['x0'].value)),
+              order[0] == 'prior')
+    return params + (lik, terms) if strict else params
+
+
+def match_leapfrog(posterior, variable_name):
+    return _posterior_spec(posterior, variable_name, strict=False)
+
+
+def match_energy(posterior, variable_name):
+    return _posterior_spec(posterior, variable_name, strict=True)
+
+
+def leapfrog(sampler, spec, q2, p2, dt, dtc, nsteps, mode, q_from):
+    """The whole integration in one launch (bit-identical to the per-step loop)."""
+    if q2.shape[1] % 3 != 0 or q2.shape[1] // 3 > 1024:
+        return False
+    _, em, precision, prior, prior_first = spec
+    packed = getattr(em, 'ypacked_device', None)
+    qf = None
+    if q_from is not None:
+        qf = q_from
+        if not (qf.is_contiguous() and qf.shape == q2.shape and qf.dtype == q2.dtype
+                and qf.device == q2.device):
+            q2.copy_(qf)
+            qf = None
+    _native.pairdist_leapfrog(q2, p2, em.ymat_device(q2.device), precision,
+                              prior, prior_first, dt, dtc, nsteps, mode,
+                              packed=packed(q2.device) if packed is not None else None,
+                              q_from=qf)
+    return True
+
+
+def energy(sampler, spec, q0):
+    """``E(x, momentum)`` with the prior row sum, chi^2 (with its memo), term sum and
+    kinetic energy in one launch, or None (a term the kernel cannot take)."""
+    if q0.shape[1] % 3 != 0 or q0.shape[1] // 3 > 2048:
+        return None
+    _, em, precision, prior, prior_first, lik, terms = spec
+    # constants of the move (components with every variable fixed): once per sample()
+    terms = [t if isinstance(t, str) else t.log_prob() for t in terms]
+
+    def kernel_term(t):
+        if isinstance(t, str):
+            return True
+        if isinstance(t, torch.Tensor):
+            return t.dim() == 0 or (t.is_cuda and t.dtype == torch.float64 and
+                                    t.is_contiguous() and t.numel() == q0.shape[0])
+        try:                                # a Python / numpy scalar
+            float(t)
+            return True
+        except (TypeError, ValueError):
+            return False
+    if not all(kernel_term(t) for t in terms):
+        return None
+    return lambda x, mom: native_hmc_energy(lik, x, mom, precision, prior, terms)
+
+
+native.register(
+    KIND, replace=True,
+    match_leapfrog=match_leapfrog, match_energy=match_energy,
+    leapfrog=leapfrog, energy=energy,
+    likelihood={('pairdist', 'gaussian_pairdist'): (native_log_prob, native_gradient)})

@@ -175,3 +175,7 @@ def make_likelihood(xses, ys, polynomial):
     from binf_amd.pdf.likelihoods import Likelihood
     return Likelihood('points', ForwardModel(xses, polynomial),
                       GaussianErrorModel(ys))
+
+
+# the fused kernels of this module's models: importing the models registers their kind
+from binf_amd.example import native_poly as _polynomial_kind  # noqa: E402,F401

@@ -8,7 +8,9 @@ kernels and the ``[C x n_data]`` mock data is never written to HBM
 """
 import torch
 
-from binf_amd import _native
+from binf_amd import _native, native
+
+KIND = 'poly'            # the name this module's hooks are registered under
 
 
 def _usable(coeffs):
@@ -20,8 +22,7 @@ def _as2d(x):
     return x if x.dim() == 2 else x.reshape(1, -1)
 
 
-def log_prob(likelihood, pair, fwm_vars, em_vars):
-    (_, fwm), (_, em) = pair
+def log_prob(likelihood, fwm, em, fwm_vars, em_vars):
     fwm_vars = dict(fwm_vars)
     em_vars = dict(em_vars)
     fwm._complete_variables(fwm_vars)
@@ -53,8 +54,7 @@ def _chi2_memo(xs, ys, shape):
     return memo.chi2_memo(ys, xs, shape, xs.device, _native.new_chi2_memo)
 
 
-def gradient(likelihood, pair, fwm_vars, em_vars):
-    (_, fwm), (_, em) = pair
+def gradient(likelihood, fwm, em, fwm_vars, em_vars):
     fwm_vars = dict(fwm_vars)
     em_vars = dict(em_vars)
     fwm._complete_variables(fwm_vars)
@@ -67,6 +67,13 @@ def gradient(likelihood, pair, fwm_vars, em_vars):
     out = _native.poly_gauss_grad(c2, fwm.design_matrix(c2.shape[1], dev),
                                   em.ys_device(dev), em_vars['precision'])
     return out if coeffs.dim() == 2 else out.reshape(-1)
+
+
+def _is_poly_pair(likelihood):
+    """Polynomial forward model + Gaussian error model, neither overridden?"""
+    fs = getattr(likelihood.forward_model, 'native_spec', lambda: None)()
+    es = getattr(likelihood.error_model, 'native_spec', lambda: None)()
+    return fs is not None and es is not None and fs[0] == 'polynomial' and es[0] == 'gaussian'
 
 
 FUSED_MAX_COEFFS = 16       # binf_hmc_sample_poly_f64 limits (include/binf_hip.h)
@@ -95,7 +102,7 @@ def posterior_hmc_spec(posterior, variable_name):
             kinds.append('c')
             consts.append(f)
         elif set(f.variables) == {variable_name} and isinstance(f, Likelihood) \
-                and lik is None and f._native_pair() is not None \
+                and lik is None and _is_poly_pair(f) \
                 and 'precision' in f.error_model.parameters:
             lik = f
             kinds.append('lik')
@@ -113,10 +120,144 @@ def posterior_hmc_spec(posterior, variable_name):
     n_pre, n_post = theta[0], len(kinds) - 1 - theta[-1]
     if theta[-1] - theta[0] + 1 != len(theta) or n_post > 1:
         return None                  # a constant between the two, or two after
-    return ('poly', lik.forward_model, lik.error_model,
+    return (KIND, lik.forward_model, lik.error_model,
             lik.error_model['precision'].value, prior,
             prior is not None and kinds.index('prior') < kinds.index('lik'),
             consts[:n_pre], consts[n_pre] if n_post else None)
+
+
+def _params(fn):
+    """A recogniser that returns the whole spec ``(kind, *params)`` as a registry
+    match hook (which returns the params)."""
+    def hook(pdf, variable_name):
+        spec = fn(pdf, variable_name)
+        return None if spec is None else tuple(spec[1:])
+    return hook
+
+
+# ---------------------------------------------------------------------------
+# HMCSampler hooks of the kind (binf_amd/native.py)
+# ---------------------------------------------------------------------------
+_POLY_WAVE_MAX_WORK = 2.0e8    # chains x data points x coefficients (see covers)
+
+
+def covers(sampler, spec, D, C=None):
+    """Is the fused small-data transition the right launch for ``D`` coefficients
+    (and, when given, ``C`` chains)?  ``sampler.fused_polynomial``: True (layout by the
+    batch), 'group' / 'lane' (one layout whatever the batch), 'always' (fused even where
+    the per-step tier is faster) or False."""
+    mode = getattr(sampler, 'fused_polynomial', True)
+    if not mode or D > FUSED_MAX_COEFFS:
+        return False
+    n_data = len(spec[2].ys)
+    if mode == 'lane' and n_data > 128:
+        return False                 # one lane per chain covers <= 128 data points
+    if n_data > 128 and C is not None and mode != 'always' and \
+            float(C) * n_data * D > _POLY_WAVE_MAX_WORK:
+        # one wave per chain wins while the batch is launch-bound (3-10x up to
+        # ~1e8 chain x data x coefficient products, scripts/probe_poly_wave.py);
+        # beyond that the MFMA gradient of the per-step tier is faster
+        return False
+    return True
+
+
+def lane_layout(sampler, spec, C):
+    """One lane per chain (csrc/hmc_poly.hip) instead of a lane group
+    (csrc/poly_chain_kernel.hpp) for the fused polynomial transition?  A lane
+    group fills the chip from a few thousand chains (20.7 vs 42 us per
+    transition at 4096 chains); with POLY_LANE_MIN_CHAINS chains and more every
+    SIMD has work either way and one lane per chain does half the instructions
+    (2^20 chains: 0.5 vs ~2 ms).  The energies are the same bits in both; the
+    force is summed in data order vs partial sums + butterfly, so a chain's
+    trajectory differs at rounding level between batches on either side of the
+    threshold (like the MFMA gradient's batch-dependent order)."""
+    from binf_amd.samplers import hmc
+    mode = getattr(sampler, 'fused_polynomial', True)
+    if mode == 'lane':
+        return True
+    if mode in ('group', False):
+        return False
+    return len(spec[2].ys) <= 128 and C >= hmc.POLY_LANE_MIN_CHAINS
+
+
+def hmc_sample(sampler, spec, q0, p0, u, accepted, adapt):
+    """The example's polynomial posterior with a small data set: the whole
+    transition in one launch (``csrc/hmc_poly.hip``)."""
+    from binf_amd.samplers.hmc import _MODES
+    _, fwm, em, precision, prior, prior_first, pre, post = spec
+    C, K = q0.shape
+    dev = q0.device
+
+    def const_term(f):
+        v = f.log_prob()
+        if not isinstance(v, torch.Tensor):
+            return torch.full((C,), float(v), dtype=torch.float64, device=dev)
+        return v.to(device=dev, dtype=torch.float64).reshape(-1).expand(C).contiguous()
+    # numpy.sum of a short list: left to right (one launch for two and more terms)
+    pre_terms = [const_term(f) for f in pre]
+    lp_pre = None if not pre_terms else \
+        (pre_terms[0] if len(pre_terms) == 1 else _native.sum_terms(pre_terms))
+    lp_post = const_term(post) if post is not None else None
+    means = prior._vec('means', dev) if prior is not None else None
+    variances = prior._vec('variances', dev) if prior is not None else None
+    q_out = torch.empty_like(q0)
+    eb = torch.empty(C, dtype=torch.float64, device=dev)
+    ea = torch.empty(C, dtype=torch.float64, device=dev)
+    _native.hmc_sample_poly(q0, p0, u, q_out, accepted, sampler.n_accepted, eb, ea,
+                            fwm.xs_device(dev), em.ys_device(dev), precision,
+                            means, variances, prior_first, lp_pre, lp_post,
+                            sampler._timestep, sampler._dt_chain, sampler.nsteps, adapt,
+                            sampler.adaption_uprate, sampler.adaption_downrate,
+                            _MODES[sampler.mode] | (_native.MODE_LANE_PER_CHAIN
+                                                    if lane_layout(sampler, spec, C) else 0))
+    sampler.last_e_before, sampler.last_e_after = eb, ea
+    return q_out
+
+
+def hmc_n(sampler, spec, n, thin, p0, u, record, out, q0, shape):
+    """``hmc_n`` hook: the multi-sweep kernel with the precision draw switched off, where
+    it applies (lane-group layout, a shape the fused transition covers)."""
+    C, K = q0.shape
+    if lane_layout(sampler, spec, C) or not covers(sampler, spec, K, C):
+        return False, None
+    return hmc_sample_n(sampler, spec, n, thin, p0, u, record, out, q0)
+
+
+# ---------------------------------------------------------------------------
+# fused _leapfrog: gradient, partial-sum reduction, kick and drift of every step in
+# one launch each (binf_poly_leapfrog_f64)
+# ---------------------------------------------------------------------------
+def posterior_leapfrog_spec(posterior, variable_name):
+    """``(KIND, forward_model, error_model, precision)`` if the force on
+    ``variable_name`` is exactly ONE polynomial + Gaussian-error likelihood with
+    its precision fixed (every other component has no differentiable variable,
+    quirk Q4) -- the example's conditional posterior of the coefficients."""
+    from binf_amd.pdf.likelihoods import Likelihood
+    if variable_name != 'coefficients':
+        return None
+    lik = None
+    for f in posterior._ordered_components():
+        if not (len(f.variables) > 0 and len(f.differentiable_variables) > 0):
+            continue
+        if lik is not None or not isinstance(f, Likelihood) or not _is_poly_pair(f) or \
+                set(f.variables) != {variable_name} or \
+                'precision' not in f.error_model.parameters:
+            return None
+        lik = f
+    if lik is None:
+        return None
+    return (KIND, lik.forward_model, lik.error_model, lik.error_model['precision'].value)
+
+
+def leapfrog(sampler, spec, q2, p2, dt, dtc, nsteps, mode, q_from):
+    if not (q2.is_cuda and q2.shape[1] <= 64):
+        return False
+    _, fwm, em, precision = spec
+    if q_from is not None:
+        q2.copy_(q_from)
+    _native.poly_leapfrog(q2, p2, fwm.design_matrix(q2.shape[1], q2.device),
+                          em.ys_device(q2.device), precision, dt, dtc, nsteps, mode)
+    return True
 
 
 # ---------------------------------------------------------------------------
@@ -152,8 +293,8 @@ def _gibbs_structure(cs, ps, C, K, dev, hmc):
     gp_where = 0 if not consts else (1 if pre else 2)
     gp = consts[0] if consts else None
     if hmc:
-        if cs._variable_name != 'coefficients' or cs._poly_lane_layout(spec, C) or \
-                cs._fused_spec('coefficients', K, C) is None:
+        if cs._variable_name != 'coefficients' or lane_layout(cs, spec, C) or \
+                not covers(cs, spec, K, C):
             return False
     # the precision sampler must look at the same data
     try:
@@ -417,3 +558,13 @@ def hmc_sample_n(sampler, spec, n, thin, p0, u, record, out, q0):
     sampler.accepted_history = flags
     sampler.counter += n
     return True, (q_out, samples)
+
+
+native.register(
+    KIND, replace=True,
+    match_hmc=_params(posterior_hmc_spec),
+    match_leapfrog=_params(posterior_leapfrog_spec),
+    covers=covers, hmc=hmc_sample, hmc_n=hmc_n, leapfrog=leapfrog,
+    gibbs=gibbs_sample_n,
+    likelihood={('polynomial', 'gaussian'): (log_prob, gradient)},
+    extras={'lane_layout': lane_layout})

@@ -6,9 +6,10 @@ Gradient (of the energy): chain rule ``J(theta) . d E / d mock`` with the
 Jacobian laid out ``[n_params x n_data]`` (reference ``:148-155``; pinned by
 ``binf/tests/pdf/likelihoods.py:114-119``).
 
-Dispatch: when forward and error model both advertise a native implementation
-that the HIP library can fuse (``native_spec``), log-prob and gradient run in
-one fused kernel and the ``[C x n_data]`` mock data never reaches HBM;
+Dispatch: when forward and error model both advertise a native kind
+(``native_spec``) and a kind registered with ``binf_amd.native`` fuses that pair,
+log-prob and gradient run in one fused kernel and the ``[C x n_data]`` mock data
+never reaches HBM;
 otherwise the models are called as written and the contraction is the
 library's generic kernel (``binf_jacobian_contract_f64``).
 """
@@ -83,48 +84,34 @@ class Likelihood(AbstractBinfPDF):
         return fwm, em
 
     def _native_pair(self):
-        fs = getattr(self.forward_model, 'native_spec', lambda: None)()
-        es = getattr(self.error_model, 'native_spec', lambda: None)()
-        if fs is not None and es is not None and \
-                fs[0] == 'polynomial' and es[0] == 'gaussian':
-            return fs, es
-        return None
+        """``(forward spec, error spec)`` if both models advertise a native kind
+        (``native_spec() -> (model kind, model)``) and a registered kind fuses the
+        pair (``binf_amd.native``), else None."""
+        from binf_amd import native
+        pair = native.model_pair(self)
+        return None if pair is None else pair[:2]
+
+    def _fused(self, which, fwm_vars, em_vars):
+        from binf_amd import native
+        pair = native.model_pair(self)
+        if pair is None:
+            return None
+        (_, fwm), (_, em), hooks = pair
+        return hooks[which](self, fwm, em, fwm_vars, em_vars)
 
     def _evaluate_log_prob(self, **variables):
         fwm_vars, em_vars = self._split_variables(variables)
-        pair = self._native_pair()
-        if pair is not None:
-            from binf_amd.example import native_poly
-            out = native_poly.log_prob(self, pair, fwm_vars, em_vars)
-            if out is not None:
-                return out
-        fs = getattr(self.forward_model, 'native_spec', lambda: None)()
-        es = getattr(self.error_model, 'native_spec', lambda: None)()
-        if fs is not None and es is not None and fs[0] == 'pairdist' and \
-                es[0] == 'gaussian_pairdist':
-            from binf_amd.example import distance
-            out = distance.native_log_prob(self, fs[1], es[1], fwm_vars, em_vars)
-            if out is not None:
-                return out
+        out = self._fused(0, fwm_vars, em_vars)
+        if out is not None:
+            return out
         mock_data = self.forward_model(**fwm_vars)
         return self.error_model.log_prob(mock_data=mock_data, **em_vars)
 
     def _evaluate_gradient(self, **variables):
         fwm_vars, em_vars = self._split_variables(variables)
-        pair = self._native_pair()
-        if pair is not None:
-            from binf_amd.example import native_poly
-            out = native_poly.gradient(self, pair, fwm_vars, em_vars)
-            if out is not None:
-                return out
-        fs = getattr(self.forward_model, 'native_spec', lambda: None)()
-        es = getattr(self.error_model, 'native_spec', lambda: None)()
-        if fs is not None and es is not None and fs[0] == 'pairdist' and \
-                es[0] == 'gaussian_pairdist':
-            from binf_amd.example import distance
-            out = distance.native_gradient(self, fs[1], es[1], fwm_vars, em_vars)
-            if out is not None:
-                return out
+        out = self._fused(1, fwm_vars, em_vars)
+        if out is not None:
+            return out
         mock_data = self.forward_model(**fwm_vars)
         dfm = self.forward_model.jacobi_matrix(**fwm_vars)
         emgrad = self.error_model.gradient(mock_data=mock_data, **em_vars)

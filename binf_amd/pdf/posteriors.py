@@ -207,99 +207,21 @@ class Posterior(AbstractBinfPDF):
                 for n, c in self._priors.items()}
         return self.__class__(liks, pris, self.name)
 
+    # -- fused kernels: asked of the registry, never named here (binf_amd/native.py) --
     def native_hmc_spec(self, variable_name):
-        """Fused-trajectory descriptor when this (conditional) posterior is one
-        the HIP library knows how to integrate in a single launch."""
-        from binf_amd.example import native_poly
-        return native_poly.posterior_hmc_spec(self, variable_name)
-
-    def _native_poly_leapfrog_spec(self, variable_name):
-        """``('poly', forward_model, error_model, precision)`` if the force on
-        ``variable_name`` is exactly ONE polynomial + Gaussian-error likelihood with
-        its precision fixed (every other component has no differentiable variable,
-        quirk Q4) -- the example's conditional posterior of the coefficients: the
-        whole ``_leapfrog`` then runs as ``binf_poly_leapfrog_f64``."""
-        from binf_amd.pdf.likelihoods import Likelihood
-        if variable_name != 'coefficients':
-            return None
-        lik = None
-        for f in self._ordered_components():
-            if not (len(f.variables) > 0 and len(f.differentiable_variables) > 0):
-                continue
-            if lik is not None or not isinstance(f, Likelihood) or f._native_pair() is None or \
-                    set(f.variables) != {variable_name} or \
-                    'precision' not in f.error_model.parameters:
-                return None
-            lik = f
-        if lik is None:
-            return None
-        return ('poly', lik.forward_model, lik.error_model, lik.error_model['precision'].value)
+        """``(kind, *params)`` when this (conditional) posterior is one a registered
+        kind integrates in a single launch per transition, else None."""
+        from binf_amd import native
+        return native.match('hmc', self, variable_name)
 
     def native_leapfrog_spec(self, variable_name):
-        """Descriptor of a fused leapfrog kernel that integrates
-        ``variable_name`` under THIS posterior's force, or None.
-
-        Recognised: exactly one restraint likelihood (pair-distance forward
-        model + Gaussian error model with the precision fixed) plus at most
-        one isotropic Gaussian prior on the same variable; components without a
-        differentiable variable do not enter the force anyway (quirk Q4).
-        The tuple records the order of the two force terms, which is this
-        class's sorted-component-name order."""
-        poly = self._native_poly_leapfrog_spec(variable_name)
-        if poly is not None:
-            return poly
-        return self._native_pairdist_spec(variable_name, strict=False)
+        """``(kind, *params)`` of a fused leapfrog kernel that integrates
+        ``variable_name`` under THIS posterior's force, or None."""
+        from binf_amd import native
+        return native.match('leapfrog', self, variable_name)
 
     def native_energy_spec(self, variable_name):
-        """Descriptor of a fused kernel for ``HMCSampler.sample()``'s energy
-        ``0.5 * sum(p**2) - log_prob`` under THIS posterior, or None.  As
-        ``native_leapfrog_spec`` for the restraint posterior, but EVERY component
-        counts: a component without differentiable variables drops out of the force,
-        not out of ``log_prob``.  Besides the likelihood and the one prior, up to two
-        components whose variables are ALL fixed (constants of the move, e.g. the
-        GammaPrior of the precision inside a Gibbs sweep) are recorded in place:
-        the last entry of the tuple lists ``'prior'`` / ``'lik'`` / such a component
-        in the Posterior's order."""
-        return self._native_pairdist_spec(variable_name, strict=True)
-
-    def _native_pairdist_spec(self, variable_name, strict):
-        from binf_amd.pdf import IsotropicGaussian
-        from binf_amd.pdf.likelihoods import Likelihood
-        lik = prior = None
-        order = []
-        terms = []          # strict: every component in the Posterior's order
-        for f in self._ordered_components():
-            if not (len(f.variables) > 0 and len(f.differentiable_variables) > 0):
-                if strict:
-                    # out of the force, not out of log_prob: a component with every variable
-                    # fixed is a constant of the move the energy kernel can add in its place
-                    if len(f.variables) > 0 or sum(1 for t in terms if not isinstance(t, str)) == 2:
-                        return None
-                    terms.append(f)
-                continue
-            if isinstance(f, Likelihood):
-                fs = getattr(f.forward_model, 'native_spec', lambda: None)()
-                es = getattr(f.error_model, 'native_spec', lambda: None)()
-                if lik is not None or fs is None or es is None or \
-                        fs[0] != 'pairdist' or es[0] != 'gaussian_pairdist' or \
-                        f.variables != {variable_name} or \
-                        'precision' not in es[1].parameters:
-                    return None
-                lik = f
-                order.append('lik')
-                terms.append('lik')
-            elif isinstance(f, IsotropicGaussian):
-                if prior is not None or f.native_hmc_spec(variable_name) is None:
-                    return None
-                prior = f
-                order.append('prior')
-                terms.append('prior')
-            else:
-                return None
-        if lik is None:
-            return None
-        em = lik.error_model
-        spec = ('pairdist', em, em['precision'].value,
-                None if prior is None else (float(prior['k'].value), float(prior['x0'].value)),
-                order[0] == 'prior')
-        return spec + (lik, terms) if strict else spec
+        """``(kind, *params)`` of a fused kernel for ``HMCSampler.sample()``'s energy
+        ``0.5 * sum(p**2) - log_prob`` under THIS posterior, or None."""
+        from binf_amd import native
+        return native.match('energy', self, variable_name)

@@ -77,16 +77,17 @@ class GibbsSampler(object):
     def _update_state(self, **variables):
         self._state.update_variables(**variables)
 
-    # One sweep of the example's scheme as ONE launch (the multi-sweep kernel with n = 1,
-    # bit-identical to the per-variable loop below; ~8 launches otherwise).  False: always
-    # the per-variable loop (the tests hold the fused launch to it).
+    # One sweep as ONE launch where a registered kind (binf_amd/native.py: ``gibbs`` hook)
+    # recognises the scheme -- the example's: the multi-sweep kernel with n = 1, bit-identical
+    # to the per-variable loop below; ~8 launches otherwise.  False: always the per-variable
+    # loop (the tests hold the fused launch to it).
     fused_sweep = True
 
     def sample(self):
         self._update_subsampler_states()          # "needed for RE", :144
         if self.fused_sweep:
-            from binf_amd.example import native_poly
-            if native_poly.gibbs_sample_n(self, 1, 1, False)[0]:
+            from binf_amd import native
+            if native.gibbs_sweeps(self, 1, 1, False)[0]:
                 self._update_conditional_pdf_params()
                 return self._state
         for var in sorted(list(self._pdf.variables)):
@@ -102,19 +103,19 @@ class GibbsSampler(object):
         ``thin, 2*thin, ...``; ``example_script.py:41`` keeps every 20th) or None
         if ``record`` is false.
 
-        For the example's scheme (HMC or RWMC on the polynomial coefficients +
-        the conjugate Gamma draw of the precision, draws from a ``DeviceRNG`` or
-        from the reference's host stream) this is ONE kernel launch with every
-        chain's state in registers between the sweeps, bit-identical to n
-        ``sample()`` calls (``csrc/gibbs_poly.hip``); any other scheme loops over
-        ``sample()``."""
+        Where a registered kind recognises the scheme (``binf_amd.native``; the
+        example's: HMC or RWMC on the polynomial coefficients + the conjugate Gamma
+        draw of the precision, draws from a ``DeviceRNG`` or from the reference's
+        host stream) this is ONE kernel launch with every chain's state in registers
+        between the sweeps, bit-identical to n ``sample()`` calls
+        (``csrc/gibbs_poly.hip``); any other scheme loops over ``sample()``."""
         n, thin = int(n), int(thin)
         if n < 1 or thin < 1:
             raise ValueError('sample_n: n >= 1 and thin >= 1 required')
         self._update_subsampler_states()
         self._update_conditional_pdf_params()
-        from binf_amd.example import native_poly
-        handled, rec = native_poly.gibbs_sample_n(self, n, thin, record)
+        from binf_amd import native
+        handled, rec = native.gibbs_sweeps(self, n, thin, record)
         if handled:
             self._update_conditional_pdf_params()
             return rec

@@ -8,8 +8,11 @@ accept, optional step-size adaption.  The state is a ``[C x D]`` fp64 ROCm
 tensor (a ``[D]`` tensor is one chain).  All arithmetic runs in HIP kernels:
 
 * fused tier  -- the PDF advertises a native trajectory kernel
-  (``pdf.native_hmc_spec``): the whole transition is one launch with q, p held
-  in registers;
+  (``pdf.native_hmc_spec(name) -> (kind, *params)``, a kind registered with
+  ``binf_amd.native``): the whole transition is one launch with q, p held in
+  registers.  The sampler never names a model: the isotropic Gaussian's kernels
+  are the built-in kind ``'gauss'`` (registered at the bottom of this module),
+  everything else registers itself (``binf_amd/native.py``);
 * generic tier -- any PDF with ``log_prob`` / ``gradient`` returning batched
   tensors: kick / drift / energy / accept are separate launches around the
   user's gradient.
@@ -20,7 +23,7 @@ from collections import namedtuple
 
 import torch
 
-from binf_amd import _native
+from binf_amd import _native, native
 from binf_amd.samplers.rng import HostLegacyRNG
 
 HMCSampleStats = namedtuple('HMCSampleStats', 'accepted stepsize')
@@ -152,11 +155,12 @@ class HMCSampler(object):
         C, D = q0.shape
         dev = q0.device
         spec = self._fused_spec(name, D, C)          # once per call: walks the posterior
-        if p0 is None and u is None and self._fused_rng(name, D, spec):
-            # the draws come from the lane streams of the fused kernels
-            if _native.gauss_persist_covers(D):
-                return self._sample_n_fused_rng(1)
-            return self._sample_long_fused_rng(name, q0, shape)
+        kind = native.get(spec) if spec is not None else None
+        if kind is not None and p0 is None and u is None and kind.hmc_rng is not None:
+            # a kernel that makes the transition's draws itself
+            drawn = kind.hmc_rng(self, spec, q0, shape)
+            if drawn is not None:
+                return drawn
         both = getattr(self.rng, 'normal_uniform', None)
         if p0 is None and u is None and both is not None:
             p0, u = both((C, D), C, dev)           # one launch for the transition's two draws
@@ -178,10 +182,8 @@ class HMCSampler(object):
             self.n_accepted = torch.zeros(C, dtype=torch.int64, device=dev)
 
         accepted = torch.empty(C, dtype=torch.uint8, device=dev)
-        if spec is not None and spec[0] == 'poly':
-            q_out = self._sample_fused_poly(spec, q0, p0, u, accepted, adapt)
-        elif spec is not None:
-            q_out = self._sample_fused_gauss(spec, q0, p0, u, accepted, adapt)
+        if kind is not None and kind.hmc is not None:
+            q_out = kind.hmc(self, spec, q0, p0, u, accepted, adapt)
         else:
             q_out = self._sample_generic(name, state, q0, p0, own_p, u,
                                          accepted, adapt)
@@ -221,10 +223,57 @@ class HMCSampler(object):
         C, D = q0.shape
         dev = q0.device
         nrec = n // thin
+        if p0 is not None:
+            p0 = p0.reshape(n, C, D)
+        if u is not None:
+            u = u.reshape(n, C)
+        if out is not None:
+            if not record or nrec < 1:
+                raise ValueError('sample_n: out= given but nothing is recorded')
+            if out.dtype != torch.float64 or out.device != dev or \
+                    not out.is_contiguous() or out.numel() != nrec * C * D:
+                raise ValueError('sample_n: out must be a contiguous fp64 [%d, %d, %d] '
+                                 'tensor on %s' % (nrec, C, D, dev))
         spec = self._fused_spec(name, D)
-        fused_rng = p0 is None and u is None and self._fused_rng(name, D, spec) and \
-            _native.gauss_persist_covers(D)
-        persist = spec is not None and spec[0] == 'gauss' and _native.gauss_persist_covers(D)
+        kind = native.get(spec) if spec is not None else None
+        if kind is not None and kind.hmc_n is not None:
+            handled, res = kind.hmc_n(self, spec, n, thin, p0, u, record, out, q0, shape)
+            if handled:
+                q_out, samples = res
+                self.state = q_out.view(shape)
+                if samples is None:
+                    return None
+                return samples if state.dim() == 2 else samples.reshape((nrec,) + tuple(shape))
+        # no multi-transition kernel for this PDF / shape: n single calls (each draws for
+        # itself when no draws were supplied)
+        rec, flags, ebs, eas = [], [], [], []
+        for i in range(n):
+            x = self.sample(p0=None if p0 is None else p0[i], u=None if u is None else u[i])
+            if record and (i + 1) % thin == 0:
+                rec.append(x)
+            flags.append(self._last_move_accepted)
+            ebs.append(self.last_e_before)
+            eas.append(self.last_e_after)
+        self.accepted_history = torch.stack(flags)
+        if all(e is not None for e in ebs):
+            self.last_e_before, self.last_e_after = torch.stack(ebs), torch.stack(eas)
+        if not (record and rec):
+            return None
+        if out is not None:
+            torch.stack(rec, out=out.view((nrec,) + tuple(rec[0].shape)))
+            return out
+        return torch.stack(rec)
+
+    # -- the built-in kind 'gauss': n transitions ------------------------------------
+    def _gauss_sample_n(self, spec, n, thin, p0, u, record, out, q0, shape):
+        """``hmc_n`` hook of the isotropic Gaussian: ONE launch of the persistent
+        kernel (state kept in registers between transitions; D <= 8192), the chunked
+        kernels for longer chains.  Returns ``(True, (q_out, samples))``."""
+        C, D = q0.shape
+        dev = q0.device
+        nrec = n // thin
+        persist = _native.gauss_persist_covers(D)
+        fused_rng = p0 is None and u is None and self._fused_rng(spec) and persist
         if fused_rng and not self._draws_in_kernel(C, D):
             # a small batch: the split kernel with the draws in HBM is the faster
             # launch, so the SAME lane-stream draws are written out first (a seed
@@ -245,50 +294,8 @@ class HMCSampler(object):
                     _fill(self.rng, 'uniform', du[i])
             p0 = dp if p0 is None else p0
             u = du if u is None else u
-        if p0 is not None:
-            p0 = p0.reshape(n, C, D)
-        if u is not None:
-            u = u.reshape(n, C)
-        if out is not None:
-            if not record or nrec < 1:
-                raise ValueError('sample_n: out= given but nothing is recorded')
-            if out.dtype != torch.float64 or out.device != dev or \
-                    not out.is_contiguous() or out.numel() != nrec * C * D:
-                raise ValueError('sample_n: out must be a contiguous fp64 [%d, %d, %d] '
-                                 'tensor on %s' % (nrec, C, D, dev))
-        if not persist and spec is not None and spec[0] == 'gauss':
-            return self._sample_n_long(spec, n, thin, p0, u, record, out, q0, shape, nrec)
-        if spec is not None and spec[0] == 'poly' and not self._poly_lane_layout(spec, C) and \
-                self._fused_spec(name, D, C) is not None:
-            # the example's coefficient conditional: n transitions in one launch
-            from binf_amd.example import native_poly
-            handled, res = native_poly.hmc_sample_n(self, spec, n, thin, p0, u, record, out, q0)
-            if handled:
-                q_out, samples = res
-                self.state = q_out.view(shape)
-                if samples is None:
-                    return None
-                return samples if state.dim() == 2 else samples.reshape((nrec,) + tuple(shape))
         if not persist:
-            # no persistent kernel for this PDF / shape: n single calls (each draws for
-            # itself when no draws were supplied)
-            rec, flags, ebs, eas = [], [], [], []
-            for i in range(n):
-                x = self.sample(p0=None if p0 is None else p0[i], u=None if u is None else u[i])
-                if record and (i + 1) % thin == 0:
-                    rec.append(x)
-                flags.append(self._last_move_accepted)
-                ebs.append(self.last_e_before)
-                eas.append(self.last_e_after)
-            self.accepted_history = torch.stack(flags)
-            if all(e is not None for e in ebs):
-                self.last_e_before, self.last_e_after = torch.stack(ebs), torch.stack(eas)
-            if not (record and rec):
-                return None
-            if out is not None:
-                torch.stack(rec, out=out.view((nrec,) + tuple(rec[0].shape)))
-                return out
-            return torch.stack(rec)
+            return True, self._sample_n_long(spec, n, thin, p0, u, record, out, q0, shape, nrec)
 
         _, k, x0 = spec
         n_adapt = max(0, min(n, self.timestep_adaption_limit - 1 - self.counter))
@@ -328,23 +335,25 @@ class HMCSampler(object):
         self._last_move_accepted = accepted[-1].view(torch.bool)
         self.accepted_history = accepted.view(torch.bool)
         self.counter += n
-        self.state = q_out.view(shape)
-        if samples is None:
+        return True, (q_out, samples)
+
+    def _gauss_sample_rng(self, spec, q0, shape):
+        """``hmc_rng`` hook of the isotropic Gaussian: with a generator whose draws are
+        the lane streams of the fused kernels, sample() is one launch that draws for
+        itself; None with any other generator."""
+        if not self._fused_rng(spec):
             return None
-        return samples if state.dim() == 2 else samples.reshape((nrec,) + tuple(shape))
+        if _native.gauss_persist_covers(q0.shape[1]):
+            return self._sample_n_fused_rng(1)
+        return self._sample_long_fused_rng(spec, q0, shape)
 
     # -- fused tier ----------------------------------------------------------
-    def _fused_rng(self, name, D, spec=False):
-        """True if this sampler's draws are the lane streams of the fused
-        Gaussian kernels (csrc/xoshiro.hpp): a device generator that allows it and
-        a Gaussian with a fused kernel.  Depends on the PDF and D only, never on
-        the number of chains -- so a shard of a run draws what the whole run
-        draws for its chains."""
-        if not getattr(self.rng, 'fused', False):
-            return False
-        if spec is False:
-            spec = self._fused_spec(name, D)
-        return spec is not None and spec[0] == 'gauss'
+    def _fused_rng(self, spec):
+        """True if this sampler's draws are the lane streams of the fused Gaussian
+        kernels (csrc/xoshiro.hpp): a device generator that allows it and a PDF of the
+        built-in kind.  Depends on the PDF only, never on the number of chains -- so a
+        shard of a run draws what the whole run draws for its chains."""
+        return bool(getattr(self.rng, 'fused', False)) and spec is not None and spec[0] == GAUSS
 
     def _draws_in_kernel(self, C, D):
         """Lane-stream draws: generated inside the sampling kernel (True) or
@@ -369,10 +378,10 @@ class HMCSampler(object):
         self.rng.offset += int(n)
         return first
 
-    def _sample_long_fused_rng(self, name, q0, shape):
+    def _sample_long_fused_rng(self, spec, q0, shape):
         """sample() for chains beyond the persistent kernel's reach with the
         draws generated in the kernels (csrc/hmc_gauss_big.hip)."""
-        _, k, x0 = self._fused_spec(name, q0.shape[1])
+        _, k, x0 = spec
         C = q0.shape[0]
         dev = q0.device
         adapt = (self.counter + 1) < self.timestep_adaption_limit
@@ -426,7 +435,7 @@ class HMCSampler(object):
         q_out = torch.empty_like(q0)
         args = (self._timestep, self._dt_chain, self.nsteps)
         tail = (k, x0, n_adapt, self.adaption_uprate, self.adaption_downrate, _MODES[self.mode])
-        if p0 is None and u is None and self._fused_rng(self._variable_name, D, spec):
+        if p0 is None and u is None and self._fused_rng(spec):
             _native.hmc_sample_n_gauss_big(q0, None, None, q_out, samples, accepted, self.n_accepted,
                                            eb, ea, *args, n, thin, *tail,
                                            rng=(self.rng.seed, self.rng.offset, self._chain_offset()))
@@ -470,10 +479,7 @@ class HMCSampler(object):
         self._last_move_accepted = accepted[-1].view(torch.bool)
         self.accepted_history = accepted.view(torch.bool)
         self.counter += n
-        self.state = q_out.view(shape)
-        if samples is None:
-            return None
-        return samples if len(shape) == 2 else samples.reshape((nrec,) + tuple(shape))
+        return q_out, samples
 
     def _sample_n_fused_rng(self, n):
         """sample() with in-kernel draws: one transition, the new state."""
@@ -483,42 +489,26 @@ class HMCSampler(object):
         return self.state
 
     def _fused_spec(self, name, D, C=None):
-        """The PDF's fused-kernel descriptor if the library covers this shape
-        (and, for ``C`` chains, if the fused kernel is the faster choice), else
-        None (generic per-step tier)."""
+        """The PDF's fused-kernel descriptor ``(kind, *params)`` if a registered kind
+        covers this shape (and, for ``C`` chains, if its kernel is the faster
+        choice -- the kind's ``covers`` hook decides), else None (generic per-step
+        tier)."""
         get_spec = getattr(self.pdf, 'native_hmc_spec', None)
         spec = get_spec(name) if get_spec is not None else None
-        if spec is not None and spec[0] == 'gauss':
-            return spec                # persistent kernel, or the chunked one for long chains
-        if spec is not None and spec[0] == 'poly' and self.fused_polynomial and \
-                D <= _native_poly_limits()[0]:
-            n_data = len(spec[2].ys)
-            if self.fused_polynomial == 'lane' and n_data > 128:
-                return None                  # one lane per chain covers <= 128 data points
-            if n_data > 128 and C is not None and self.fused_polynomial != 'always' and \
-                    float(C) * n_data * D > _POLY_WAVE_MAX_WORK:
-                # one wave per chain wins while the batch is launch-bound (3-10x up to
-                # ~1e8 chain x data x coefficient products, scripts/probe_poly_wave.py);
-                # beyond that the MFMA gradient of the per-step tier is faster
-                return None
-            return spec
-        return None
+        if spec is None:
+            return None
+        kind = native.get(spec)
+        if kind is None or (kind.hmc is None and kind.hmc_n is None and kind.hmc_rng is None):
+            return None
+        if kind.covers is not None and not kind.covers(self, spec, D, C):
+            return None
+        return spec
 
     def _poly_lane_layout(self, spec, C):
-        """One lane per chain (csrc/hmc_poly.hip) instead of a lane group
-        (csrc/poly_chain_kernel.hpp) for the fused polynomial transition?  A lane
-        group fills the chip from a few thousand chains (20.7 vs 42 us per
-        transition at 4096 chains); with POLY_LANE_MIN_CHAINS chains and more every
-        SIMD has work either way and one lane per chain does half the instructions
-        (2^20 chains: 0.5 vs ~2 ms).  The energies are the same bits in both; the
-        force is summed in data order vs partial sums + butterfly, so a chain's
-        trajectory differs at rounding level between batches on either side of the
-        threshold (like the MFMA gradient's batch-dependent order)."""
-        if self.fused_polynomial == 'lane':
-            return True
-        if self.fused_polynomial in ('group', False):
-            return False
-        return len(spec[2].ys) <= 128 and C >= POLY_LANE_MIN_CHAINS
+        """The layout choice of the fused small-data polynomial transition (kept here
+        for its callers; the decision is the registered kind's: ``extras['lane_layout']``
+        of the module that registers the polynomial kind)."""
+        return native.get(spec).extras['lane_layout'](self, spec, C)
 
     def _sample_fused_gauss(self, spec, q0, p0, u, accepted, adapt):
         _, k, x0 = spec
@@ -533,38 +523,6 @@ class HMCSampler(object):
         launch(q0, p0, u, q_out, accepted, self.n_accepted, eb, ea, self._timestep,
                self._dt_chain, self.nsteps, k, x0, adapt, self.adaption_uprate,
                self.adaption_downrate, _MODES[self.mode])
-        self.last_e_before, self.last_e_after = eb, ea
-        return q_out
-
-    def _sample_fused_poly(self, spec, q0, p0, u, accepted, adapt):
-        """The example's polynomial posterior with a small data set: the whole
-        transition in one launch (``csrc/hmc_poly.hip``)."""
-        _, fwm, em, precision, prior, prior_first, pre, post = spec
-        C, K = q0.shape
-        dev = q0.device
-
-        def const_term(f):
-            v = f.log_prob()
-            if not isinstance(v, torch.Tensor):
-                return torch.full((C,), float(v), dtype=torch.float64, device=dev)
-            return v.to(device=dev, dtype=torch.float64).reshape(-1).expand(C).contiguous()
-        # numpy.sum of a short list: left to right (one launch for two and more terms)
-        pre_terms = [const_term(f) for f in pre]
-        lp_pre = None if not pre_terms else \
-            (pre_terms[0] if len(pre_terms) == 1 else _native.sum_terms(pre_terms))
-        lp_post = const_term(post) if post is not None else None
-        means = prior._vec('means', dev) if prior is not None else None
-        variances = prior._vec('variances', dev) if prior is not None else None
-        q_out = torch.empty_like(q0)
-        eb = torch.empty(C, dtype=torch.float64, device=dev)
-        ea = torch.empty(C, dtype=torch.float64, device=dev)
-        _native.hmc_sample_poly(q0, p0, u, q_out, accepted, self.n_accepted, eb, ea,
-                                fwm.xs_device(dev), em.ys_device(dev), precision,
-                                means, variances, prior_first, lp_pre, lp_post,
-                                self._timestep, self._dt_chain, self.nsteps, adapt,
-                                self.adaption_uprate, self.adaption_downrate,
-                                _MODES[self.mode] | (_native.MODE_LANE_PER_CHAIN
-                                                     if self._poly_lane_layout(spec, C) else 0))
         self.last_e_before, self.last_e_after = eb, ea
         return q_out
 
@@ -603,32 +561,14 @@ class HMCSampler(object):
 
         leap = getattr(pdf, 'native_leapfrog_spec', None)
         leap = leap(name) if (leap is not None and self.fused_leapfrog) else None
-        if leap is not None and leap[0] == 'pairdist' and q2.shape[1] % 3 == 0 \
-                and q2.shape[1] // 3 <= 1024:
-            # the whole integration in one launch (bit-identical to the loop)
-            _, em, precision, prior, prior_first = leap
-            packed = getattr(em, 'ypacked_device', None)
-            qf = None
-            if q_from is not None:
-                qf = _as2d(q_from)
-                if not (qf.is_contiguous() and qf.shape == q2.shape and qf.dtype == q2.dtype
-                        and qf.device == q2.device):
-                    q2.copy_(qf)
-                    qf = None
-            _native.pairdist_leapfrog(q2, p2, em.ymat_device(q2.device), precision,
-                                      prior, prior_first, dt, dtc, nsteps, mode,
-                                      packed=packed(q2.device) if packed is not None else None,
-                                      q_from=qf)
-            return q, p
+        kind = native.get(leap) if leap is not None else None
+        if kind is not None and kind.leapfrog is not None:
+            # the whole integration in the kind's own launches (bit-identical to the loop)
+            if kind.leapfrog(self, leap, q2, p2, dt, dtc, nsteps, mode,
+                             None if q_from is None else _as2d(q_from)):
+                return q, p
         if q_from is not None:
             q2.copy_(_as2d(q_from))
-        if leap is not None and leap[0] == 'poly' and q2.is_cuda and q2.shape[1] <= 64:
-            # gradient, partial-sum reduction, kick and drift of every step in one launch
-            # each (bit-identical to the loop below)
-            _, fwm, em, precision = leap
-            _native.poly_leapfrog(q2, p2, fwm.design_matrix(q2.shape[1], q2.device),
-                                  em.ys_device(q2.device), precision, dt, dtc, nsteps, mode)
-            return q, p
         # half kick, drift, (nsteps - 1) x [gradient, kick + next drift], half kick:
         # the reference's sequence (hmc.py:116-123) with every interior kick
         # and the drift that follows it in one pass over memory
@@ -650,28 +590,13 @@ class HMCSampler(object):
             mom, _as_chain_vector(pdf.log_prob(**{name: x.view(shape)})).contiguous())
         espec = getattr(pdf, 'native_energy_spec', None)
         espec = espec(name) if (espec is not None and self.fused_energy and q0.is_cuda) else None
-        if espec is not None and espec[0] == 'pairdist' and q0.shape[1] % 3 == 0 \
-                and q0.shape[1] // 3 <= 2048:
-            # prior row sum, chi^2 (with its memo), term sum and kinetic energy in one launch
-            # (bit-identical to the calls above)
-            from binf_amd.example import distance as _dist
-            _, em, precision, prior, prior_first, lik, terms = espec
-            # constants of the move (components with every variable fixed): once per sample()
-            terms = [t if isinstance(t, str) else t.log_prob() for t in terms]
-
-            def kernel_term(t):
-                if isinstance(t, str):
-                    return True
-                if isinstance(t, torch.Tensor):
-                    return t.dim() == 0 or (t.is_cuda and t.dtype == torch.float64 and
-                                            t.is_contiguous() and t.numel() == q0.shape[0])
-                try:                                # a Python / numpy scalar
-                    float(t)
-                    return True
-                except (TypeError, ValueError):
-                    return False
-            if all(kernel_term(t) for t in terms):
-                E = lambda x, mom: _dist.native_hmc_energy(lik, x, mom, precision, prior, terms)
+        ekind = native.get(espec) if espec is not None else None
+        if ekind is not None and ekind.energy is not None:
+            # the PDF's terms, their sum and the kinetic energy in the kind's one launch
+            # (bit-identical to the calls above); None = not this shape
+            fused = ekind.energy(self, espec, q0)
+            if fused is not None:
+                E = fused
 
         p = p0 if own_p else p0.clone()
         e_before = E(q0, p)
@@ -693,8 +618,9 @@ class HMCSampler(object):
         return q
 
 
-_POLY_WAVE_MAX_WORK = 2.0e8    # chains x data points x coefficients (see _fused_spec)
-POLY_LANE_MIN_CHAINS = 65536   # see HMCSampler._poly_lane_layout
+# From this many chains on, kinds that can lay a chain out either over a lane group or on
+# one lane choose the lane (read by the polynomial kind's lane_layout)
+POLY_LANE_MIN_CHAINS = 65536
 
 
 def _fill(rng, kind, out):
@@ -709,11 +635,6 @@ def _fill(rng, kind, out):
         out.copy_(rng.uniform(out.numel(), out.device).reshape(out.shape))
 
 
-def _native_poly_limits():
-    from binf_amd.example import native_poly
-    return native_poly.FUSED_MAX_COEFFS, native_poly.FUSED_MAX_DATA
-
-
 def _as2d(x):
     return x if x.dim() == 2 else x.reshape(1, -1)
 
@@ -723,3 +644,17 @@ def _as_chain_vector(x):
         raise TypeError('pdf.log_prob must return a tensor with one value per '
                         'chain, got %r' % type(x))
     return x.reshape(-1)
+
+
+# ---------------------------------------------------------------------------
+# the built-in kind: the isotropic Gaussian (``binf_amd.pdf.IsotropicGaussian``
+# returns ``('gauss', k, x0)`` from ``native_hmc_spec``), SURVEY 8(a) rows a1-a5, a16
+# ---------------------------------------------------------------------------
+GAUSS = 'gauss'
+native.register(
+    GAUSS, replace=True,
+    hmc=lambda sampler, spec, q0, p0, u, accepted, adapt:
+        sampler._sample_fused_gauss(spec, q0, p0, u, accepted, adapt),
+    hmc_rng=lambda sampler, spec, q0, shape: sampler._gauss_sample_rng(spec, q0, shape),
+    hmc_n=lambda sampler, spec, n, thin, p0, u, record, out, q0, shape:
+        sampler._gauss_sample_n(spec, n, thin, p0, u, record, out, q0, shape))

@@ -142,7 +142,8 @@ def test_c3_sample_at_8192_chains_inside_the_bound(device):
     assert np.array_equal(acc, u < np.exp(np.clip(-(ea - eb), -308.0, 709.0)))
     pb = PB.PolyBound(xs, ys, K, prior_mu=np.zeros(K), prior_var=np.ones(K) * 5)
     for c in (0, 63, 64, 4095, 4096, 8191):                    # both tiles of a wave, both ends
-        ref = R.RefHMCSampler(R.PolyCoefficientsConditional(xs, ys, tau, np.zeros(K), np.ones(K) * 5, 1.0, 0.2),
+        ref = R.RefHMCSampler(R.PolyCoefficientsConditional(xs, ys, tau, np.zeros(K), np.ones(K) * 5, 1.0,
+                                                            1.0),   # rate 1.0: quirk Q6 (clone passes shape twice)
                               q0[c].copy(), dt, L, variable_name='coefficients',
                               normal=lambda size, c=c: p0[c].copy(), uniform=lambda c=c: u[c])
         want = ref.sample()
