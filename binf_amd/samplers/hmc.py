@@ -348,12 +348,20 @@ class HMCSampler(object):
         return self._sample_long_fused_rng(spec, q0, shape)
 
     # -- fused tier ----------------------------------------------------------
-    def _fused_rng(self, spec):
+    def _fused_rng(self, name_or_spec, D=None, spec=False):
         """True if this sampler's draws are the lane streams of the fused Gaussian
         kernels (csrc/xoshiro.hpp): a device generator that allows it and a PDF of the
         built-in kind.  Depends on the PDF only, never on the number of chains -- so a
-        shard of a run draws what the whole run draws for its chains."""
-        return bool(getattr(self.rng, 'fused', False)) and spec is not None and spec[0] == GAUSS
+        shard of a run draws what the whole run draws for its chains.  Called with the
+        PDF's spec, or with ``(variable name, D)`` to look it up."""
+        if not getattr(self.rng, 'fused', False):
+            return False
+        if isinstance(name_or_spec, str):
+            if spec is False:
+                spec = self._fused_spec(name_or_spec, D)
+        else:
+            spec = name_or_spec
+        return spec is not None and spec[0] == GAUSS
 
     def _draws_in_kernel(self, C, D):
         """Lane-stream draws: generated inside the sampling kernel (True) or

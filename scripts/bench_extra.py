@@ -13,6 +13,16 @@ import torch
 # lane-operations/s without FMA contraction (bench.py)
 MFMA_F64_PEAK_TFLOPS = 78.6
 VALU_PEAK_LANEOPS = 39.3e12
+# What a bare loop of v_mfma_f64_16x16x4_f64 on random operands SUSTAINS on this chip
+# (scripts/mfma64_duty.hip, profiles/r04_b_mfma64_duty.jsonl: 70.0 - 70.9 TFLOP/s at 2 - 4
+# waves per SIMD, 2.39 GHz in-kernel clock, 70.9 - 71.6 cycles per MFMA and SIMD instead of
+# the 64 the datasheet figure assumes; every VALU instruction beside it costs another 3.4 - 5.9)
+MFMA_F64_SUSTAINED_TFLOPS = 70.8
+# FP64 operations of one UNORDERED pair of the restraint force as the algorithm defines them
+# (sqrt and divide one operation each): 3 sub (d = xi - xj), 3 mul + 2 add (r^2), 1 sqrt,
+# 1 sub + 1 div + 1 mul (w = tau (r - y) / r), 3 mul (w d), 6 add (both beads) = 21
+C5_ALGORITHMIC_OPS_PER_PAIR = 21.0
+C5_ISA_OPS_PER_PAIR = 24.0        # VALU instructions the n <= 256 scheme issues per pair and lane
 
 
 def _timed(fn, n, warm=2, settle_s=0.0):
@@ -67,6 +77,7 @@ def c3_polynomial(dev, C=8192, K=33, N=16384, L=20):
             'grad_kernel_ms': t_grad * 1e3,
             'grad_TFLOPs': flops / t_grad / 1e12,
             'mfma_frac': flops / t_grad / 1e12 / MFMA_F64_PEAK_TFLOPS,
+            'mfma_frac_of_sustained': flops / t_grad / 1e12 / MFMA_F64_SUSTAINED_TFLOPS,
             'logp_kernel_ms': t_logp * 1e3,
             'hmc_sample_ms': t_hmc * 1e3,
             'chain_leapfrog_steps_per_s': C * L / t_hmc,
@@ -123,10 +134,11 @@ def c5_distance(dev, C=256, n=256, L=20):
             'leapfrog_kernel_ms': t_l[L] * 1e3,
             'force_eval_in_trajectory_us': t_e * 1e6,
             'pair_interactions_per_s': pairs / t_e,
-            # 24 VALU instructions per UNORDERED pair and lane (ISA of the n <= 256 scheme,
-            # DESIGN.md 4.4) against the issue rate of the chip (one VALU instruction per
-            # lane and clock)
-            'valu_frac': 24.0 * 0.5 * pairs / t_e / VALU_PEAK_LANEOPS,
+            # 21 algorithm-defined FP64 operations per UNORDERED pair (sqrt, divide = 1 each)
+            # against 39.3e12 lane-operations/s; the kernel issues 24 VALU instructions per
+            # pair and lane (valu_issue_frac: pipe utilisation, not a roofline)
+            'valu_frac': C5_ALGORITHMIC_OPS_PER_PAIR * 0.5 * pairs / t_e / VALU_PEAK_LANEOPS,
+            'valu_issue_frac': C5_ISA_OPS_PER_PAIR * 0.5 * pairs / t_e / VALU_PEAK_LANEOPS,
             'hmc_sample_ms': t_h * 1e3,
             'chain_leapfrog_steps_per_s': leg['chain_leapfrog_steps_per_s'],
             'acceptance': leg['ranks'][0]['self_check']['acceptance'],
@@ -219,7 +231,7 @@ def c2_strong_scaling_shares(dev, D=1024, L=20, F=64):
 # by bench.py before it touches the GPU), so every frac can be recomputed from
 # the kernel_stats rows carried in the block.
 # ---------------------------------------------------------------------------
-ROOFLINE_KERNELS = {'C3': 'poly_grad_mfma_kernel', 'C5': 'pairdist_leapfrog_sym_kernel',
+ROOFLINE_KERNELS = {'C3': 'poly_grad_mfma', 'C5': 'pairdist_leapfrog_sym_kernel',
                     'C1_gibbs': 'poly_chain_kernel<4, false, true, 0>'}
 C3_SHAPE = dict(C=8192, K=33, N=16384)
 C5_SHAPE = dict(C=256, n=256, L=20)
@@ -332,12 +344,14 @@ def run_all(dev, kstats=None):
                         'TFLOP/s', 'SURVEY 8(d): 4 K N flops per chain and gradient x %d chains '
                         '(one launch = one gradient of every chain)' % s3['C']),
         'C5': _roofline(kstats, 'C5', 'valu',
-                        24.0 * 0.5 * s5['C'] * s5['n'] * (s5['n'] - 1) * (s5['L'] + 1),
+                        C5_ALGORITHMIC_OPS_PER_PAIR * 0.5 * s5['C'] * s5['n'] * (s5['n'] - 1) * (s5['L'] + 1),
                         VALU_PEAK_LANEOPS / 1e12, 'T lane-op/s',
-                        '24 VALU instructions per unordered pair (ISA count, DESIGN.md 4.4) x '
-                        'n (n - 1) / 2 pairs x %d chains x (L + 1) = %d force evaluations of one '
-                        'fused leapfrog launch; peak = 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz'
-                        % (s5['C'], s5['L'] + 1)),
+                        '21 FP64 operations per unordered pair as the algorithm defines them (3 sub, '
+                        '3 mul + 2 add, 1 sqrt, 1 sub + 1 div + 1 mul, 3 mul, 6 add; sqrt and divide one '
+                        'each) x n (n - 1) / 2 pairs x %d chains x (L + 1) = %d force evaluations of one '
+                        'fused leapfrog launch; peak = 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz.  The kernel '
+                        'ISSUES 24 VALU instructions per pair (Newton steps of the correctly rounded sqrt '
+                        'and of the reciprocal included): valu_issue_frac' % (s5['C'], s5['L'] + 1)),
         # 13 lane-operations per data point and force evaluation (Horner K - 1, residual 2,
         # K accumulates + K - 1 powers) -- the arithmetic of the model, not the butterflies
         'C1_gibbs': _roofline(kstats, 'C1_gibbs', 'valu',
@@ -348,6 +362,22 @@ def run_all(dev, kstats=None):
                               '(latency-bound at this batch: 512 waves for 1024 SIMDs)'
                               % (s1['C'], s1['sweeps'])),
     }
+    if blocks['C3'] is not None:
+        b = blocks['C3']
+        b['mfma_sustained_ceiling'] = MFMA_F64_SUSTAINED_TFLOPS
+        b['frac_of_sustained'] = b['achieved'] / MFMA_F64_SUSTAINED_TFLOPS
+        b['sustained_ceiling_is'] = ('bare v_mfma_f64_16x16x4_f64 loop on random operands, best of 1-4 waves '
+                                     'per SIMD: 70.8 TFLOP/s at a 2.39 GHz in-kernel clock (no DVFS give-back '
+                                     'on FP64 MFMA; 71 cycles per MFMA and SIMD, not 64) -- '
+                                     'scripts/mfma64_duty.hip, profiles/r04_b_mfma64_duty.jsonl')
+    if blocks['C5'] is not None:
+        b = blocks['C5']
+        b['algorithmic_ops_per_pair'] = C5_ALGORITHMIC_OPS_PER_PAIR
+        b['isa_valu_per_pair'] = C5_ISA_OPS_PER_PAIR
+        b['valu_issue_frac'] = b['frac'] * C5_ISA_OPS_PER_PAIR / C5_ALGORITHMIC_OPS_PER_PAIR
+    if blocks['C1_gibbs'] is not None:
+        blocks['C1_gibbs']['note'] = ('latency-bound by the batch, not a kernel-quality figure: 4096 chains are '
+                                      '512 waves for 1024 SIMDs (0.27 of the VALU rate at 2^20 chains)')
     for k, b in blocks.items():
         if b is not None and k in res and 'error' not in res[k]:
             res[k]['roofline'] = b

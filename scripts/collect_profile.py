@@ -26,6 +26,14 @@ for sub, out in (('prof', 'bench_kernel_stats'), ('prof_e2e', 'fused_generator_k
         if len(r[0]) > 160:
             r[0] = r[0][:157] + '...'
     csv.writer(open(os.path.join(P, '%s_%s.csv' % (tag, out)), 'w')).writerows(rows[:25])
+for name in ('mfma64_duty.jsonl',):
+    if os.path.exists(os.path.join(G, name)):
+        shutil.copy(os.path.join(G, name), os.path.join(P, '%s_%s' % (tag, name)))
+for name in ('bench_gloo2', 'bench_gloo2_strong'):
+    f = os.path.join(G, name + '.json')
+    if os.path.exists(f) and open(f).read().strip():
+        last = open(f).read().strip().splitlines()[-1]
+        open(os.path.join(P, '%s_%s_rehearsal.json' % (tag, name)), 'w').write(last + '\n')
 for name in ('pytest_tail.txt', 'smoke.txt'):
     shutil.copy(os.path.join(G, name), os.path.join(P, '%s_%s' % (tag, name)))
 b = json.load(open(os.path.join(G, 'bench.json')))

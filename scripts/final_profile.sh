@@ -51,6 +51,14 @@ for _ in range(10): _native.poly_gauss_grad(q0, A, ty, 2.5)
 torch.cuda.synchronize()
 PY
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_poly -- python3 /tmp/polyk.py > /dev/null 2>&1
+# the same counters for the GENERAL gradient kernel (what the whole-tile kernel trimmed away)
+BINF_POLY_GRAD_GENERAL=1 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_poly_general -- python3 /tmp/polyk.py > /dev/null 2>&1
+# what the chip sustains on FP64 MFMA, and what an instruction beside one costs (C3's ceiling)
+[ -x $R/scripts/mfma64_duty ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 $R/scripts/mfma64_duty.hip -o $R/scripts/mfma64_duty
+timeout -k 10 300 $R/scripts/mfma64_duty 1.0 > $O/mfma64_duty.jsonl
+# the multi-rank control flow with the C4 / C5 legs: 2 gloo ranks sharing this GPU (a rehearsal)
+(cd $R && BINF_BENCH_BACKEND=gloo python3 bench.py --gpus 2 --no-cpu-baseline > $O/bench_gloo2.json 2> $O/bench_gloo2.err)
+(cd $R && BINF_BENCH_BACKEND=gloo python3 bench.py --gpus 2 --scaling strong --no-cpu-baseline > $O/bench_gloo2_strong.json 2>> $O/bench_gloo2.err)
 # C5 (pair-distance model)
 for C in 256 2048; do
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_dist_$C -- python3 $R/scripts/bench_distance.py $C > $O/bench_distance_$C.json 2>/dev/null

@@ -90,17 +90,19 @@ out['fused_generator_kernel'] = {'rocprof_kernel_mean_us': statistics.mean(de) i
                                  'us_per_transition': statistics.mean(de) / 64 if de else None,
                                  'us_per_transition_last_40': statistics.mean(de[-40:]) / 64
                                  if len(de) >= 40 else None}
-m, _ = counters('pmc_poly', 'poly_grad_mfma')
-dp = durations('pmc_poly', 'poly_grad_mfma')
-if m and dp:
-    t = statistics.mean(dp) * 1e-6
-    cyc = m['GRBM_GUI_ACTIVE'] / 8
-    out['poly_grad_mfma'] = {'kernel_us_under_pmc': t * 1e6, 'shader_clock_GHz': cyc / t * 1e-9,
-                             # busy cycles summed over the 1024 SIMDs / kernel cycles
-                             'mfma_busy_frac': m['SQ_VALU_MFMA_BUSY_CYCLES'] / (1024 * cyc),
-                             'mfma_insts_per_wave': m['SQ_INSTS_MFMA'] / m['SQ_WAVES'],
-                             'valu_insts_per_wave': m['SQ_INSTS_VALU'] / m['SQ_WAVES'],
-                             'useful_TFLOPs': 4.0 * 33 * 16384 * 8192 / t / 1e12}
+for key, d in (('poly_grad_mfma', 'pmc_poly'), ('poly_grad_mfma_general_kernel', 'pmc_poly_general')):
+    m, _ = counters(d, 'poly_grad_mfma')
+    dp = durations(d, 'poly_grad_mfma')
+    if m and dp:
+        t = statistics.mean(dp) * 1e-6
+        cyc = m['GRBM_GUI_ACTIVE'] / 8
+        out[key] = {'kernel_us_under_pmc': t * 1e6, 'shader_clock_GHz': cyc / t * 1e-9,
+                    # busy cycles summed over the 1024 SIMDs / kernel cycles
+                    'mfma_busy_frac': m['SQ_VALU_MFMA_BUSY_CYCLES'] / (1024 * cyc),
+                    'mfma_insts_per_wave': m['SQ_INSTS_MFMA'] / m['SQ_WAVES'],
+                    'valu_insts_per_wave': m['SQ_INSTS_VALU'] / m['SQ_WAVES'],
+                    'valu_insts_per_mfma': m['SQ_INSTS_VALU'] / m['SQ_INSTS_MFMA'],
+                    'useful_TFLOPs': 4.0 * 33 * 16384 * 8192 / t / 1e12}
 # where a C3 sample() spends its time (kernel trace of scripts/bench_poly.py)
 f = first(O + '/prof_poly/**/*kernel_stats.csv')
 if f:

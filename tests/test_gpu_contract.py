@@ -204,7 +204,7 @@ def test_posterior_sum_chunks_beyond_16_terms_and_broadcasts_device_scalars(devi
         if i % 9 == 4:
             t, w = float(v[0]), float(v[0])                    # a Python float
         elif i % 9 == 7:
-            t, w = dev_t(np.array(v[1]), device), v[1]         # a 0-dim device tensor
+            t, w = torch.tensor(v[1], dtype=torch.float64, device=device), v[1]   # 0-dim device tensor
             assert t.dim() == 0
         else:
             t, w = dev_t(v, device), v
@@ -220,7 +220,8 @@ def test_posterior_sum_chunks_beyond_16_terms_and_broadcasts_device_scalars(devi
             w = w + v
         assert np.array_equal(g, w), T
     # only device scalars and floats: a 0-dim device tensor comes back
-    s = _sum_in_order([dev_t(np.array(1.5), device), 2.25, dev_t(np.array(-0.125), device)])
+    s = _sum_in_order([torch.tensor(1.5, dtype=torch.float64, device=device), 2.25,
+                       torch.tensor(-0.125, dtype=torch.float64, device=device)])
     assert s.dim() == 0 and s.is_cuda and float(s) == (1.5 + 2.25) + -0.125
     # [C x D] gradients
     a, b, c = (rs.standard_normal((5, 7)) for _ in range(3))
