@@ -215,10 +215,11 @@ def test_fused_generator_equals_sampling_from_its_own_dump(device, C, D, L, k, x
     kw = dict(timestep_adaption_limit=4, variable_name='x', mode=mode, record_energies=True)
     a = HMCSampler(IsotropicGaussian(k, x0), q0, dt, L, rng=DeviceRNG(seed, device, fused='always'), **kw)
     assert a._fused_rng('x', D) and a._draws_in_kernel(C, D)
-    rec_a = a.sample_n(n)                                    # offset 0
-    rec_a2 = a.sample_n(2, thin=2)                           # offset 1
+    rec_a = a.sample_n(n)                                    # stream positions 0 .. n - 1
+    rec_a2 = a.sample_n(2, thin=2)                           # positions n, n + 1 (one per TRANSITION, ABI 5)
+    assert a.rng.offset == n + 2
     p0, u = _native.hmc_gauss_rng_draws(n, C, D, seed, 0, device)
-    p1, u1 = _native.hmc_gauss_rng_draws(2, C, D, seed, 1, device)
+    p1, u1 = _native.hmc_gauss_rng_draws(2, C, D, seed, n, device)
     b = HMCSampler(IsotropicGaussian(k, x0), q0, dt, L, **kw)
     rec_b = b.sample_n(n, p0=p0, u=u)
     e_b = (b.last_e_before.clone(), b.last_e_after.clone())
