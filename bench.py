@@ -90,6 +90,8 @@ def parse(argv=None):
     ap.add_argument('--sustain-ms', type=float, default=1000.0,
                     help='after the timed steps: the same launches for this long, reported as '
                          'value_sustained (0 = skip)')
+    ap.add_argument('--no-single-call', action='store_true',
+                    help='skip the short one-transition-per-launch measurement (roofline.single_sample_call)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-other-mode', action='store_true',
                     help='skip the short extra measurement in the other arithmetic mode')
@@ -536,7 +538,7 @@ def main():
     # the single sample() call GibbsSampler.sample() drives (gibbs.py:148): one transition per
     # launch, same kernel family -- reported beside the F-transition launch
     single = None
-    if F > 1 and world == 1 and not args.pmc_child:
+    if F > 1 and world == 1 and not args.pmc_child and not args.no_single_call:
         s1 = make_sampler(args.mode)
         for i in range(8):
             s1.sample(p0=p_bufs[0][i], u=u_bufs[0][i])

@@ -16,7 +16,7 @@ python3 bench.py --fuse 1 --steps 400 --warmup 100 --no-cpu-baseline --no-extra 
 python3 bench.py --mode fma --no-cpu-baseline --no-extra --no-other-mode > $O/bench_fma.json 2>/dev/null
 python3 bench.py --thin 64 --no-cpu-baseline --no-extra --no-other-mode > $O/bench_thin64.json 2>/dev/null
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 $R/bench.py --no-cpu-baseline --no-other-mode --no-extra --no-pmc --sustain-ms 0 > $O/bench_under_rocprof.json 2>/dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 $R/bench.py --no-cpu-baseline --no-other-mode --no-extra --no-pmc --no-single-call --sustain-ms 0 > $O/bench_under_rocprof.json 2>/dev/null
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 $R/bench.py --pmc-child --steps 6 --warmup 2 > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 $R/bench.py --pmc-child --steps 6 --warmup 2 > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES --output-format csv -d $O/pmc_valu -- python3 $R/bench.py --pmc-child --steps 100 --warmup 20 > /dev/null 2>&1

@@ -41,6 +41,8 @@ F = b['roofline']['transitions_per_launch']
 fe, nfe = counters('pmc_fetch', 'persist')
 wr, nwr = counters('pmc_write', 'persist')
 d = durations('prof', 'persist')
+# only the multi-transition launches (a run may also hold one-transition launches of the same kernel)
+d = [x for x in d if x > 0.3 * max(d)] if d else d
 out['persist_kernel'] = {
     'rocprof_kernel_mean_us': statistics.mean(d) if d else None, 'rocprof_kernel_n': len(d),
     # the last 20 dispatches are bench.py's timed steps (settle and warm-up come before)
