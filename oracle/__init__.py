@@ -9,20 +9,26 @@ anything from here, and only as the checker; ``binf_amd`` never does.
 
 PARITY PINNING STATUS (read before trusting a comparison against this):
 
-* The reference package cannot be imported in the build container: it needs
-  the third-party ``csb`` toolbox (reference ``setup.py:25``), which is not
-  installed, not vendored and has no pinned version.  No substitute ``csb``
-  module is fabricated to force the import, so nothing here was generated by
-  executing reference code.
-* What pins the restatement is therefore only what the reference's own tests
-  hold: ``-13.0`` / ``-29.0`` (``binf/tests/pdf/__init__.py:67,73,88``),
-  ``252.0`` and ``[252., 396.]`` (``binf/tests/pdf/likelihoods.py:110-119``)
-  and the Gibbs sweep ``x == 3.0, y == 18.0``
-  (``binf/tests/samplers/gibbs.py:104-112``).
-* None of those exercises ``HMCSampler._leapfrog`` / ``sample``
-  (``binf/samplers/hmc.py:92-164``) and the clip bounds of ``csb.numeric.exp``
-  are restated from its published source from memory.  For the leapfrog /
-  energy / accept numerics the status is **parity unpinned**: the golden
-  ``.npz`` files under ``tests/golden/`` are outputs of THIS restatement
-  (script: ``oracle/gen_golden.py``), not of the reference.
+* ``import binf`` is impossible in the build container: it needs the third-party
+  ``csb`` toolbox (reference ``setup.py:25``), which is not installed, not
+  vendored and has no pinned version, and most of the package is Python-2
+  source.  No substitute ``csb`` module is written or registered anywhere.
+* Pinned by the reference's own tests (the plumbing): ``-13.0`` / ``-29.0``
+  (``binf/tests/pdf/__init__.py:67,73,88``), ``252.0`` and ``[252., 396.]``
+  (``binf/tests/pdf/likelihoods.py:110-119``) and the Gibbs sweep
+  ``x == 3.0, y == 18.0`` (``binf/tests/samplers/gibbs.py:104-112``).
+* Pinned by OUTPUTS OF THE REFERENCE'S OWN CODE (round 4): ``HMCSampler._leapfrog``
+  (``binf/samplers/hmc.py:92-125``).  ``oracle/gen_ref_leapfrog.py`` compiles the
+  reference's class from ``hmc.py`` itself with its single csb import statement
+  (``hmc.py:10``) dropped from the syntax tree -- nothing supplied in its place;
+  ``__init__`` and ``_leapfrog`` use nothing from csb -- and writes
+  ``tests/golden/ref_leapfrog_*.npz``.  ``RefHMCSampler._leapfrog`` and
+  ``oracle_c.c`` reproduce those files bit for bit (``tests/test_ref_leapfrog.py``).
+* Still **parity unpinned**: ``HMCSampler.sample`` beyond the integrator -- the
+  energies ``V(q) + 0.5 * np.sum(p ** 2)``, the accept test through
+  ``csb.numeric.exp`` and the adaption (``hmc.py:136-164,183-191``): no reference
+  test runs them, and ``exp`` is absent (its clip bounds are restated from CSB's
+  published source from memory).  The other golden ``.npz`` files under
+  ``tests/golden/`` (``gauss_*``, ``poly_*``, ``dist_*``) are outputs of THIS
+  restatement (``oracle/gen_golden.py``), not of the reference.
 """

@@ -2,10 +2,12 @@
 TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).  numpy restatement of the
 binf hot path, one chain per sampler object exactly as the reference runs it.
 
-Parity status: pinned by the reference's own test known-answers for the PDF /
-Likelihood / Gibbs plumbing; **parity unpinned** for the HMC numerics
-(``binf/samplers/hmc.py:92-164`` is executed by no reference test and the
-reference cannot be imported here -- see oracle/__init__.py).
+Parity status (see oracle/__init__.py): pinned by the reference's own test
+known-answers for the PDF / Likelihood / Gibbs plumbing; ``_leapfrog``
+(``binf/samplers/hmc.py:92-125``) pinned bit for bit by outputs of the reference's
+own code (``tests/golden/ref_leapfrog_*.npz``, ``oracle/gen_ref_leapfrog.py``);
+**parity unpinned** for the rest of ``sample()`` (``hmc.py:136-164``: energies,
+the accept test through the absent ``csb.numeric.exp``, adaption).
 
 Every function cites the reference lines (relative to the reference root) it
 restates.  Arithmetic is kept in the reference's operation order so that the
