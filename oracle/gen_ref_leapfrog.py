@@ -192,6 +192,26 @@ def main():
         save(tag, kind=np.array('dist'), q0=q0, p0=p0, q_out=q, p_out=p, timestep=np.float64(dt),
              nsteps=np.int64(L), ys=ys, precision=np.float64(4.0), n_beads=np.int64(n),
              prior_k=np.float64(prior_k))
+    # HMCSampler._adapt_timestep (hmc.py:183-191) is free of csb as well: the step size after a
+    # sequence of accepted / rejected moves, in the reference's own order of multiplications
+    # (uprate on ACCEPT, quirk Q3).  The flags are set the way sample() sets them (hmc.py:153).
+    for tag, dt0, up, down, seed in [('default_rates', 0.3, 1.05, 0.95, 500), ('other_rates', 0.0123, 1.3, 0.6, 510)]:
+        flags = np.random.RandomState(seed).uniform(size=(16, 12)) < 0.7
+        steps = np.empty(flags.shape)
+        for c in range(flags.shape[0]):
+            s = Sampler(Gaussian(1.0, 0.0), np.zeros(2), dt0, 3, timestep_adaption_limit=1000,
+                        adaption_uprate=up, adaption_downrate=down, variable_name='x')
+            for i, f in enumerate(flags[c]):
+                s._last_move_accepted = bool(f)
+                s._adapt_timestep()
+                steps[c, i] = s.timestep
+        path = os.path.join(OUT, 'ref_adapt_timestep_%s.npz' % tag)
+        np.savez_compressed(path, provenance=np.array(PROVENANCE.replace(
+            "HMCSampler._leapfrog (binf/samplers/hmc.py:92-125)",
+            "HMCSampler._adapt_timestep (binf/samplers/hmc.py:183-191)")), kind=np.array('adapt'),
+            accepted=flags, timestep0=np.float64(dt0), uprate=np.float64(up), downrate=np.float64(down),
+            timesteps=steps)
+        written.append(os.path.basename(path))
     print('wrote %d files to %s:\n  %s' % (len(written), OUT, '\n  '.join(written)))
 
 

@@ -125,7 +125,7 @@ for case in range(n_cases):
 
     # ---- MFMA gradient ------------------------------------------------------
     K = int(rs.randint(1, 65))
-    N = int(rs.choice([1, 15, 16, 17, 100, 1000, 4099, 16384]))
+    N = int(rs.choice([1, 15, 16, 17, 32, 100, 160, 1000, 1024, 4096, 4099, 16384]))   # incl. whole-tile sets (N % 16 == 0): the trimmed MFMA kernel
     Cg = int(rs.choice([1, 15, 16, 17, 63, 64, 65, 130, 2100]))
     if Cg * N > 4e6:
         Cg = 17

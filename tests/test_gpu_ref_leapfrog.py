@@ -125,3 +125,36 @@ def test_pair_distance_leapfrog_vs_the_reference_integrator(device, path, fused)
     assert np.abs(q - g['q_out']).max() <= 1e-10 * np.abs(g['q_out']).max()
     assert np.abs(p - g['p_out']).max() <= 1e-10 * np.abs(g['p_out']).max()
     assert not np.array_equal(q, g['q0'])
+
+
+@pytest.mark.parametrize('path', golden_files('ref_adapt_timestep_'),
+                         ids=lambda p: p.split('ref_adapt_timestep_')[-1][:-4])
+@pytest.mark.parametrize('D', [8, 1024, 9000])
+def test_adaption_follows_the_reference_run_bitwise(device, path, D):
+    """Step-size adaption inside the kernels (persistent kernel D = 8 / 1024, long-chain path
+    D = 9000) and the ``_adapt_timestep`` method against the step sizes the REFERENCE's own
+    ``_adapt_timestep`` (hmc.py:183-191) produced for the same accept / reject sequences; the
+    moves are forced with u = 0 (accept) / u = inf (reject)."""
+    g = load_golden(path)
+    flags, want = g['accepted'], g['timesteps']
+    up, down, dt0 = float(g['uprate']), float(g['downrate']), float(g['timestep0'])
+    C, n = flags.shape
+    u = dev_t(np.where(flags.T, 0.0, np.inf), device)                       # [n, C]
+    q0 = torch.zeros((C, D), dtype=torch.float64, device=device)
+    kw = dict(timestep_adaption_limit=1000, adaption_uprate=up, adaption_downrate=down, variable_name='x')
+    # n single calls
+    s = HMCSampler(IsotropicGaussian(), q0, dt0, 1, **kw)
+    for i in range(n):
+        s.sample(p0=torch.full((C, D), 1e-3, dtype=torch.float64, device=device), u=u[i])
+        assert np.array_equal(s.last_move_accepted.cpu().numpy(), flags[:, i])
+        assert np.array_equal(s.timestep.cpu().numpy(), want[:, i]), i
+    # one multi-transition launch
+    s = HMCSampler(IsotropicGaussian(), q0, dt0, 1, **kw)
+    s.sample_n(n, p0=torch.full((n, C, D), 1e-3, dtype=torch.float64, device=device), u=u, record=False)
+    assert np.array_equal(s.timestep.cpu().numpy(), want[:, -1])
+    # the method, driven by hand as the fixture was made
+    s = HMCSampler(IsotropicGaussian(), q0, dt0, 1, **kw)
+    for i in range(n):
+        s._last_move_accepted = torch.from_numpy(flags[:, i]).to(device)
+        s._adapt_timestep()
+        assert np.array_equal(s.timestep.cpu().numpy(), want[:, i]), i

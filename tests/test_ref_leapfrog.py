@@ -76,3 +76,36 @@ def test_c_restatement_reproduces_the_reference_integrator_bitwise(path):
     for c in range(C):
         want = 0.5 * k * np.sum((g['q_out'][c] - x0) ** 2) + 0.5 * np.sum(g['p_out'][c] ** 2)
         assert out['e_after'][c] == want
+
+
+ADAPT = golden_files('ref_adapt_timestep_')
+
+
+@pytest.mark.parametrize('path', ADAPT, ids=lambda p: p.split('ref_adapt_timestep_')[-1][:-4])
+def test_restatements_reproduce_the_reference_adaption_bitwise(path):
+    """``HMCSampler._adapt_timestep`` (hmc.py:183-191), run from the reference's own source
+    (oracle/gen_ref_leapfrog.py): the step size after a sequence of accepted / rejected moves.
+    The numpy restatement follows it bit for bit, and so does the C restatement's in-transition
+    adaption (moves forced with u = 0 / u = inf)."""
+    g = load_golden(path)
+    assert 'hmc.py:183-191' in str(g['provenance'])
+    flags, want = g['accepted'], g['timesteps']
+    up, down, dt0 = float(g['uprate']), float(g['downrate']), float(g['timestep0'])
+    C, n = flags.shape
+    for c in range(C):
+        s = R.RefHMCSampler(R.GaussianPDF(), np.zeros(2), dt0, 3, timestep_adaption_limit=1000,
+                            adaption_uprate=up, adaption_downrate=down, variable_name='x')
+        for i in range(n):
+            s._last_move_accepted = bool(flags[c, i])
+            s._adapt_timestep()
+            assert s.timestep == want[c, i], (c, i)
+    # C restatement: one chain per row, tiny steps (any proposal would be accepted at u = 0)
+    q = np.zeros((C, 4))
+    dts = np.full(C, dt0)
+    for i in range(n):
+        u = np.where(flags[:, i], 0.0, np.inf)
+        out = c_oracle.hmc_sample_gauss(q, np.ones((C, 4)) * 1e-3, u, dts, 1, adapt=True, uprate=up,
+                                        downrate=down)
+        assert np.array_equal(out['accepted'].astype(bool), flags[:, i])
+        dts = out['timestep_out']
+        assert np.array_equal(dts, want[:, i]), i
