@@ -338,16 +338,11 @@ __global__ void __launch_bounds__(256) poly_grad_mfma_kernel(const GradArgs a)
 // ---------------------------------------------------------------------------
 template <int B> struct BufC { static constexpr int value = B; };
 
-// Workgroups per CU the register allocator is held to: 3 (12 waves per CU, <= 168
-// VGPRs) where the kernel fits without spilling inside the tile loop -- K <= 33, the
-// K <= 36 and K <= 48 shapes -- else 2.
-constexpr int grad_full_wgs(int KS, int KV)
-{
-    return ((KS <= 8 && KV <= 1) || KS == 9 || (KS == 12 && KV == 0)) ? 3 : 2;
-}
-
+// Two workgroups (8 waves) per CU are what the launch shape asks for (grad_splits: 2 waves per
+// SIMD keep the matrix pipe fed, a third buys nothing -- 66.9 vs 66.4 TFLOP/s at C3); the
+// register allocator gets the 256 VGPRs that leaves it, so no instantiation spills.
 template <int KS, int RT, int KV, int CT>
-__global__ void __launch_bounds__(256, grad_full_wgs(KS, KV)) poly_grad_mfma_full_kernel(const GradArgs a)
+__global__ void __launch_bounds__(256, 2) poly_grad_mfma_full_kernel(const GradArgs a)
 {
     constexpr int KB = 4 * KS;
     constexpr int ROWS0 = (4 * KS > 16 * RT) ? 4 * KS : 16 * RT;
@@ -560,25 +555,29 @@ split_reduce_kick_drift_kernel(const double *part, double *q, double *p, const d
 
 static int grad_ct(int64_t C)
 {
-    // two 16-chain tiles per wave once there are enough chains to fill the chip
+    // two 16-chain tiles per wave once there are enough chains to fill the chip (settled
+    // sweep of the whole-tile kernel, gpurun_out/r04_grad_sweep2: 4096 chains 63.7 vs 62.9
+    // TFLOP/s, 2048 chains 55.0 vs 57.8)
     static int forced = -1;
     if (forced < 0) {
         const char *e = getenv("BINF_POLY_GRAD_CT");      // development aid
         forced = e ? atoi(e) : 0;
     }
     if (forced == 1 || forced == 2) return forced;
-    return C >= 2048 ? 2 : 1;
+    return C >= 4096 ? 2 : 1;
 }
 
 static int grad_splits(int64_t C, int64_t N)
 {
-    // aim at ~4 workgroups per CU; never more splits than data tiles
+    // aim at 2 workgroups per CU (2 waves per SIMD keep the matrix pipe fed; fewer, longer
+    // workgroups mean fewer partial sums to write and add up); never more splits than data tiles
     const int64_t wgx = (C + 64 * grad_ct(C) - 1) / (64 * grad_ct(C));
     const int64_t ntiles = (N + 15) / 16;
     static int64_t target = 0;
     if (target == 0) {
         const char *e = getenv("BINF_POLY_GRAD_WGS");     // development aid
-        target = e ? atoll(e) : 1024;            // measured best on MI355X (512..4096 tried)
+        target = e ? atoll(e) : 512;             // measured best on MI355X (round 4, settled: 512 / 640 /
+                                                 // 768 / 1024 at 1024 .. 8192 chains; 384 starves the chip)
     }
     int64_t ns = (target + wgx - 1) / wgx;
     if (ns > 64) ns = 64;
