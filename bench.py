@@ -540,7 +540,7 @@ def main():
     single = None
     if F > 1 and world == 1 and not args.pmc_child and not args.no_single_call:
         s1 = make_sampler(args.mode)
-        for i in range(8):
+        for i in range(min(8, F)):
             s1.sample(p0=p_bufs[0][i], u=u_bufs[0][i])
         torch.cuda.synchronize()
         g0 = torch.cuda.Event(enable_timing=True)

@@ -161,3 +161,30 @@ def test_distance_golden_is_what_the_restatement_gives(name):
     r = G.run_dist_set(*spec[1:])
     for k in r:
         assert np.array_equal(r[k], g[k]), k
+
+
+def test_c_oracle_under_asan_and_ubsan(tmp_path):
+    """The checker itself under the sanitizers that ARE available here (CPU build; GPU ASan is not
+    offered on this pool): oracle_c.c + oracle/sanitize_main.c built with -fsanitize=address,undefined
+    and run over ragged lengths around the pairwise-sum leaf / chunk boundaries, exact-size heap
+    buffers, one and two OpenMP threads."""
+    import os
+    import shutil
+    import subprocess
+    from conftest import ROOT
+    gcc = shutil.which('gcc')
+    if gcc is None:
+        pytest.skip('no gcc')
+    exe = str(tmp_path / 'oracle_san')
+    cmd = [gcc, '-O1', '-g', '-fno-omit-frame-pointer', '-ffp-contract=off', '-fopenmp',
+           '-fsanitize=address,undefined', '-fno-sanitize-recover=all',
+           os.path.join(ROOT, 'oracle', 'oracle_c.c'), os.path.join(ROOT, 'oracle', 'sanitize_main.c'),
+           '-o', exe, '-lm']
+    b = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    if b.returncode != 0 and b'sanitize' in b.stderr.lower():
+        pytest.skip('this gcc has no sanitizer runtime: ' + b.stderr.decode()[-200:])
+    assert b.returncode == 0, b.stderr.decode()[-2000:]
+    r = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300,
+                       env=dict(os.environ, ASAN_OPTIONS='detect_leaks=1:abort_on_error=0', OMP_NUM_THREADS='2'))
+    assert r.returncode == 0, (r.stdout.decode()[-500:], r.stderr.decode()[-3000:])
+    assert b'sanitized oracle run ok' in r.stdout
