@@ -342,6 +342,52 @@ def dry_run(args, rank, world):
         dist.destroy_process_group()
 
 
+def c2_strong_leg(args, comm, dev, F, thin, D, L, launches=10):
+    """The C2 job at FIXED size -- args.chains chains in all -- sharded over the ranks of this run
+    (512 per GPU at N = 8: a chain spread over several waves, csrc/hmc_gauss_split.hip): same
+    launches as the headline (sample_n(F), every thin-th state recorded, draws resident in HBM),
+    wall clock between two barriers, MAX over ranks."""
+    from binf_amd.dist import shard_chains
+    from binf_amd.pdf import IsotropicGaussian
+    from binf_amd.samplers.hmc import HMCSampler
+    total = args.chains
+    off, Cs = shard_chains(total, comm.rank, comm.world)
+    if Cs < 1:
+        raise ValueError('%d chains leave rank %d without one' % (total, comm.rank))
+    q0 = torch.from_numpy(np.ascontiguousarray(
+        np.random.RandomState(1234).standard_normal((total, D))[off:off + Cs])).to(dev)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(7000 + comm.rank)
+    p = [torch.randn((F, Cs, D), dtype=torch.float64, device=dev, generator=gen) for _ in range(2)]
+    u = [torch.rand((F, Cs), dtype=torch.float64, device=dev, generator=gen) for _ in range(2)]
+    rec = torch.empty((F // thin, Cs, D), dtype=torch.float64, device=dev)
+    s = HMCSampler(IsotropicGaussian(1.0, 0.0), q0, args.timestep, L, variable_name='x', mode=args.mode)
+    t_s = time.perf_counter()
+    i = 0
+    while time.perf_counter() - t_s < 0.15:            # settle
+        s.sample_n(F, thin=thin, p0=p[i % 2], u=u[i % 2], out=rec)
+        i += 1
+        torch.cuda.synchronize()
+    comm.barrier()
+    t0 = time.perf_counter()
+    for j in range(launches):
+        s.sample_n(F, thin=thin, p0=p[j % 2], u=u[j % 2], out=rec)
+    comm.barrier()
+    mine = time.perf_counter() - t0
+    elapsed = comm.max(mine)
+    ranks = comm.all_gather_object({'rank': comm.rank, 'chain_offset': off, 'chains': Cs, 'elapsed_s': mine,
+                                    'value': Cs * L * F * launches / mine,
+                                    'acceptance': float(s.acceptance_rate.mean())})
+    return {'workload': 'C2 strong scaling: %d chains IN ALL over %d GPUs (%d on rank 0), sample_n(%d) x %d '
+                        'launches, every %s state recorded' % (total, comm.world, ranks[0]['chains'], F, launches,
+                                                              'transition\'s' if thin == 1 else '%d.' % thin),
+            'chain_leapfrog_steps_per_s': total * L * F * launches / elapsed,
+            'chains_total': total, 'n_gpus': comm.world, 'scaling': 'strong',
+            'us_per_transition': elapsed / (launches * F) * 1e6,
+            'sum_of_rank_values': sum(r['value'] for r in ranks), 'ranks': ranks,
+            'timing': 'wall clock between two barriers, MAX over ranks'}
+
+
 def main():
     argv = sys.argv[1:]
     args = parse(argv)
@@ -616,13 +662,21 @@ def main():
         per_rank = [None] * world
         dist.all_gather_object(per_rank, mine)
 
-    # The sharded C4 / C5 legs (every rank: they hold barriers and the sample gather).
+    # The sharded C4 / C5 legs (every rank: they hold barriers and the sample gather), and --
+    # in a weak-scaling run -- the C2 job of FIXED size (--chains in all) sharded over the same
+    # ranks: SURVEY 8(e)'s secondary, strong-scaling figure from the same invocation.
     legs = None
     if world > 1 and not args.no_legs and not args.no_extra:
         del p_bufs, u_bufs, rec_bufs
         torch.cuda.empty_cache()
         from scripts import bench_legs
-        legs = bench_legs.run_legs(dev, bench_legs.Comm(dist, backend, dev), scaling=args.scaling)
+        comm = bench_legs.Comm(dist, backend, dev)
+        legs = bench_legs.run_legs(dev, comm, scaling=args.scaling)
+        if args.scaling == 'weak' and F > 1:
+            try:
+                legs['C2_strong'] = c2_strong_leg(args, comm, dev, F, thin, D, L)
+            except Exception as e:                  # noqa: BLE001 -- never breaks the headline
+                legs['C2_strong'] = {'error': '%s: %s' % (type(e).__name__, e)}
 
     if rank == 0:
         transitions = K * F
