@@ -13,8 +13,13 @@ HBM and allocated before the timed region; each timed launch reads draws that no
 earlier launch in the run has touched recently (>= 2 GiB of other traffic in
 between, the Infinity Cache is 256 MiB).
 
-Multi-GPU: chains are sharded (weak scaling, 4096 chains per GPU), no collective
-in the data path; the RCCL gather of one recorded draw is timed separately.
+Multi-GPU: chains are sharded (weak scaling, 4096 chains per GPU; --scaling strong:
+4096 in all), no collective in the data path; the RCCL gather of one recorded draw
+is timed separately.  With N > 1 every rank also runs the sharded C4 (Gibbs-within-HMC,
+polynomial) and C5 (pair-distance) legs -- scripts/bench_legs.py: per-rank shards by
+DeviceRNG.for_shard, SampleStore recording, a timed gather(dst=0), per-rank self-check
+fields -- and, in a weak run, the fixed-size C2 job sharded over the same ranks
+(extra.C2_strong): one line holds every figure north_star names.
 
   python bench.py [--gpus N] [--steps K] [--warmup W]
 
