@@ -7,9 +7,6 @@ A FOURTH kind is registered here, from outside the package: a shifted Gaussian w
 PDF class lives in this test file and whose launcher drives the library's existing
 ``binf_hmc_sample_gauss_f64``.  ``HMCSampler.sample()`` and ``sample_n()`` take it
 with no change to ``HMCSampler`` / ``Posterior`` / ``Likelihood`` / ``GibbsSampler``."""
-import os
-import subprocess
-
 import numpy as np
 import pytest
 import torch
@@ -18,7 +15,6 @@ from binf_amd import ArrayParameter, _native, native
 from binf_amd.params import Parameter
 from binf_amd.pdf import AbstractBinfPDF, IsotropicGaussian
 from binf_amd.samplers.hmc import _MODES, HMCSampler
-from conftest import ROOT
 
 pytestmark = pytest.mark.gpu
 
@@ -135,33 +131,7 @@ def test_a_kinds_covers_hook_sends_other_shapes_to_the_per_step_tier(device, fou
     assert CALLS['hmc'] == 0 and CALLS['covers'] >= 1
 
 
-def test_registry_api():
-    assert {'gauss', 'poly', 'pairdist'} <= {k.name for k in native.kinds()} or \
-        {'gauss'} <= {k.name for k in native.kinds()}
-    with pytest.raises(ValueError):
-        native.register('gauss', hmc=_hmc)                   # taken (replace=True to override)
-    with pytest.raises(TypeError):
-        native.register('x', no_such_hook=_hmc)
-    with pytest.raises(TypeError):
-        native.register('x', hmc='not callable')
-    with pytest.raises(TypeError):
-        native.register('x', likelihood={'polynomial': (None, None)})
-    assert native.get('no such kind') is None and native.get(('gauss', 1.0, 0.0)).name == 'gauss'
-    assert native.match('hmc', IsotropicGaussian(), 'x') is None     # a PDF that IS a kind answers itself
-    assert IsotropicGaussian(2.0, 0.5).native_hmc_spec('x') == ('gauss', 2.0, 0.5)
-
-
-def test_the_core_never_names_a_model():
-    """`grep -rn "binf_amd.example" binf_amd/samplers binf_amd/pdf binf_amd/model`
-    is empty -- and so is a search for the kinds' names in the core's code."""
-    r = subprocess.run(['grep', '-rn', '--include=*.py', 'binf_amd.example',
-                        os.path.join(ROOT, 'binf_amd', 'samplers'), os.path.join(ROOT, 'binf_amd', 'pdf'),
-                        os.path.join(ROOT, 'binf_amd', 'model')], stdout=subprocess.PIPE)
-    assert r.stdout.decode() == ''
-    for rel in ('samplers/hmc.py', 'samplers/gibbs.py', 'pdf/posteriors.py', 'pdf/likelihoods.py'):
-        src = open(os.path.join(ROOT, 'binf_amd', rel)).read()
-        for name in ("'poly'", "'pairdist'", "'polynomial'", "'gaussian_pairdist'"):
-            assert name not in src, (rel, name)
+# (the registry's API and the "core never names a model" grep are CPU tests: tests/test_registry.py)
 
 
 def test_example_kinds_register_on_import_and_dispatch(device):
