@@ -91,7 +91,15 @@ def test_error_model_and_fused_logp(device, K, N, C):
     assert np.array_equal(got, (mock - ys) * taus[:, None])
 
 
-@pytest.mark.parametrize('K,N,C', SHAPES + [(33, 4096, 130), (4, 20, 1000)])
+# data sets made of whole 16-point tiles take the trimmed kernel (poly_grad_mfma_full_kernel): one
+# tile, fewer tiles than splits, every K instantiation incl. the VALU tails (17, 18, 33, 34, 49,
+# 50), ragged chain counts on either side of the two-tiles-per-wave threshold (4096), C = 1
+WHOLE_TILE_SHAPES = [(1, 16, 1), (4, 32, 5), (8, 16, 200), (16, 48, 3), (17, 64, 130), (18, 16, 70),
+                     (32, 160, 9), (33, 64, 130), (34, 16, 200), (36, 320, 7), (48, 96, 65), (49, 32, 3),
+                     (50, 160, 70), (64, 320, 9), (16, 4096, 4100), (33, 1024, 4097), (5, 16384, 2)]
+
+
+@pytest.mark.parametrize('K,N,C', SHAPES + [(33, 4096, 130), (4, 20, 1000)] + WHOLE_TILE_SHAPES)
 def test_mfma_gradient_matches_numpy_chain_rule(device, K, N, C):
     """J . ((mock - ys) * tau) with J = vstack([xs**i]) (likelihoods.py:148-155)."""
     xs, ys, theta = synth(K, N, C, K + N + C)
