@@ -212,6 +212,32 @@ def main():
             accepted=flags, timestep0=np.float64(dt0), uprate=np.float64(up), downrate=np.float64(down),
             timesteps=steps)
         written.append(os.path.basename(path))
+    # the csb-free attribute plumbing of the reference's class (hmc.py:56-90,127-134,166-181):
+    # what GibbsSampler and user code read from a sampler
+    import json
+    s = Sampler(Gaussian(1.0, 0.0), np.arange(3.0), 0.25, 7)             # variable_name left at None
+    fresh = {'acceptance_rate': s.acceptance_rate, 'variable_name': s.variable_name,
+             'last_move_accepted': s.last_move_accepted, 'n_accepted': s.n_accepted, 'counter': s.counter,
+             'timestep': s.timestep, 'nsteps': s.nsteps,
+             'timestep_adaption_limit': s.timestep_adaption_limit,
+             'adaption_uprate': s.adaption_uprate, 'adaption_downrate': s.adaption_downrate}
+    stats = s.last_draw_stats
+    fresh['last_draw_stats'] = {k: {'fields': list(v._fields), 'values': list(v)} for k, v in stats.items()}
+    s.n_accepted, s.counter = 3, 4
+    s._last_move_accepted = True
+    named = Sampler(Gaussian(1.0, 0.0), np.arange(3.0), 0.25, 7, variable_name='coefficients')
+    copy = s._copy_state(s.state)
+    plumbing = {'provenance': PROVENANCE.replace("HMCSampler._leapfrog (binf/samplers/hmc.py:92-125)",
+                                                 "HMCSampler attribute plumbing (binf/samplers/hmc.py:56-90,127-134,166-181)"),
+                'fresh': fresh,
+                'after_3_of_4': {'acceptance_rate': s.acceptance_rate, 'last_move_accepted': s.last_move_accepted,
+                                 'last_draw_stats_values': list(s.last_draw_stats['HMC'])},
+                'named': {'variable_name': named.variable_name, 'last_draw_stats_keys': list(named.last_draw_stats)},
+                'copy_state': {'equal': bool(np.array_equal(copy, s.state)), 'same_object': copy is s.state}}
+    path = os.path.join(OUT, 'ref_hmc_attributes.json')
+    with open(path, 'w') as f:
+        json.dump(plumbing, f, indent=1, sort_keys=True)
+    written.append(os.path.basename(path))
     print('wrote %d files to %s:\n  %s' % (len(written), OUT, '\n  '.join(written)))
 
 

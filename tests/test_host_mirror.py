@@ -473,3 +473,43 @@ def test_density_leftovers_and_validation_hook():
     with pytest.raises(ValueError):
         p['ParamA'] = Parameter(13.0, 'ParamA')
     assert p['ParamA'].value == 3.0
+
+
+def test_hmc_sampler_attributes_follow_the_reference_run():
+    """``tests/golden/ref_hmc_attributes.json``: what the REFERENCE's own HMCSampler object answers
+    for the attributes GibbsSampler and user code read (hmc.py:56-90,127-134,166-181) -- produced by
+    oracle/gen_ref_leapfrog.py from the reference's source (csb import dropped, no stand-in).  This
+    package's HMCSampler gives the same answers (no kernel involved; host tensors)."""
+    import json
+    import os
+    import torch
+    from binf_amd.pdf import IsotropicGaussian
+    from binf_amd.samplers.hmc import HMCSampler
+    from conftest import GOLDEN_DIR
+    ref = json.load(open(os.path.join(GOLDEN_DIR, 'ref_hmc_attributes.json')))
+    assert 'hmc.py:56-90' in ref['provenance']
+    state = torch.arange(3.0, dtype=torch.float64)
+    s = HMCSampler(IsotropicGaussian(), state, 0.25, 7)                 # variable_name left at None
+    f = ref['fresh']
+    for name in ('acceptance_rate', 'variable_name', 'last_move_accepted', 'n_accepted', 'counter',
+                 'timestep', 'nsteps', 'timestep_adaption_limit', 'adaption_uprate', 'adaption_downrate'):
+        assert getattr(s, name) == f[name], name
+    stats = s.last_draw_stats
+    assert list(stats) == list(f['last_draw_stats'])
+    got = stats['HMC']
+    assert list(got._fields) == f['last_draw_stats']['HMC']['fields']
+    assert list(got) == f['last_draw_stats']['HMC']['values']
+    s.n_accepted, s.counter = 3, 4
+    s._last_move_accepted = True
+    a = ref['after_3_of_4']
+    assert s.acceptance_rate == a['acceptance_rate'] and s.last_move_accepted is a['last_move_accepted']
+    assert list(s.last_draw_stats['HMC']) == a['last_draw_stats_values']
+    named = HMCSampler(IsotropicGaussian(), state, 0.25, 7, variable_name='coefficients')
+    assert named.variable_name == ref['named']['variable_name']
+    assert list(named.last_draw_stats) == ref['named']['last_draw_stats_keys']
+    c = s._copy_state(s.state)
+    assert bool(torch.equal(c, s.state)) is ref['copy_state']['equal']
+    assert (c is s.state) is ref['copy_state']['same_object']
+    # quirk Q1, as the reference: sample() with variable_name None fails with a TypeError
+    with pytest.raises(TypeError):
+        s.sample()
