@@ -24,6 +24,15 @@ PARITY PINNING STATUS (read before trusting a comparison against this):
   ``__init__`` and ``_leapfrog`` use nothing from csb -- and writes
   ``tests/golden/ref_leapfrog_*.npz``.  ``RefHMCSampler._leapfrog`` and
   ``oracle_c.c`` reproduce those files bit for bit (``tests/test_ref_leapfrog.py``).
+* Also pinned by reference-run outputs (round 4, ``oracle/gen_ref_leapfrog.py`` /
+  ``oracle/gen_ref_example.py``): ``_adapt_timestep`` (``hmc.py:183-191``), the
+  sampler's attribute plumbing, and the EXAMPLE's arithmetic -- the method bodies of
+  ``binf/example/likelihood.py:24-30,54-61`` and ``priors.py:23-25,49-54`` compiled
+  unchanged and called with a data-only ``self``, class ``RWMCSampler``
+  (``samplers.py:54-92``) as it stands, ``GammaSampler``'s shape / rate / sample
+  (``samplers.py:27-51``; only the Python-2-only ``_get_prior`` replaced) -- incl. two
+  whole chains of ``example_script.py`` that ``ref_example.example_script_chain``
+  reproduces bit for bit (``tests/test_ref_example.py``).
 * Still **parity unpinned**: ``HMCSampler.sample`` beyond the integrator -- the
   energies ``V(q) + 0.5 * np.sum(p ** 2)``, the accept test through
   ``csb.numeric.exp`` and the adaption (``hmc.py:136-164,183-191``): no reference

@@ -11,8 +11,12 @@ exactly the operations the reference classes would perform:
   priors of make_priors()        binf/example/priors.py:66-73
 
 Parity status: the plumbing rules are pinned by the reference's test
-known-answers (tests/test_host_mirror.py); the numerics are **parity
-unpinned** (the reference never runs HMC and cannot be imported here).
+known-answers (tests/test_host_mirror.py); ``example_script_chain`` (RWMC + Gamma,
+the reference's own wiring) is pinned bit for bit by states the reference's own
+RWMCSampler / GammaSampler classes produced (tests/golden/ref_example_chain_*.npz,
+oracle/gen_ref_example.py); ``gibbs_hmc_chain`` inherits the status of
+HMCSampler.sample: integrator pinned by reference output, energies + accept test
+**parity unpinned** (csb's exp is absent).
 
 Quirk Q6 is reproduced: the GammaPrior inside every CONDITIONAL posterior is a
 clone built with (shape, shape) (binf/example/priors.py:27-32), so both the
