@@ -234,6 +234,25 @@ def main():
                                  'last_draw_stats_values': list(s.last_draw_stats['HMC'])},
                 'named': {'variable_name': named.variable_name, 'last_draw_stats_keys': list(named.last_draw_stats)},
                 'copy_state': {'equal': bool(np.array_equal(copy, s.state)), 'same_object': copy is s.state}}
+    # BinfState (binf/samplers/__init__.py:9-57) is a plain object class too: the module's two
+    # csb import statements (:5-6, names BinfState never touches) are dropped the same way
+    with open('/root/reference/binf/samplers/__init__.py') as f:
+        tree = ast.parse(f.read())
+    n_before = len(tree.body)
+    tree.body = [n for n in tree.body if not (isinstance(n, ast.ImportFrom) and (n.module or '').split('.')[0] == 'csb')]
+    assert n_before - len(tree.body) == 2
+    smod = types.ModuleType('binf_reference_samplers')
+    exec(compile(tree, 'binf/samplers/__init__.py', 'exec'), smod.__dict__)
+    st = smod.BinfState({'b': 2.0, 'a': 1.0})
+    view = st.variables
+    view['a'] = 99.0                                    # a COPY: the state must not change
+    st.update_variables(c=3.0, a=1.5)
+    st.update_momenta(a=-1.0)
+    plumbing['binf_state'] = {'variables_after_update': dict(st.variables), 'copy_is_detached': st.variables['a'] == 1.5,
+                              'view_after_write': view, 'momenta': dict(st.momenta),
+                              'fresh_is_empty': smod.BinfState().variables == {} and smod.BinfState().momenta == {},
+                              'provenance': 'BinfState of binf/samplers/__init__.py:9-57 executed from its source with '
+                                            'the two csb import statements (:5-6) dropped; nothing substituted'}
     path = os.path.join(OUT, 'ref_hmc_attributes.json')
     with open(path, 'w') as f:
         json.dump(plumbing, f, indent=1, sort_keys=True)

@@ -513,3 +513,23 @@ def test_hmc_sampler_attributes_follow_the_reference_run():
     # quirk Q1, as the reference: sample() with variable_name None fails with a TypeError
     with pytest.raises(TypeError):
         s.sample()
+
+
+def test_binf_state_follows_the_reference_run():
+    """BinfState (binf/samplers/__init__.py:9-57) executed from the reference's source (its two csb
+    import statements dropped): `.variables` is a COPY, updates merge, momenta likewise -- this
+    package's BinfState answers the same."""
+    import json
+    import os
+    from binf_amd.samplers import BinfState
+    from conftest import GOLDEN_DIR
+    ref = json.load(open(os.path.join(GOLDEN_DIR, 'ref_hmc_attributes.json')))['binf_state']
+    st = BinfState({'b': 2.0, 'a': 1.0})
+    view = st.variables
+    view['a'] = 99.0
+    st.update_variables(c=3.0, a=1.5)
+    st.update_momenta(a=-1.0)
+    assert dict(st.variables) == ref['variables_after_update']
+    assert (st.variables['a'] == 1.5) is ref['copy_is_detached']
+    assert view == ref['view_after_write'] and dict(st.momenta) == ref['momenta']
+    assert (BinfState().variables == {} and BinfState().momenta == {}) is ref['fresh_is_empty']
