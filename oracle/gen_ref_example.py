@@ -23,13 +23,17 @@ CAN run, unchanged, is the arithmetic these classes are made of:
   that returns the precision prior directly -- which is what the reference's method does after
   printing it.
 
-Around them this script supplies what the reference's csb-based classes would have supplied: the
-chain rule of ``Likelihood`` (``binf/pdf/likelihoods.py:141-155``: error-model log-prob of the forward
-model's output; ``dfm.dot(emgrad)``), the Posterior's sum over components in sorted-name order
-(``posteriors.py:147-151``; quirk Q5) and the Gibbs sweep (``gibbs.py:136-151``: alphabetical,
+The glue is the reference's own wherever it is free of csb and of Python-2-only calls: the method
+bodies of ``Likelihood._split_variables / _evaluate_log_prob / _evaluate_gradient``
+(``binf/pdf/likelihoods.py:122-155``) and of the Posterior's log-prob
+(``_get_component_variables_list / _evaluate_components / _evaluate_log_prob``,
+``posteriors.py:117-151``) are compiled unchanged as well and run over duck-typed models /
+components.  What this script supplies itself: the ORDER of the Posterior's components (sorted
+name -- quirk Q5: the reference's is Python-2 hash order), the completion of fixed variables
+(``binf/pdf/__init__.py:153-160``), and the Gibbs sweep (``gibbs.py:136-151``: alphabetical,
 conditionals refreshed from the state; quirk Q6: the conditional copy of the GammaPrior carries
-rate = shape).  Those three are restatements and stay pinned only by the reference's unit-test
-known answers; the arithmetic inside them is the reference's own.
+rate = shape) -- ``GibbsSampler`` itself derives from a csb class.  Those stay pinned by the
+reference's unit-test known answers.
 
 Pinned by these fixtures (see tests/test_ref_example.py): Horner via the callable of
 ``example_script.py:21``, the design matrix, the Gaussian error model's log-prob and gradient in the
@@ -54,9 +58,11 @@ PROVENANCE = ('outputs of the REFERENCE\'s example code executed from its own so
               'definitions compiled unchanged, called with a data-only self), class RWMCSampler '
               '(samplers.py:54-92, unchanged) and GammaSampler._calculate_shape/_calculate_rate/'
               'sample (samplers.py:27-51, unchanged; the Python-2-only _get_prior replaced by a '
-              'method returning the prior); csb absent, nothing substituted for it; Likelihood chain '
-              'rule, Posterior sum order and Gibbs sweep supplied by oracle/gen_ref_example.py; '
-              'numpy %s' % np.__version__)
+              'method returning the prior), glued by the method bodies of Likelihood '
+              '(binf/pdf/likelihoods.py:122-155) and of the Posterior log-prob (posteriors.py:117-151), '
+              'unchanged, over duck-typed components; csb absent, nothing substituted for it; the '
+              'component order (sorted name, Q5), the completion of fixed variables and the Gibbs '
+              'sweep supplied by oracle/gen_ref_example.py; numpy %s' % np.__version__)
 
 
 def method(path, cls, name):
@@ -111,6 +117,65 @@ def main():
     gamma_logp = method(pri_py, 'GammaPrior', '_evaluate_log_prob')
     gauss_logp = method(pri_py, 'GaussianPrior', '_evaluate_log_prob')
     polynomial = np.polynomial.polynomial.polyval            # example_script.py:21
+    # ... and the glue they sit in, as far as it is free of csb and of Python-2-only calls: the
+    # method bodies of Likelihood (binf/pdf/likelihoods.py:122-155) and of the Posterior's log-prob
+    # (binf/pdf/posteriors.py:117-151), given duck-typed components
+    pdf_lik_py, post_py = '/root/reference/binf/pdf/likelihoods.py', '/root/reference/binf/pdf/posteriors.py'
+
+    class FwmDuck(object):
+        variables = {'coefficients'}
+
+        def __init__(self, data):
+            self.data = data
+
+        def __call__(self, coefficients):
+            return fwm_eval(self.data, coefficients)
+
+        def jacobi_matrix(self, coefficients):
+            return fwm_jac(self.data, coefficients)
+
+    class EmDuck(object):
+        variables = {'mock_data', 'precision'}
+
+        def __init__(self, data):
+            self.data = data
+            self.ys = data.ys
+
+        def log_prob(self, mock_data, precision):
+            return em_logp(self.data, mock_data, precision)
+
+        def gradient(self, mock_data, precision):
+            return em_grad(self.data, mock_data, precision)
+
+    class RefLikelihood(object):
+        """The reference's Likelihood arithmetic: its own _split_variables / _evaluate_log_prob /
+        _evaluate_gradient bodies around duck-typed models."""
+        _split_variables = method(pdf_lik_py, 'Likelihood', '_split_variables')
+        _evaluate_log_prob = method(pdf_lik_py, 'Likelihood', '_evaluate_log_prob')
+        _evaluate_gradient = method(pdf_lik_py, 'Likelihood', '_evaluate_gradient')
+        variables = {'coefficients', 'precision'}
+
+        def __init__(self, fwm, em):
+            self.forward_model, self.error_model = fwm, em
+
+        def log_prob(self, **variables):                 # AbstractBinfPDF.log_prob minus csb's bookkeeping
+            return self._evaluate_log_prob(**variables)
+
+        def gradient(self, **variables):
+            return self._evaluate_gradient(**variables)
+
+    class RefPosteriorSum(object):
+        """The reference's Posterior log-prob arithmetic: its own _get_component_variables_list /
+        _evaluate_components / _evaluate_log_prob bodies over duck-typed components held in
+        sorted-name order (Q5: the reference's own order is Python-2 hash order)."""
+        _get_component_variables_list = method(post_py, 'Posterior', '_get_component_variables_list')
+        _evaluate_components = method(post_py, 'Posterior', '_evaluate_components')
+        _evaluate_log_prob = method(post_py, 'Posterior', '_evaluate_log_prob')
+
+        def __init__(self, components):
+            from collections import OrderedDict
+            self._components = OrderedDict((k, components[k]) for k in sorted(components))
+
     os.makedirs(OUT, exist_ok=True)
     written = []
 
@@ -131,10 +196,11 @@ def main():
         gam = Data(shape=1.0, rate=0.2)
         mock = np.stack([fwm_eval(fwm, theta[c]) for c in range(C)])
         jac = fwm_jac(fwm, theta[0])
-        lp = np.array([em_logp(em, mock[c], taus[c]) for c in range(C)])
-        lp1 = np.array([em_logp(em, mock[c], 1.0) for c in range(C)])
+        rlik = RefLikelihood(FwmDuck(fwm), EmDuck(em))
+        lp = np.array([rlik.log_prob(coefficients=theta[c], precision=taus[c]) for c in range(C)])
+        lp1 = np.array([rlik.log_prob(coefficients=theta[c], precision=1.0) for c in range(C)])
         eg = np.stack([em_grad(em, mock[c], taus[c]) for c in range(C)])
-        grad = np.stack([jac.dot(eg[c]) for c in range(C)])            # likelihoods.py:155
+        grad = np.stack([rlik.gradient(coefficients=theta[c], precision=taus[c]) for c in range(C)])  # likelihoods.py:148-155
         path = os.path.join(OUT, 'ref_example_models_%s.npz' % tag)
         np.savez_compressed(
             path, provenance=np.array(PROVENANCE), xs=xs, ys=ys, theta=theta, precision=taus,
@@ -160,36 +226,42 @@ def main():
         def _get_prior(self):                   # stands for samplers.py:14-25 (Python 2 only)
             return self.pdf.priors['precision_prior']
 
-    class Likelihood(object):                   # binf/pdf/likelihoods.py:141-146
-        def __init__(self, fwm, em):
-            self.forward_model, self.error_model = fwm, em
+    class Component(object):
+        """A component of a conditional posterior as the Posterior's loop sees it: its free
+        variables and log_prob(**free); fixed variables are completed from the conditional's
+        current values (AbstractBinfPDF._complete_variables, binf/pdf/__init__.py:153-160)."""
 
-        def log_prob(self, coefficients, precision):
-            return em_logp(self.error_model, fwm_eval(self.forward_model, coefficients), precision)
+        def __init__(self, variables, fn):
+            self.variables, self._fn = variables, fn
+
+        def log_prob(self, **free):
+            return self._fn(**free)
 
     class ConditionalPosterior(dict):
         """The conditional posteriors GibbsSampler installs (gibbs.py:40-52), as far as the two
-        subsamplers look at them: log_prob(coefficients=...) summed over the components in
-        sorted-name order (posteriors.py:147-151, Q5), .likelihoods, .priors, ['coefficients'].value."""
+        subsamplers look at them: log_prob(coefficients=...) through the reference's Posterior
+        arithmetic, .likelihoods, .priors, ['coefficients'].value."""
 
         def __init__(self, lik, cprior, pprior):
             super(ConditionalPosterior, self).__init__()
             self.likelihoods = {'points': lik}
             self.priors = {'coefficients_prior': cprior, 'precision_prior': pprior}
             self.precision = None
+            self._sum = RefPosteriorSum({
+                'coefficients_prior': Component({'coefficients'}, lambda coefficients: gauss_logp(cprior, coefficients)),
+                'points': Component({'coefficients'}, lambda coefficients: lik.log_prob(
+                    coefficients=coefficients, precision=self.precision)),
+                'precision_prior': Component(set(), lambda: gamma_logp(pprior, self.precision))})
 
         def log_prob(self, coefficients):
-            terms = {'coefficients_prior': gauss_logp(self.priors['coefficients_prior'], coefficients),
-                     'points': self.likelihoods['points'].log_prob(coefficients, self.precision),
-                     'precision_prior': gamma_logp(self.priors['precision_prior'], self.precision)}
-            return np.sum([terms[k] for k in sorted(terms)])
+            return self._sum._evaluate_log_prob(coefficients=coefficients)
 
     for tag, seed, sweeps, stepsize, N in [('seed0', 0, 300, 0.1, 20), ('seed7_n50', 7, 120, 0.05, 50)]:
         np.random.seed(seed)
         real = np.array([2.0, -4.0, 1.0, 1.5])
         xs = np.linspace(-2, 2, N)
         ys = np.random.normal(loc=polynomial(xs, real), scale=1.0 / np.sqrt(2.5))      # example_script.py:22-23
-        lik = Likelihood(Data(xses=xs, polynomial=polynomial), Data(ys=ys))
+        lik = RefLikelihood(FwmDuck(Data(xses=xs, polynomial=polynomial)), EmDuck(Data(ys=ys)))
         cprior = Data({'means': Value(np.zeros(4)), 'variances': Value(np.ones(4) * 5)})  # priors.py:70
         # Q6: the conditional copies are made by GammaPrior.clone -> (shape, shape)
         pprior = Data(shape=1.0, rate=1.0)

@@ -7,9 +7,10 @@ Gaussian error model and the two priors (``binf/example/likelihood.py:24-30,54-6
 ``self``; its ``RWMCSampler`` class (``samplers.py:54-92``) executed as it stands; its
 ``GammaSampler._calculate_shape / _calculate_rate / sample`` (``samplers.py:27-51``) as they stand
 (the Python-2-only ``_get_prior`` replaced by a method that returns the prior).  csb is absent and
-nothing is substituted for it.  The Likelihood chain rule, the Posterior's sum order and the Gibbs
-sweep around them are the generating script's (restatements, pinned by the reference's unit-test
-known answers).
+nothing is substituted for it.  They are glued by the reference's own Likelihood / Posterior log-prob
+method bodies (``binf/pdf/likelihoods.py:122-155``, ``posteriors.py:117-151``) over duck-typed
+components; the generating script supplies the component order (sorted name, Q5), the completion of
+fixed variables and the Gibbs sweep.
 
 CPU: the numpy restatement reproduces every file bit for bit.  The HIP kernels are held to the same
 files in ``tests/test_gpu_ref_example.py``."""
