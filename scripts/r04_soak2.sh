@@ -1,0 +1,17 @@
+# second round-4 soak: other seeds, more cases (about 15 minutes of GPU time)
+set -o pipefail
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/${1:-r04_soak2}
+mkdir -p $O
+step() {                                  # step <seconds> <name> <args...>
+    local secs=$1 name=$2; shift 2
+    timeout -k 10 $secs python3 tests/soak/$name.py "$@" > $O/$name.log 2>&1
+    local rc=$?
+    echo "$name rc=$rc" | tee -a $O/rc.txt
+    tail -1 $O/$name.log
+    return $rc
+}
+step 400 fuzz_models 1500 91 && step 400 fuzz_gauss 20000 92 && step 200 fuzz_reductions 12000 93 && step 300 fuzz_gibbs_n 25000 94
+rc=$?
+grep -c MISMATCH $O/*.log || true
+exit $rc
