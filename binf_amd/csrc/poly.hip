@@ -322,7 +322,7 @@ __global__ void __launch_bounds__(256) poly_grad_mfma_kernel(const GradArgs a)
 // them sustains 70.8 TFLOP/s (71 cycles per MFMA and SIMD at 2.39 GHz, 0.90 of the
 // 78.6 datasheet figure); every VALU instruction a wave adds -- FP64, FP32, integer,
 // v_mov alike -- costs the SIMD's matrix pipe another 3.4 - 5.9 cycles, whereas idle
-// cycles and ds_read are hidden.  The general kernel issues ~130 VALU instructions
+// cycles and ds_read are hidden.  The general kernel issues ~100 VALU instructions
 // per 32 MFMAs (address arithmetic for the prefetch and both LDS buffers, AGPR
 // read-back of the forward accumulators, tail selects): 56 - 59 TFLOP/s.  Here:
 //   * the tile loop is unrolled over the two LDS buffers, so every LDS address is a
