@@ -127,7 +127,9 @@ def main(argv=None):
 
     coeffs = store_c.gather(args.chains)           # [n_kept, chains, 4] on every rank
     prec = store_p.gather(args.chains)
-    if rank == 0:
+    if rank == 0 and coeffs.shape[0] == 0:
+        print('no draw kept: --iterations {} does not exceed --burn-in {}'.format(args.iterations, args.burn_in))
+    elif rank == 0:
         c = coeffs.reshape(-1, 4)
         print('kept {} draws x {} chains'.format(coeffs.shape[0], coeffs.shape[1]))
         print('true coefficients     :', real_coeffs, ' precision', real_precision)
