@@ -64,7 +64,35 @@ def load_reference_sampler():
     mod = types.ModuleType('binf_reference_hmc')
     exec(compile(tree, REFERENCE_HMC, 'exec'), mod.__dict__)
     assert 'exp' not in mod.__dict__
+    _split_sample(tree, mod)
     return mod.HMCSampler
+
+
+def _split_sample(tree, mod):
+    """``HMCSampler.sample`` (hmc.py:136-164) needs csb in ONE statement, ``acc =
+    np.random.uniform() < exp(-(E_after - E_before))`` (:151).  Its other statements are
+    compiled unchanged as two methods of the reference class: ``sample_until_accept(self)``
+    = the statements before it (:143-150: the energy function, the copy of the state, the
+    momentum draw, E_before, the leapfrog call, E_after) returning their local variables,
+    and ``sample_after_accept(self, acc, q)`` = the statements after it (:153-164: the
+    bookkeeping, the adaption check, the state replacement, the returned copy).  Nothing
+    is written for line 151 itself: the caller draws the uniform the reference draws
+    there and passes an accept flag in."""
+    cls = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == 'HMCSampler')
+    fn = next(n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name == 'sample')
+    body = [n for n in fn.body if not (isinstance(n, ast.Expr) and isinstance(getattr(n, 'value', None), ast.Constant))]
+    at = next(i for i, n in enumerate(body) if isinstance(n, ast.Assign) and
+              getattr(n.targets[0], 'id', None) == 'acc')
+    assert 'exp' in ast.dump(body[at]) and at == 6 and len(body) == 11, (at, len(body))
+    before = ast.parse('def sample_until_accept(self):\n    pass').body[0]
+    before.body = body[:at] + ast.parse('return E_before, E_after, q, p').body
+    after = ast.parse('def sample_after_accept(self, acc, q):\n    pass').body[0]
+    after.body = body[at + 1:]
+    helper = ast.Module(body=[before, after], type_ignores=[])
+    ast.fix_missing_locations(helper)
+    exec(compile(helper, REFERENCE_HMC + ':sample[split at :151]', 'exec'), mod.__dict__)
+    mod.HMCSampler.sample_until_accept = mod.__dict__.pop('sample_until_accept')
+    mod.HMCSampler.sample_after_accept = mod.__dict__.pop('sample_after_accept')
 
 
 # -- duck-typed PDFs (numpy, one chain) ------------------------------------------------------
@@ -76,6 +104,9 @@ class Gaussian(object):
 
     def gradient(self, x):
         return self.k * (x - self.x0)
+
+    def log_prob(self, x):                      # binf/pdf/__init__.py:185
+        return -0.5 * self.k * np.sum((x - self.x0) ** 2)
 
 
 class PolyCoefficients(object):
@@ -212,6 +243,53 @@ def main():
             accepted=flags, timestep0=np.float64(dt0), uprate=np.float64(up), downrate=np.float64(down),
             timesteps=steps)
         written.append(os.path.basename(path))
+    # ---- sample() itself, every statement but the one that needs csb (see _split_sample) ------
+    for tag, D, L, k, x0, dt, C, ncalls, limit, seed in [
+            ('gauss_d4_l1', 4, 1, 1.0, 0.0, 0.30, 8, 3, 0, 600),
+            ('gauss_d33_l20_k2p5', 33, 20, 2.5, 0.3, 0.35, 8, 3, 0, 610),
+            ('gauss_d33_l2_adapt', 33, 2, 1.0, 0.0, 0.70, 8, 5, 4, 620),
+            ('gauss_d200_l20', 200, 20, 1.0, -0.2, 0.30, 4, 2, 0, 630),
+            ('gauss_d1024_l20', 1024, 20, 1.0, 0.0, 0.22, 6, 3, 0, 640),
+            ('gauss_d1024_l5_adapt', 1024, 5, 2.5, 0.3, 0.30, 4, 4, 10, 650),
+            ('gauss_d9000_l3', 9000, 3, 1.0, 0.0, 0.02, 2, 2, 0, 660)]:
+        q0 = np.random.RandomState(seed).standard_normal((C, D))
+        rec = {n: [] for n in ('p0', 'u', 'e_before', 'e_after', 'accepted', 'state', 'timestep',
+                               'counter', 'n_accepted', 'proposal')}
+        for c in range(C):
+            np.random.seed(seed + 1 + c)                    # chain c consumes its own legacy stream
+            s = Sampler(Gaussian(k, x0), q0[c].copy(), dt, L, timestep_adaption_limit=limit, variable_name='x')
+            row = {n: [] for n in rec}
+            for _ in range(ncalls):
+                stream = np.random.get_state()
+                e_b, e_a, q, p = s.sample_until_accept()                       # hmc.py:143-150
+                shadow = np.random.RandomState()
+                shadow.set_state(stream)
+                row['p0'].append(shadow.normal(size=D))                       # the draw of :146, replayed
+                u = np.random.uniform()                                        # the draw of :151
+                # the accept flag: the ONE thing not computed by reference code (csb's exp is absent);
+                # numpy's exp of the reference's own energies (|dE| is far inside any clip bound here)
+                acc = bool(u < np.exp(-(e_a - e_b)))
+                ret = s.sample_after_accept(acc, q)                            # hmc.py:153-164
+                assert ret is not s.state and np.array_equal(ret, s.state)    # a copy (Q9)
+                for n, v in (('u', u), ('e_before', e_b), ('e_after', e_a), ('accepted', acc),
+                             ('state', s.state.copy()), ('timestep', s.timestep), ('counter', s.counter),
+                             ('n_accepted', s.n_accepted), ('proposal', q.copy())):
+                    row[n].append(v)
+            for n in rec:
+                rec[n].append(np.array(row[n]))
+        path = os.path.join(OUT, 'ref_sample_%s.npz' % tag)
+        np.savez_compressed(
+            path, provenance=np.array(PROVENANCE.replace(
+                "HMCSampler._leapfrog (binf/samplers/hmc.py:92-125)",
+                "HMCSampler.sample (binf/samplers/hmc.py:136-164), every statement but :151 -- split there into "
+                "the statements before (:143-150) and after (:153-164); the accept flag passed in is u < "
+                "numpy.exp(-(E_after - E_before)) of the reference's own energies, computed by the generating "
+                "script --") + '; chain c: np.random.seed(seed + 1 + c)'),
+            kind=np.array('gauss'), q0=q0, k=np.float64(k), x0=np.float64(x0), timestep0=np.float64(dt),
+            nsteps=np.int64(L), adaption_limit=np.int64(limit), seed=np.int64(seed),
+            **{n: np.array(v) for n, v in rec.items()})                        # [C, ncalls, ...]
+        written.append(os.path.basename(path))
+
     # the csb-free attribute plumbing of the reference's class (hmc.py:56-90,127-134,166-181):
     # what GibbsSampler and user code read from a sampler
     import json

@@ -158,3 +158,49 @@ def test_adaption_follows_the_reference_run_bitwise(device, path, D):
         s._last_move_accepted = torch.from_numpy(flags[:, i]).to(device)
         s._adapt_timestep()
         assert np.array_equal(s.timestep.cpu().numpy(), want[:, i]), i
+
+
+@pytest.mark.parametrize('path', golden_files('ref_sample_'), ids=lambda p: p.split('ref_sample_')[-1][:-4])
+def test_whole_transitions_vs_the_reference_run_sample(device, path):
+    """``tests/golden/ref_sample_*.npz``: the reference's own ``sample()`` run statement by statement
+    (all but the csb line :151; see tests/test_ref_leapfrog.py) with the draws it made recorded.  The
+    fused kernels -- persistent kernel (one call per transition, and all transitions in one launch),
+    long-chain path for D = 9000 -- fed with those draws return the reference's energies, accept
+    flags, states, adapted step sizes and counters bit for bit."""
+    g = load_golden(path)
+    C, ncalls, D = g['p0'].shape
+    k, x0, L = float(g['k']), float(g['x0']), int(g['nsteps'])
+    limit, dt0 = int(g['adaption_limit']), float(g['timestep0'])
+    p0 = dev_t(np.swapaxes(g['p0'], 0, 1), device)                  # [ncalls, C, D]
+    u = dev_t(g['u'].T, device)                                     # [ncalls, C]
+
+    def sampler():
+        return HMCSampler(IsotropicGaussian(k, x0), dev_t(g['q0'], device), dt0, L,
+                          timestep_adaption_limit=limit, variable_name='x', record_energies=True)
+    s = sampler()
+    for i in range(ncalls):
+        out = s.sample(p0=p0[i], u=u[i])
+        assert np.array_equal(s.last_e_before.cpu().numpy(), g['e_before'][:, i]), i
+        assert np.array_equal(s.last_e_after.cpu().numpy(), g['e_after'][:, i]), i
+        assert np.array_equal(s.last_move_accepted.cpu().numpy(), g['accepted'][:, i]), i
+        assert np.array_equal(out.cpu().numpy(), g['state'][:, i]), i
+        ts = s.timestep
+        ts = ts.cpu().numpy() if isinstance(ts, torch.Tensor) else np.full(C, ts)
+        assert np.array_equal(ts, g['timestep'][:, i]), i
+        assert s.counter == int(g['counter'][0, i])
+        assert np.array_equal(s.n_accepted.cpu().numpy(), g['n_accepted'][:, i])
+    s = sampler()
+    rec = s.sample_n(ncalls, p0=p0, u=u)
+    assert np.array_equal(rec.cpu().numpy(), np.swapaxes(g['state'], 0, 1))
+    assert np.array_equal(s.accepted_history.cpu().numpy(), g['accepted'].T)
+    assert np.array_equal(s.last_e_after.cpu().numpy(), g['e_after'].T)
+    ts = s.timestep
+    ts = ts.cpu().numpy() if isinstance(ts, torch.Tensor) else np.full(C, ts)
+    assert np.array_equal(ts, g['timestep'][:, -1])
+    # ... and the per-step tier (any pdf.gradient / pdf.log_prob): the same bits
+    s = sampler()
+    s.pdf.native_hmc_spec = lambda name: None
+    for i in range(ncalls):
+        out = s.sample(p0=p0[i], u=u[i])
+        assert np.array_equal(out.cpu().numpy(), g['state'][:, i]), i
+        assert np.array_equal(s.last_e_after.cpu().numpy(), g['e_after'][:, i]), i

@@ -109,3 +109,53 @@ def test_restatements_reproduce_the_reference_adaption_bitwise(path):
         assert np.array_equal(out['accepted'].astype(bool), flags[:, i])
         dts = out['timestep_out']
         assert np.array_equal(dts, want[:, i]), i
+
+
+SAMPLES = golden_files('ref_sample_')
+
+
+@pytest.mark.parametrize('path', SAMPLES, ids=lambda p: p.split('ref_sample_')[-1][:-4])
+def test_restatements_reproduce_the_reference_sample_bitwise(path):
+    """``HMCSampler.sample`` (hmc.py:136-164) run from the reference's own source, statement by
+    statement, except the ONE statement that needs csb (``acc = np.random.uniform() < exp(...)``,
+    :151; oracle/gen_ref_leapfrog.py:_split_sample): the momentum draw, E_before, the trajectory,
+    E_after, then -- with the accept flag the fixture records -- the bookkeeping, the adaption
+    check AFTER the counter increment, the state replacement and the returned copy.
+
+    The numpy and the C restatement run their WHOLE sample() (their own accept test included) on
+    the recorded draws and land on the same energies, flags, states, step sizes and counters, bit
+    for bit: what remains unpinned in sample() is csb's ``exp`` alone."""
+    g = load_golden(path)
+    assert 'every statement but :151' in str(g['provenance'])
+    C, ncalls, D = g['p0'].shape
+    k, x0, L = float(g['k']), float(g['x0']), int(g['nsteps'])
+    limit, dt0 = int(g['adaption_limit']), float(g['timestep0'])
+    for c in range(C):
+        draws = {'i': 0}
+        s = R.RefHMCSampler(R.GaussianPDF(k, x0), g['q0'][c].copy(), dt0, L, timestep_adaption_limit=limit,
+                            variable_name='x', normal=lambda size: g['p0'][c, draws['i']].copy(),
+                            uniform=lambda: g['u'][c, draws['i']])
+        for i in range(ncalls):
+            draws['i'] = i
+            ret = s.sample()
+            assert s.last_E_before == g['e_before'][c, i] and s.last_E_after == g['e_after'][c, i], (c, i)
+            assert bool(s.last_move_accepted) == bool(g['accepted'][c, i])
+            assert np.array_equal(s.state, g['state'][c, i]) and np.array_equal(ret, g['state'][c, i])
+            assert ret is not s.state
+            assert s.timestep == g['timestep'][c, i] and s.counter == g['counter'][c, i]
+            assert s.n_accepted == g['n_accepted'][c, i]
+    # the C restatement, all chains at once, call by call (adaption while counter < limit, hmc.py:156)
+    q = g['q0'].copy()
+    dts = np.full(C, dt0)
+    for i in range(ncalls):
+        out = c_oracle.hmc_sample_gauss(q, g['p0'][:, i], g['u'][:, i], dts, L, k=k, x0=x0,
+                                        adapt=(i + 1) < limit)
+        assert np.array_equal(out['accepted'].astype(bool), g['accepted'][:, i])
+        assert np.array_equal(out['e_before'], g['e_before'][:, i]) and np.array_equal(out['e_after'], g['e_after'][:, i])
+        assert np.array_equal(out['q_out'], g['state'][:, i])
+        dts = out['timestep_out']
+        assert np.array_equal(dts, g['timestep'][:, i])
+        q = out['q_out']
+    # the reference drew the momentum it recorded: the stream replay is consistent
+    np.random.seed(int(g['seed']) + 1)
+    assert np.array_equal(np.random.normal(size=D), g['p0'][0, 0]) and np.random.uniform() == g['u'][0, 0]
