@@ -33,11 +33,16 @@ PARITY PINNING STATUS (read before trusting a comparison against this):
   (``samplers.py:27-51``; only the Python-2-only ``_get_prior`` replaced) -- incl. two
   whole chains of ``example_script.py`` that ``ref_example.example_script_chain``
   reproduces bit for bit (``tests/test_ref_example.py``).
-* Still **parity unpinned**: ``HMCSampler.sample`` beyond the integrator -- the
-  energies ``V(q) + 0.5 * np.sum(p ** 2)``, the accept test through
-  ``csb.numeric.exp`` and the adaption (``hmc.py:136-164,183-191``): no reference
-  test runs them, and ``exp`` is absent (its clip bounds are restated from CSB's
-  published source from memory).  The other golden ``.npz`` files under
-  ``tests/golden/`` (``gauss_*``, ``poly_*``, ``dist_*``) are outputs of THIS
+* ``HMCSampler.sample`` (``hmc.py:136-164``) is pinned the same way for every statement
+  but one: ``oracle/gen_ref_leapfrog.py:_split_sample`` compiles the statements before
+  (``:143-150``) and after (``:153-164``) the csb line ``acc = np.random.uniform() <
+  exp(-(E_after - E_before))`` (``:151``) unchanged as two methods of the reference class;
+  the accept flag passed in between is ``u < numpy.exp(...)`` of the reference's own
+  energies.  ``tests/golden/ref_sample_*.npz``; ``RefHMCSampler.sample`` and ``oracle_c.c``
+  reproduce energies, flags, states, step sizes and counters bit for bit.
+* Still **parity unpinned**: the DEFINITION of ``csb.numeric.exp`` (restated as
+  ``numpy.exp(numpy.clip(x, -308, 709))`` from CSB's published source from memory; the
+  clip matters only for ``|dE|`` beyond the bounds).  The other golden ``.npz`` files
+  under ``tests/golden/`` (``gauss_*``, ``poly_*``, ``dist_*``) are outputs of THIS
   restatement (``oracle/gen_golden.py``), not of the reference.
 """

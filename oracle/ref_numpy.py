@@ -6,8 +6,9 @@ Parity status (see oracle/__init__.py): pinned by the reference's own test
 known-answers for the PDF / Likelihood / Gibbs plumbing; ``_leapfrog``
 (``binf/samplers/hmc.py:92-125``) pinned bit for bit by outputs of the reference's
 own code (``tests/golden/ref_leapfrog_*.npz``, ``oracle/gen_ref_leapfrog.py``);
-**parity unpinned** for the rest of ``sample()`` (``hmc.py:136-164``: energies,
-the accept test through the absent ``csb.numeric.exp``, adaption).
+``sample()`` (``hmc.py:136-164``) pinned statement by statement by
+``tests/golden/ref_sample_*.npz`` except the one csb line (``:151``): **parity
+unpinned** is only the definition of ``csb.numeric.exp`` (clip bounds below).
 
 Every function cites the reference lines (relative to the reference root) it
 restates.  Arithmetic is kept in the reference's operation order so that the
