@@ -30,25 +30,41 @@
 
 namespace binf {
 
-template <int TMAX, bool REGULAR, int LW>
+template <int TMAX, bool REGULAR, int LW, bool UDT = false>
 static hipError_t launch_n_trl(const GaussNArgs &a, bool unit, bool fma, dim3 grid,
                                hipStream_t st)
 {
     constexpr int BS = (LW == 3) ? 512 : 256;
+    constexpr int R = GAUSS_RNG_HBM;
     if (unit) {
-        if (fma) hmc_gauss_persist_kernel<TMAX, REGULAR, true, true, LW><<<grid, BS, 0, st>>>(a);
-        else     hmc_gauss_persist_kernel<TMAX, REGULAR, true, false, LW><<<grid, BS, 0, st>>>(a);
+        if (fma) hmc_gauss_persist_kernel<TMAX, REGULAR, true, true, LW, R, UDT><<<grid, BS, 0, st>>>(a);
+        else     hmc_gauss_persist_kernel<TMAX, REGULAR, true, false, LW, R, UDT><<<grid, BS, 0, st>>>(a);
     } else {
-        if (fma) hmc_gauss_persist_kernel<TMAX, REGULAR, false, true, LW><<<grid, BS, 0, st>>>(a);
-        else     hmc_gauss_persist_kernel<TMAX, REGULAR, false, false, LW><<<grid, BS, 0, st>>>(a);
+        if (fma) hmc_gauss_persist_kernel<TMAX, REGULAR, false, true, LW, R, UDT><<<grid, BS, 0, st>>>(a);
+        else     hmc_gauss_persist_kernel<TMAX, REGULAR, false, false, LW, R, UDT><<<grid, BS, 0, st>>>(a);
     }
     return hipGetLastError();
+}
+
+// One step size for the whole batch and no adaption in this launch: the UDT instantiation
+// (hmc_gauss_kernel.hpp) -- built for the regular one-wave-per-chain shapes, where the
+// vector registers it frees are worth ~3 %; every other launch reads `timestep` per lane.
+static bool gauss_uniform_dt(const GaussNArgs &a)
+{
+    static int off = -1;
+    if (off < 0) {
+        const char *e = getenv("BINF_GAUSS_UNIFORM_DT");     // development aid: =0 disables
+        off = (e && e[0] == '0') ? 1 : 0;
+    }
+    return !off && a.dt_chain == nullptr && a.n_adapt == 0;
 }
 
 template <int TMAX>
 static hipError_t launch_n_t(const GaussNArgs &a, bool regular, bool unit, bool fma,
                              dim3 grid, hipStream_t st)
 {
+    if (regular && gauss_uniform_dt(a))
+        return launch_n_trl<TMAX, true, 0, true>(a, unit, fma, grid, st);
     return regular ? launch_n_trl<TMAX, true, 0>(a, unit, fma, grid, st)
                    : launch_n_trl<TMAX, false, 0>(a, unit, fma, grid, st);
 }

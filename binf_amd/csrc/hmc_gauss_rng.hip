@@ -24,7 +24,12 @@ static hipError_t launch_rng(const GaussNArgs &a, const GaussPlan &p, bool unit,
     if (p.LW > 0) return launch_gauss_rng_wide(a, p, RNG, unit, fma, st);   // hmc_gauss_rng_wide.hip
     const dim3 grid((unsigned)((p.blocks + 1) / 2));   // 8 waves per workgroup (gauss_wpb)
     const int t = p.tneed;
+    // one step size for the batch, no adaption: the scalar-register instantiation (UDT,
+    // hmc_gauss_kernel.hpp), as in hmc_gauss.hip
+    const bool udt = RNG == GAUSS_RNG_FUSED && !a.dt_chain && a.n_adapt == 0;
 #define BINF_RNG_CASE(T)                                                            \
+    if (p.regular && t == T && udt)                                                 \
+        return launch_rng_tr<T, true, RNG, 0, RNG == GAUSS_RNG_FUSED>(a, unit, fma, grid, st); \
     return (p.regular && t == T) ? launch_rng_tr<T, true, RNG>(a, unit, fma, grid, st) \
                                  : launch_rng_tr<T, false, RNG>(a, unit, fma, grid, st)
     if (t <= 1) { BINF_RNG_CASE(1); }

@@ -6,17 +6,17 @@
 
 namespace binf {
 
-template <int TMAX, bool REGULAR, int RNG, int LW = 0>
+template <int TMAX, bool REGULAR, int RNG, int LW = 0, bool UDT = false>
 static hipError_t launch_rng_tr(const GaussNArgs &a, bool unit, bool fma, dim3 grid, hipStream_t st)
 {
     if (RNG == GAUSS_RNG_DUMP) {
-        hmc_gauss_persist_kernel<TMAX, REGULAR, true, false, LW, RNG><<<grid, 512, 0, st>>>(a);
+        hmc_gauss_persist_kernel<TMAX, REGULAR, true, false, LW, RNG, UDT><<<grid, 512, 0, st>>>(a);
     } else if (unit) {
-        if (fma) hmc_gauss_persist_kernel<TMAX, REGULAR, true, true, LW, RNG><<<grid, 512, 0, st>>>(a);
-        else     hmc_gauss_persist_kernel<TMAX, REGULAR, true, false, LW, RNG><<<grid, 512, 0, st>>>(a);
+        if (fma) hmc_gauss_persist_kernel<TMAX, REGULAR, true, true, LW, RNG, UDT><<<grid, 512, 0, st>>>(a);
+        else     hmc_gauss_persist_kernel<TMAX, REGULAR, true, false, LW, RNG, UDT><<<grid, 512, 0, st>>>(a);
     } else {
-        if (fma) hmc_gauss_persist_kernel<TMAX, REGULAR, false, true, LW, RNG><<<grid, 512, 0, st>>>(a);
-        else     hmc_gauss_persist_kernel<TMAX, REGULAR, false, false, LW, RNG><<<grid, 512, 0, st>>>(a);
+        if (fma) hmc_gauss_persist_kernel<TMAX, REGULAR, false, true, LW, RNG, UDT><<<grid, 512, 0, st>>>(a);
+        else     hmc_gauss_persist_kernel<TMAX, REGULAR, false, false, LW, RNG, UDT><<<grid, 512, 0, st>>>(a);
     }
     return hipGetLastError();
 }

@@ -191,6 +191,41 @@ def test_per_chain_timestep_and_adaption(device):
     assert np.array_equal(want['timestep_out'][~up], dts[~up] * 0.95)
 
 
+@pytest.mark.parametrize('D,C', [(64, 300), (128, 130), (256, 70), (512, 40), (768, 2100), (1024, 2100)])
+@pytest.mark.parametrize('k,x0,mode', [(1.0, 0.0, _native.MODE_EXACT), (2.5, 0.3, _native.MODE_EXACT),
+                                       (1.0, 0.0, _native.MODE_FMA)])
+def test_uniform_step_size_instantiation_same_bits(device, D, C, k, x0, mode):
+    """Without per-chain step sizes and without adaption the launcher picks the kernel
+    instantiation that keeps the step size in scalar registers (hmc_gauss.hip:
+    gauss_uniform_dt; regular one-wave-per-chain shapes).  Same chains, bit for bit, as
+    the per-lane instantiation (forced here by handing over a dt_chain of equal entries),
+    one transition or several per launch -- and the oracle's (EXACT mode)."""
+    rs = np.random.RandomState(D + C)
+    L, dt, n, thin = 3, 0.17, 4, 2
+    q0, p0, u = rs.standard_normal((C, D)) + x0, rs.standard_normal((n, C, D)), rs.uniform(size=(n, C))
+    uni = run_fused(device, q0, p0[0], u[0], dt, L, k=k, x0=x0, mode=mode)
+    per = run_fused(device, q0, p0[0], u[0], 99.0, L, k=k, x0=x0, mode=mode, dt_chain=np.full(C, dt))
+    assert_bitwise(uni, per)
+    assert 0 < uni['accepted'].sum()
+    if mode == _native.MODE_EXACT:
+        assert_bitwise(uni, c_oracle.hmc_sample_gauss(q0, p0[0], u[0], dt, L, k=k, x0=x0))
+
+    def many(dt_chain, timestep):
+        tq = dev_t(q0, device)
+        out, rec = torch.empty_like(tq), torch.empty((n // thin, C, D), dtype=torch.float64, device=device)
+        acc = torch.empty((n, C), dtype=torch.uint8, device=device)
+        nacc = torch.zeros(C, dtype=torch.int64, device=device)
+        eb, ea = (torch.empty((n, C), dtype=torch.float64, device=device) for _ in range(2))
+        _native.hmc_sample_n_gauss(tq, dev_t(p0, device), dev_t(u, device), out, rec, acc, nacc, eb, ea,
+                                   timestep, dt_chain, L, n, thin, k, x0, 0, 1.05, 0.95, mode)
+        return [t.cpu() for t in (out, rec, acc, nacc, eb, ea)]
+
+    a = many(None, dt)
+    b = many(torch.full((C,), dt, dtype=torch.float64, device=device), 99.0)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+
+
 def test_in_place_state_update(device):
     rs = np.random.RandomState(12)
     C, D, L, dt = 96, 1024, 20, 0.2
