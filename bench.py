@@ -403,6 +403,20 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     args.gpus = world
+    # BINF_BENCH_FORCE_DIST=1: take the N > 1 control flow (process group, per-rank fields,
+    # gathers, the sharded C4 / C5 / strong-C2 legs) with however many ranks there are --
+    # with ONE rank on a one-GPU box this drives every collective of the multi-GPU run
+    # through RCCL itself (profiles/r04_n_*), which a gloo rehearsal cannot
+    multi = world > 1 or os.environ.get('BINF_BENCH_FORCE_DIST') == '1'
+    if multi and world == 1:
+        os.environ['BINF_DIST_NO_SHORTCUT'] = '1'      # binf_amd/dist.py: no one-rank short cut
+    if multi and not in_dist:
+        import socket
+        sock = socket.socket()
+        sock.bind(('127.0.0.1', 0))
+        os.environ.update(RANK='0', LOCAL_RANK='0', WORLD_SIZE='1', MASTER_ADDR='127.0.0.1',
+                          MASTER_PORT=str(sock.getsockname()[1]))
+        sock.close()
     if os.environ.get('BINF_BENCH_DRYRUN') == '1':
         return dry_run(args, rank, world)
     ensure_library()
@@ -423,7 +437,7 @@ def main():
     # HBM traffic of the dominant kernel by PMC, measured live in child runs --
     # BEFORE this process initialises the GPU (rank 0 of a single-GPU run only)
     live_traffic, live_src = None, 'not attempted'
-    if world == 1 and F > 1 and not args.pmc_child and not args.no_pmc:
+    if not multi and F > 1 and not args.pmc_child and not args.no_pmc:
         if under_profiler():
             live_src = 'this process itself runs under a profiler'
         else:
@@ -432,7 +446,7 @@ def main():
             if live_traffic is not None:
                 live_src += '; %.0f s' % (time.perf_counter() - t_p)
     kstats, kstats_src = None, 'not attempted'
-    if world == 1 and not args.pmc_child and not args.no_pmc and not args.no_extra:
+    if not multi and not args.pmc_child and not args.no_pmc and not args.no_extra:
         if under_profiler():
             kstats_src = 'this process itself runs under a profiler'
         else:
@@ -452,7 +466,7 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device('cuda', dev_index)
     dist = None
-    if world > 1:
+    if multi:
         import torch.distributed as dist
         if backend == 'nccl':
             dist.init_process_group('nccl', device_id=dev)
@@ -589,7 +603,7 @@ def main():
     # the single sample() call GibbsSampler.sample() drives (gibbs.py:148): one transition per
     # launch, same kernel family -- reported beside the F-transition launch
     single = None
-    if F > 1 and world == 1 and not args.pmc_child and not args.no_single_call:
+    if F > 1 and not multi and not args.pmc_child and not args.no_single_call:
         s1 = make_sampler(args.mode)
         for i in range(min(8, F)):
             s1.sample(p0=p_bufs[0][i], u=u_bufs[0][i])
@@ -616,7 +630,7 @@ def main():
     # Outside the metric: the same workload in the other arithmetic mode ('fma'
     # contracts each multiply-add; within 1e-10 of 'exact', not bit-identical).
     other = None
-    if world == 1 and not args.no_other_mode:
+    if not multi and not args.no_other_mode:
         om = 'fma' if args.mode == 'exact' else 'exact'
         s2 = make_sampler(om)
         K2 = min(K, 8)
@@ -671,7 +685,7 @@ def main():
     # in a weak-scaling run -- the C2 job of FIXED size (--chains in all) sharded over the same
     # ranks: SURVEY 8(e)'s secondary, strong-scaling figure from the same invocation.
     legs = None
-    if world > 1 and not args.no_legs and not args.no_extra:
+    if multi and not args.no_legs and not args.no_extra:
         del p_bufs, u_bufs, rec_bufs
         torch.cuda.empty_cache()
         from scripts import bench_legs
@@ -797,7 +811,7 @@ def main():
             res['sample_gather_bytes_per_rank'] = C * D * 8
             res['ranks'] = per_rank
         if sustained is not None:
-            res['value_sustained'] = sustained['value_per_gpu'] * world if world == 1 else \
+            res['value_sustained'] = sustained['value_per_gpu'] * world if not multi else \
                 sum(r['sustained_value'] for r in per_rank)
             res['sustained'] = {'launches': sustained['launches'], 'ms': sustained['ms'],
                                 'what': 'the same launches for >= %g ms right after the timed steps '
@@ -805,7 +819,7 @@ def main():
                                         'the ranks)' % args.sustain_ms}
         if other is not None:
             res['other_mode'] = other
-        if world == 1 and not args.no_extra:
+        if not multi and not args.no_extra:
             # free the C2 buffers first (the sub-results allocate their own)
             del p_bufs, u_bufs, rec_bufs, sampler
             torch.cuda.empty_cache()
@@ -819,7 +833,7 @@ def main():
             # the polynomial (C4) and pair-distance (C5) legs of this N-GPU run, each with
             # its own sample gather and per-rank figures (scripts/bench_legs.py)
             res['extra'] = legs
-        if world == 1 and not args.no_cpu_baseline:
+        if not multi and not args.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline(D, L, dt, args.cpu_chains,
                                                args.cpu_calls)
         print(json.dumps(res), flush=True)

@@ -11,6 +11,8 @@ draws are recorded into an on-device store, thinned (the reference's own
 script keeps 1 in 20 after burn-in, ``example_script.py:41``), and gathered
 once.
 """
+import os
+
 import torch
 
 
@@ -70,7 +72,10 @@ def gather_chains(local, n_chains_total=None, group=None, async_op=False, dst=No
     ``async_op=True`` returns a :class:`PendingGather` at once: sampling can go on
     while the collective runs (do not overwrite ``local`` before ``wait()``)."""
     dist = _dist()
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()) or \
+            (dist.get_world_size(group) == 1 and os.environ.get('BINF_DIST_NO_SHORTCUT') != '1'):
+        # (BINF_DIST_NO_SHORTCUT=1: a one-rank group still goes through the collective -- how a
+        # one-GPU box rehearses the RCCL calls themselves, bench.py BINF_BENCH_FORCE_DIST)
         return PendingGather(None, local, lambda t: t) if async_op else local
     ws = dist.get_world_size(group)
     if dst is not None and not 0 <= int(dst) < ws:

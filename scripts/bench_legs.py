@@ -115,7 +115,7 @@ def run_leg(leg, comm, sweeps, warm=3, thin=5, settle_s=0.1, gather_reps=3):
 
     # the exchange step: the recorded draws to rank 0, timed beside the metric
     gather = None
-    if comm.world > 1:
+    if comm.dist is not None:
         wire = store if comm.backend == 'nccl' else store.to('cpu')
         got = wire.gather(leg.n_chains_total, dst=0)
         shape_ok = (got is None) if comm.rank != 0 else \

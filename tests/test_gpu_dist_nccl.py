@@ -46,6 +46,22 @@ def test_rccl_single_rank_collectives(device):
             st.record(x)
             st.record(x + 1)
             assert st.gather(4).shape == (2, 4, 3)
+            # ... and the same calls with the one-rank short cut of binf_amd/dist.py switched
+            # off: gather_chains / SampleStore.gather now issue dist.gather(dst=0) and
+            # all_gather_into_tensor on RCCL (sync and async), as every rank of an N-GPU run does
+            os.environ['BINF_DIST_NO_SHORTCUT'] = '1'
+            try:
+                assert torch.equal(gather_chains(x, 4), x)
+                assert torch.equal(gather_chains(x, 4, dst=0), x)
+                assert torch.equal(gather_chains(x, 4, dst=0, async_op=True).wait(), x)
+                assert torch.equal(gather_chains(x, 4, async_op=True).wait(), x)
+                got = st.gather(4, dst=0)
+                assert got.shape == (2, 4, 3) and torch.equal(got[1], x + 1)
+                objs = [None]
+                dist.all_gather_object(objs, {'rank': 0, 'value': 1.5})   # bench.py's per-rank fields
+                assert objs == [{'rank': 0, 'value': 1.5}]
+            finally:
+                del os.environ['BINF_DIST_NO_SHORTCUT']
         finally:
             dist.destroy_process_group()
     finally:
