@@ -396,6 +396,7 @@ def c2_strong_leg(args, comm, dev, F, thin, D, L, launches=10):
 def main():
     argv = sys.argv[1:]
     args = parse(argv)
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')   # dmabuf IPC only on this pool (RCCL)
     in_dist = 'WORLD_SIZE' in os.environ and 'RANK' in os.environ
     if args.gpus > 1 and not in_dist:
         self_launch(args, argv)
