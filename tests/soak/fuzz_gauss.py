@@ -22,7 +22,7 @@ rs = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 t0 = time.time()
 bad = 0
 for case in range(n_cases):
-    kind = rs.randint(6)
+    kind = rs.randint(7)
     if kind == 0:
         D = int(rs.randint(1, 130))
     elif kind == 1:
@@ -33,9 +33,13 @@ for case in range(n_cases):
         D = int(rs.randint(1100, 8193))
     elif kind == 4:
         D = int(8 * rs.randint(1, 1025))
-    else:
+    elif kind == 5:
         D = int(rs.randint(7600, 40000))             # ragged 7-level trees, multi-chunk rows (generic tier)
+    else:
+        D = int(rs.choice([64, 128, 256, 512, 768, 1024]))   # regular trees, one wave per chain
     C = int(rs.choice([1, 2, 3, 7, 8, 9, 31, 64, 65, 200, 1030]))
+    if kind == 6:                                    # enough chains to stay off the split kernel:
+        C = int(rs.choice([2049, 2100, 2817]))       # the scalar-step-size instantiation when limit == 0
     if D * C > 3e6:
         C = max(1, int(3e6 // D))
     L = int(rs.randint(1, 9))
