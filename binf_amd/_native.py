@@ -94,6 +94,7 @@ SIGNATURES = {
     'binf_row_sumsq_diff_f64': (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _f64,
                                        _vp]),
     'binf_poly_forward_f64': (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _vp]),
+    'binf_predictive_density_f64': (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _f64, _vp]),
     'binf_gauss_err_grad_f64': (_i32, [_vp, _vp, _f64, _vp, _vp, _i64, _i64,
                                        _vp]),
     'binf_gauss_err_logp_f64': (_i32, [_vp, _vp, _f64, _vp, _vp, _i64, _i64,
@@ -157,7 +158,7 @@ SIGNATURES = {
                                   ctypes.POINTER(_i32), ctypes.POINTER(_i32)]),
 }
 
-ABI_VERSION = 5        # keep in step with BINF_ABI_VERSION (include/binf_hip.h)
+ABI_VERSION = 6        # keep in step with BINF_ABI_VERSION (include/binf_hip.h)
 
 
 def lib():
@@ -467,6 +468,24 @@ def poly_forward(coeffs, xs):
                                      dptr(xs, numel=N, name='xs'), dptr(out),
                                      C, K, N, stream_handle(coeffs.device))
     check(rc, 'binf_poly_forward_f64')
+    return out
+
+
+@_launcher
+def predictive_density(mock, precision, ys, half_log_2pi):
+    """binf_predictive_density_f64: ``mock`` [S x nx], ``precision`` [S], ``ys``
+    [nx x ny] -> densities [nx x ny] (``binf/example/misc.py:3-16`` for a grid)."""
+    S, nx = _cd(mock)
+    if ys.dim() != 2 or ys.shape[0] != nx:
+        raise ValueError('predictive_density: ys must be [nx x ny] with nx = %d' % nx)
+    ny = ys.shape[1]
+    out = torch.empty((nx, ny), dtype=torch.float64, device=mock.device)
+    rc = lib().binf_predictive_density_f64(dptr(mock, numel=S * nx, name='mock'),
+                                           dptr(precision, numel=S, name='precision'),
+                                           dptr(ys, numel=nx * ny, name='ys'), dptr(out),
+                                           S, nx, ny, float(half_log_2pi),
+                                           stream_handle(mock.device))
+    check(rc, 'binf_predictive_density_f64')
     return out
 
 

@@ -136,6 +136,27 @@ def main(argv=None):
         print('posterior mean (coeff):', c.mean(0).cpu().numpy().round(3))
         print('posterior std  (coeff):', c.std(0).cpu().numpy().round(3))
         print('posterior mean (prec) : {:.3f}'.format(float(prec.mean())))
+        # example_script.py:42 and :50-56 without the drawing: the log-probability of every kept
+        # sample (one batched evaluation), the MAP estimate, and the posterior-predictive tube
+        # over the data range -- predict() for 100 x 150 points x all kept samples in ONE launch
+        # where the reference loops in Python (binf/example/plots.py:10-11)
+        import time
+        from binf_amd.example.misc import prediction_tube
+        p = prec.reshape(-1)
+        log_probs = posterior.log_prob(coefficients=c, precision=p)
+        best = int(torch.argmax(log_probs))
+        map_coeffs = c[best].cpu().numpy()
+        print('MAP coefficients      :', map_coeffs.round(3), ' precision {:.3f}'.format(float(p[best])))
+        space = np.linspace(-2, 2, 100)
+        map_fit = polynomial(space, map_coeffs)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        tube = prediction_tube((c, p), polynomial, space, map_fit - 10, map_fit + 10, 150)
+        dt = time.perf_counter() - t0
+        print('prediction tube       : {} x {} points x {} samples in {:.1f} ms; 90 % interval at x = 0: '
+              '[{:.2f}, {:.2f}], prediction {:.2f} (true curve {:.2f})'.format(
+                  len(space), 150, c.shape[0], dt * 1e3, tube.lower[50], tube.upper[50],
+                  tube.prediction[50], polynomial(space[50], real_coeffs)))
     return coeffs, prec
 
 

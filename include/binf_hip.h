@@ -45,8 +45,10 @@ extern "C" {
  * 5: binf_sum_terms_bcast_f64 (terms that are ONE device double, broadcast: a 0-dim
  *    tensor never has to be read back to the host); binf_hmc_sample_n_gauss_rng_f64 /
  *    binf_hmc_gauss_rng_draws_f64 take one stream position per TRANSITION (offset + i),
- *    as the long-chain entry points always did. */
-#define BINF_ABI_VERSION 5
+ *    as the long-chain entry points always did.
+ * 6: binf_predictive_density_f64 (the consumer side of the sample store: the
+ *    posterior-predictive density over a grid of points in one launch). */
+#define BINF_ABI_VERSION 6
 
 #define BINF_E_ARG        (-1)  /* null pointer / negative size / bad flag    */
 #define BINF_E_UNSUPPORTED (-2) /* shape outside what the kernels cover       */
@@ -670,6 +672,28 @@ int32_t binf_rwmc_accept_f64(const double *proposal, const double *state,
                              uint8_t *accepted, int64_t *n_accepted, int64_t C,
                              int64_t K, uint64_t seed, uint64_t offset,
                              int64_t chain_offset, void *stream);
+
+/* ------------------------------------------------------------------------
+ * Posterior-predictive density of a Gaussian error model over a grid of points,
+ * from S drawn samples: predict (binf/example/misc.py:3-16) for every point of the
+ * [nx x ny] grid that plot_prediction_tube walks with two Python loops
+ * (binf/example/plots.py:8-11) -- one launch.
+ *   out[i,j] = exp(log_sum_exp_s f[s,i,j]) / S                          (misc.py:16)
+ *   f[s,i,j] = -0.5 * (mock[s,i] - ys[i,j])**2 * precision[s]
+ *              + 0.5 * log(precision[s]) - half_log_2pi                  (misc.py:8)
+ *   log_sum_exp(x) = log(sum(exp(x - max(x)))) + max(x)   (csb.numeric.log_sum_exp:
+ *   csb is absent, its published definition; "parity unpinned")
+ * mock [S x nx]: the forward model at predict_space[i] for sample s (for the
+ * polynomial model: binf_poly_forward_f64 of the sampled coefficients); precision
+ * [S]; ys, out [nx x ny]; half_log_2pi = 0.5 * log(2 pi) as the host computes it.
+ * NaN / inf follow numpy (a negative precision gives NaN, S >= 1 required: the
+ * reference's max() of no samples raises).  Lane-strided sums and the device
+ * library's log / exp: ~1e-14 relative to the numpy restatement, not bit-identical.
+ * ---------------------------------------------------------------------- */
+int32_t binf_predictive_density_f64(const double *mock, const double *precision,
+                                    const double *ys, double *out, int64_t S,
+                                    int64_t nx, int64_t ny, double half_log_2pi,
+                                    void *stream);
 
 /* ------------------------------------------------------------------------
  * Pairwise-distance-restraint model (BASELINE config C5; build-defined, the

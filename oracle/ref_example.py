@@ -125,3 +125,45 @@ def example_script_chain(seed, sweeps, stepsize=0.1, n_data_points=20):
         out_a.append(bool(accepted))
     return dict(xs=xses, ys=ys, coefficients=np.array(out_c), precision=np.array(out_t),
                 accepted=np.array(out_a), acceptance_rate=n_acc / float(n_moves))
+
+
+# ---- the consumer side: posterior-predictive density (binf/example/misc.py, plots.py) ----------
+def log_sum_exp(x, axis=0):
+    """``csb.numeric.log_sum_exp`` -- csb is absent from /root/reference; this is its published
+    definition (csb 1.2.x, csb/numeric/__init__.py): the maximum along ``axis`` taken out of the
+    exponentials.  **Parity unpinned** (no reference output can be produced without csb)."""
+    xmax = x.max(axis)
+    return np.log(np.exp(x - xmax).sum(axis)) + xmax
+
+
+def predict_integrands(x, y, coefficients, precisions, polynomial=R.polyval):
+    """The list ``integrands`` of ``predict`` (binf/example/misc.py:8-9), one entry per sample;
+    pinned bit for bit by tests/golden/ref_predict_*.npz (the reference's own statement run on
+    data-only samples, oracle/gen_ref_predict.py)."""
+    return np.array([-0.5 * (polynomial(x, c) - y) ** 2 * tau + 0.5 * np.log(tau)
+                     - 0.5 * np.log(2.0 * np.pi) for c, tau in zip(coefficients, precisions)])
+
+
+def predict(x, y, coefficients, precisions, polynomial=R.polyval):
+    """``predict`` (binf/example/misc.py:3-16) for samples given as arrays
+    (``coefficients`` [S x K], ``precisions`` [S])."""
+    integrands = predict_integrands(x, y, coefficients, precisions, polynomial)
+    return np.exp(log_sum_exp(integrands)) / len(coefficients)
+
+
+def prediction_tube(coefficients, precisions, predict_space, ys_from, ys_to, n_ys, polynomial=R.polyval,
+                    probs=None):
+    """The numbers ``plot_prediction_tube`` draws (binf/example/plots.py:8-27): the y grid per x,
+    the predictive density on it, its cumulative sums, the 5 % / 95 % limits and the trapezoid mean.
+    ``probs``: densities to post-process instead of computing them (the fixtures pin the
+    post-processing with densities handed to the reference's own statements)."""
+    predicted_ys = np.array([np.linspace(ys_from[i], ys_to[i], n_ys) for i, _ in enumerate(predict_space)])
+    if probs is None:
+        probs = np.array([[predict(x, y, coefficients, precisions, polynomial) for y in predicted_ys[i]]
+                          for i, x in enumerate(predict_space)])
+    cdfs = np.cumsum(probs * (predicted_ys[:, 1] - predicted_ys[:, 0])[:, None], 1)
+    lower = np.array([predicted_ys[i][np.where(cdfs[i] < 0.05)[0][-1]] for i in range(len(predict_space))])
+    upper = np.array([predicted_ys[i][np.where(cdfs[i] > 0.95)[0][0]] for i in range(len(predict_space))])
+    trapezoid = getattr(np, 'trapezoid', None) or np.trapz
+    mean = np.array([trapezoid(predicted_ys[i] * probs[i], predicted_ys[i]) for i in range(len(predict_space))])
+    return dict(predicted_ys=predicted_ys, probs=probs, cdfs=cdfs, lower=lower, upper=upper, prediction=mean)
