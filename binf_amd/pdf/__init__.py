@@ -136,5 +136,9 @@ class IsotropicGaussian(AbstractBinfPDF):
         return None
 
 
+# the reference's name for it (``from binf.pdf import TestHO``)
+TestHO = IsotropicGaussian
+
+
 def _as2d(x):
     return x if x.dim() == 2 else x.reshape(1, -1)

@@ -533,3 +533,27 @@ def test_binf_state_follows_the_reference_run():
     assert (st.variables['a'] == 1.5) is ref['copy_is_detached']
     assert view == ref['view_after_write'] and dict(st.momenta) == ref['momenta']
     assert (BinfState().variables == {} and BinfState().momenta == {}) is ref['fresh_is_empty']
+
+
+def test_mirror_offers_every_name_the_reference_modules_define():
+    """``tests/golden/ref_api_surface.json`` (oracle/gen_ref_surface.py): every class, function and
+    method name of the reference's hot-path modules and of its example application.  After
+    ``s/binf/binf_amd/`` an import of any of them succeeds and every method is there (inherited
+    or defined; the private ones too -- subclasses written against the reference call them)."""
+    import importlib
+    import json
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'ref_api_surface.json')
+    surface = json.load(open(path))['modules']
+    assert len(surface) == 15
+    missing = []
+    for mod, names in surface.items():
+        m = importlib.import_module(mod.replace('binf', 'binf_amd', 1))
+        for name, methods in names.items():
+            if not hasattr(m, name):
+                missing.append('%s.%s' % (mod, name))
+                continue
+            for meth in methods or []:
+                if not hasattr(getattr(m, name), meth):
+                    missing.append('%s.%s.%s' % (mod, name, meth))
+    assert missing == []
