@@ -206,7 +206,7 @@ def hmc_sample(sampler, spec, q0, p0, u, accepted, adapt):
     _native.hmc_sample_poly(q0, p0, u, q_out, accepted, sampler.n_accepted, eb, ea,
                             fwm.xs_device(dev), em.ys_device(dev), precision,
                             means, variances, prior_first, lp_pre, lp_post,
-                            sampler._timestep, sampler._dt_chain, sampler.nsteps, adapt,
+                            sampler._timestep, sampler._dt_chain, sampler.leapfrog_steps, adapt,
                             sampler.adaption_uprate, sampler.adaption_downrate,
                             _MODES[sampler.mode] | (_native.MODE_LANE_PER_CHAIN
                                                     if lane_layout(sampler, spec, C) else 0))
@@ -421,7 +421,7 @@ def gibbs_sample_n(gibbs, n, thin, record):
             cs.n_accepted = torch.zeros(C, dtype=torch.int64, device=dev)
         eb = torch.empty((n, C), dtype=torch.float64, device=dev)
         ea = torch.empty((n, C), dtype=torch.float64, device=dev)
-        kw = dict(move=_native.MOVE_HMC, mode=_MODES[cs.mode], nsteps=cs.nsteps,
+        kw = dict(move=_native.MOVE_HMC, mode=_MODES[cs.mode], nsteps=cs.leapfrog_steps,
                   timestep=cs._timestep, dt_chain=cs._dt_chain, n_adapt=n_adapt,
                   uprate=cs.adaption_uprate, downrate=cs.adaption_downrate,
                   n_accepted=cs.n_accepted, e_before=eb, e_after=ea)
@@ -536,7 +536,7 @@ def hmc_sample_n(sampler, spec, n, thin, p0, u, record, out, q0):
     try:
         _native.gibbs_poly_sample_n(
             q0, tau, q_out, torch.empty_like(tau), fwm.xs_device(dev), em.ys_device(dev), n, thin,
-            move=_native.MOVE_HMC, mode=_MODES[sampler.mode], nsteps=sampler.nsteps,
+            move=_native.MOVE_HMC, mode=_MODES[sampler.mode], nsteps=sampler.leapfrog_steps,
             timestep=sampler._timestep, dt_chain=sampler._dt_chain, n_adapt=n_adapt,
             uprate=sampler.adaption_uprate, downrate=sampler.adaption_downrate,
             prior_means=prior._vec('means', dev) if prior is not None else None,

@@ -61,8 +61,8 @@ class HMCSampler(object):
             raise ValueError("mode must be 'exact' or 'fma', not %r" % (mode,))
         self.pdf = pdf
         self.state = state
-        self._timestep = timestep
-        self._dt_chain = None
+        self._dt_chain, self._timestep = None, 0.0
+        self.timestep = timestep          # a number, or a [C] tensor of per-chain step sizes
         self.nsteps = nsteps
         self.timestep_adaption_limit = timestep_adaption_limit
         self.adaption_uprate = adaption_uprate
@@ -99,6 +99,13 @@ class HMCSampler(object):
         else:
             self._timestep = float(value)
             self._dt_chain = None
+
+    @property
+    def leapfrog_steps(self):
+        """Steps a trajectory takes: ``nsteps``, and 1 for ``nsteps < 1`` -- the reference's
+        loop (``hmc.py:118-120``) runs ``nsteps - 1`` times and is followed by one more drift
+        and half kick (``:122-123``) whatever ``nsteps`` is."""
+        return max(1, int(self.nsteps))
 
     @property
     def acceptance_rate(self):
@@ -149,7 +156,7 @@ class HMCSampler(object):
         if not isinstance(name, str):
             # reference: pdf.log_prob(**{None: x}) -> TypeError (quirk Q1)
             raise TypeError('HMCSampler needs variable_name to sample()')
-        state = self.state
+        state = _device_state(self.state)
         shape = state.shape                       # quirk Q2: arrays only
         q0 = (state if state.dim() == 2 else state.reshape(1, -1)).contiguous()
         C, D = q0.shape
@@ -217,7 +224,7 @@ class HMCSampler(object):
         n, thin = int(n), int(thin)
         if n < 1 or thin < 1:
             raise ValueError('sample_n: n >= 1 and thin >= 1 required')
-        state = self.state
+        state = _device_state(self.state)
         shape = state.shape
         q0 = (state if state.dim() == 2 else state.reshape(1, -1)).contiguous()
         C, D = q0.shape
@@ -242,7 +249,7 @@ class HMCSampler(object):
                 q_out, samples = res
                 self.state = q_out.view(shape)
                 if samples is None:
-                    return None
+                    return self._no_records(shape, dev) if record else None
                 return samples if state.dim() == 2 else samples.reshape((nrec,) + tuple(shape))
         # no multi-transition kernel for this PDF / shape: n single calls (each draws for
         # itself when no draws were supplied)
@@ -257,12 +264,19 @@ class HMCSampler(object):
         self.accepted_history = torch.stack(flags)
         if all(e is not None for e in ebs):
             self.last_e_before, self.last_e_after = torch.stack(ebs), torch.stack(eas)
-        if not (record and rec):
+        if not record:
             return None
+        if not rec:
+            return self._no_records(shape, dev)
         if out is not None:
             torch.stack(rec, out=out.view((nrec,) + tuple(rec[0].shape)))
             return out
         return torch.stack(rec)
+
+    @staticmethod
+    def _no_records(shape, dev):
+        """``sample_n(n, thin)`` with ``thin > n`` records nothing: ``[0, *state shape]``."""
+        return torch.empty((0,) + tuple(shape), dtype=torch.float64, device=dev)
 
     # -- the built-in kind 'gauss': n transitions ------------------------------------
     def _gauss_sample_n(self, spec, n, thin, p0, u, record, out, q0, shape):
@@ -318,7 +332,7 @@ class HMCSampler(object):
         if fused_rng:
             _native.hmc_sample_n_gauss_rng(q0, q_out, samples, accepted, self.n_accepted,
                                            eb, ea, self._timestep, self._dt_chain,
-                                           self.nsteps, n, thin, k, x0, n_adapt,
+                                           self.leapfrog_steps, n, thin, k, x0, n_adapt,
                                            self.adaption_uprate, self.adaption_downrate,
                                            _MODES[self.mode], self.rng.seed,
                                            self.rng.offset,
@@ -327,7 +341,7 @@ class HMCSampler(object):
         else:
             _native.hmc_sample_n_gauss(q0, p0.contiguous(), u.contiguous(), q_out,
                                        samples, accepted, self.n_accepted, eb, ea,
-                                       self._timestep, self._dt_chain, self.nsteps,
+                                       self._timestep, self._dt_chain, self.leapfrog_steps,
                                        n, thin, k, x0, n_adapt,
                                        self.adaption_uprate,
                                        self.adaption_downrate, _MODES[self.mode])
@@ -405,7 +419,7 @@ class HMCSampler(object):
             eb = torch.empty(C, dtype=torch.float64, device=dev)
             ea = torch.empty(C, dtype=torch.float64, device=dev)
         _native.hmc_sample_gauss_big_rng(q0, q_out, accepted, self.n_accepted, eb, ea,
-                                         self._timestep, self._dt_chain, self.nsteps, k, x0,
+                                         self._timestep, self._dt_chain, self.leapfrog_steps, k, x0,
                                          adapt, self.adaption_uprate, self.adaption_downrate,
                                          _MODES[self.mode], self.rng.seed,
                                          self.rng.offset,
@@ -441,7 +455,7 @@ class HMCSampler(object):
             eb = torch.empty((n, C), dtype=torch.float64, device=dev)
             ea = torch.empty((n, C), dtype=torch.float64, device=dev)
         q_out = torch.empty_like(q0)
-        args = (self._timestep, self._dt_chain, self.nsteps)
+        args = (self._timestep, self._dt_chain, self.leapfrog_steps)
         tail = (k, x0, n_adapt, self.adaption_uprate, self.adaption_downrate, _MODES[self.mode])
         if p0 is None and u is None and self._fused_rng(spec):
             _native.hmc_sample_n_gauss_big(q0, None, None, q_out, samples, accepted, self.n_accepted,
@@ -529,7 +543,7 @@ class HMCSampler(object):
         launch = _native.hmc_sample_gauss if _native.gauss_persist_covers(D) \
             else _native.hmc_sample_gauss_big       # chains of any length, chunked
         launch(q0, p0, u, q_out, accepted, self.n_accepted, eb, ea, self._timestep,
-               self._dt_chain, self.nsteps, k, x0, adapt, self.adaption_uprate,
+               self._dt_chain, self.leapfrog_steps, k, x0, adapt, self.adaption_uprate,
                self.adaption_downrate, _MODES[self.mode])
         self.last_e_before, self.last_e_after = eb, ea
         return q_out
@@ -572,7 +586,7 @@ class HMCSampler(object):
         kind = native.get(leap) if leap is not None else None
         if kind is not None and kind.leapfrog is not None:
             # the whole integration in the kind's own launches (bit-identical to the loop)
-            if kind.leapfrog(self, leap, q2, p2, dt, dtc, nsteps, mode,
+            if kind.leapfrog(self, leap, q2, p2, dt, dtc, max(1, int(nsteps)), mode,
                              None if q_from is None else _as2d(q_from)):
                 return q, p
         if q_from is not None:
@@ -629,6 +643,16 @@ class HMCSampler(object):
 # From this many chains on, kinds that can lay a chain out either over a lane group or on
 # one lane choose the lane (read by the polynomial kind's lane_layout)
 POLY_LANE_MIN_CHAINS = 65536
+
+
+def _device_state(state):
+    """The sampler state as it is -- except a numpy array, refused by name (the reference's
+    states are numpy arrays; here they are ROCm tensors and there is no CPU path).  Anything
+    without a ``shape`` keeps failing the reference's way (quirk Q2: AttributeError)."""
+    if type(state).__module__ == 'numpy':
+        raise TypeError('the sampler state is a numpy %s; binf_amd keeps states as ROCm (cuda) fp64 '
+                        'tensors and evaluates on the GPU only (no CPU path)' % type(state).__name__)
+    return state
 
 
 def _fill(rng, kind, out):

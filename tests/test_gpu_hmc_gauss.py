@@ -517,6 +517,47 @@ def test_hmcsampler_quirks(device):
         s2.sample()
 
 
+def test_constructor_and_call_edge_cases_follow_the_reference(device):
+    """nsteps < 1 integrates ONE step (hmc.py:118-123: the loop runs nsteps - 1 times, the last
+    drift and half kick always); a [C] tensor as ``timestep`` is a per-chain step size; thinning
+    beyond n records nothing (an empty record, not None); host arrays are refused by name."""
+    rs = np.random.RandomState(21)
+    C, D = 5, 33
+    q0, p0, u = rs.standard_normal((C, D)), rs.standard_normal((C, D)), rs.uniform(size=C)
+    outs = {}
+    for L in (1, 0, -2):
+        s = HMCSampler(IsotropicGaussian(), dev_t(q0, device), 0.4, L, variable_name='x', record_energies=True)
+        outs[L] = (s.sample(p0=dev_t(p0, device), u=dev_t(u, device)).cpu().numpy(), s.last_e_after.cpu().numpy())
+        assert s.nsteps == L and s.leapfrog_steps == 1
+        for c in range(C):
+            ref = R.RefHMCSampler(R.GaussianPDF(), q0[c].copy(), 0.4, L, variable_name='x',
+                                  normal=lambda size, c=c: p0[c].copy(), uniform=lambda c=c: u[c])
+            assert np.array_equal(ref.sample(), outs[L][0][c]) and ref.last_E_after == outs[L][1][c]
+        # the per-step tier (a PDF without a fused kernel) takes the same single step
+        plain = IsotropicGaussian()
+        plain.native_hmc_spec = lambda name: None
+        g = HMCSampler(plain, dev_t(q0, device), 0.4, L, variable_name='x')
+        assert np.array_equal(g.sample(p0=dev_t(p0, device), u=dev_t(u, device)).cpu().numpy(), outs[L][0])
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[-2][0], outs[1][0])
+
+    dts = rs.uniform(0.05, 0.5, size=C)
+    s = HMCSampler(IsotropicGaussian(), dev_t(q0, device), dev_t(dts, device), 3, variable_name='x')
+    got = s.sample(p0=dev_t(p0, device), u=dev_t(u, device)).cpu().numpy()
+    assert np.array_equal(got, c_oracle.hmc_sample_gauss(q0, p0, u, dts, 3)['q_out'])
+    assert torch.equal(s.timestep, dev_t(dts, device))
+
+    s = HMCSampler(IsotropicGaussian(), dev_t(q0, device), 0.1, 2, variable_name='x')
+    rec = s.sample_n(3, thin=5, p0=dev_t(rs.standard_normal((3, C, D)), device), u=dev_t(rs.uniform(size=(3, C)), device))
+    assert rec.shape == (0, C, D) and s.counter == 3
+    plain = IsotropicGaussian()
+    plain.native_hmc_spec = lambda name: None
+    assert HMCSampler(plain, dev_t(q0, device), 0.1, 2, variable_name='x').sample_n(2, thin=3).shape == (0, C, D)
+    with pytest.raises(TypeError, match='sampler state is a numpy'):
+        HMCSampler(IsotropicGaussian(), q0, 0.1, 2, variable_name='x').sample()
+    with pytest.raises(ValueError, match='must live in GPU memory'):
+        HMCSampler(IsotropicGaussian(), torch.from_numpy(q0), 0.1, 2, variable_name='x').sample()
+
+
 def test_sampler_never_mutates_tensors_it_handed_out(device):
     q0 = torch.randn((16, 256), dtype=torch.float64, device=device)
     keep = q0.clone()
