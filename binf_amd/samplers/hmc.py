@@ -46,6 +46,17 @@ class HMCSampler(object):
       mode  'exact' (default; bit-identical to the numpy restatement) or 'fma'.
       record_energies  keep E_before / E_after of the last call in
             ``last_e_before`` / ``last_e_after``.
+      graph  per-step tier only (PDFs without a whole-transition kernel): capture the
+            transition's launches -- energies, every gradient call, kicks and drifts, the
+            accept -- ONCE as a HIP graph and replay it (``True``: for batches up to
+            ``GRAPH_MAX_ELEMENTS`` elements, where the launches themselves are the cost:
+            2.7-2.9x at 64 ... 2048 chains x 64 ... 768 dims; ``'always'``; default
+            ``False``).  Same bits as the eager launches.  The PDF's ``log_prob`` /
+            ``gradient`` must then be pure device code: no host synchronisation, and whatever
+            they read besides the variable must keep its ADDRESS between calls -- numbers
+            are frozen into the graph.  Parameters reachable through ``pdf.parameters``
+            (and a Posterior's / Likelihood's components) are watched: a changed number or a
+            replaced tensor means a new capture; anything else needs ``reset_graph()``.
 
     The tensor returned by ``sample()`` IS the new state (no defensive copy --
     a copy would double the HBM traffic of the transition).  The sampler never
@@ -56,9 +67,13 @@ class HMCSampler(object):
     def __init__(self, pdf, state, timestep, nsteps, timestep_adaption_limit=0,
                  adaption_uprate=1.05, adaption_downrate=0.95,
                  variable_name=None, rng=None, mode='exact',
-                 record_energies=False):
+                 record_energies=False, graph=False):
         if mode not in _MODES:
             raise ValueError("mode must be 'exact' or 'fma', not %r" % (mode,))
+        if graph not in (False, True, 'always'):
+            raise ValueError("graph must be False, True or 'always', not %r" % (graph,))
+        self.graph = graph
+        self._graphs, self._graph_warm, self._graph_captures = {}, set(), 0
         self.pdf = pdf
         self.state = state
         self._dt_chain, self._timestep = None, 0.0
@@ -191,6 +206,9 @@ class HMCSampler(object):
         accepted = torch.empty(C, dtype=torch.uint8, device=dev)
         if kind is not None and kind.hmc is not None:
             q_out = kind.hmc(self, spec, q0, p0, u, accepted, adapt)
+        elif self.graph and q0.is_cuda and (self.graph == 'always' or
+                                            q0.numel() <= GRAPH_MAX_ELEMENTS):
+            q_out = self._sample_graphed(name, state, q0, p0, own_p, u, accepted, adapt)
         else:
             q_out = self._sample_generic(name, state, q0, p0, own_p, u,
                                          accepted, adapt)
@@ -638,6 +656,118 @@ class HMCSampler(object):
                               self.adaption_uprate, self.adaption_downrate)
         self.last_e_before, self.last_e_after = e_before, e_after
         return q
+
+
+    # -- the per-step tier as one HIP graph --------------------------------------------
+    def reset_graph(self):
+        """Forget the captured graphs (after changing something the PDF reads that is not
+        one of its registered parameters)."""
+        self._graphs.clear()
+        self._graph_warm.clear()
+
+    def _graph_key(self, state, q0, adapt):
+        dtc = self._dt_chain
+        return (tuple(state.shape), q0.device.index, bool(adapt), float(self._timestep),
+                None if dtc is None else dtc.data_ptr(), int(self.nsteps), self.mode,
+                float(self.adaption_uprate), float(self.adaption_downrate),
+                self.n_accepted.data_ptr(), bool(self.fused_leapfrog), bool(self.fused_energy),
+                type(self)._leapfrog, _graph_signature(self.pdf))
+
+    def _sample_graphed(self, name, state, q0, p0, own_p, u, accepted, adapt):
+        """``_sample_generic`` replayed from a HIP graph: first call with a configuration
+        eager (it also warms every lazily initialised piece up), second call captured, every
+        later one replayed.  Inputs are copied into the graph's own buffers and the new state
+        out of them, so no tensor handed out is ever written again."""
+        key = self._graph_key(state, q0, adapt)
+        entry = self._graphs.get(key)
+        if entry is None:
+            if key not in self._graph_warm:
+                self._graph_warm.add(key)
+                if len(self._graph_warm) > 4 * GRAPH_MAX_CAPTURES:
+                    self._graph_gives_up('%d configurations seen, none twice' % len(self._graph_warm))
+                return self._sample_generic(name, state, q0, p0, own_p, u, accepted, adapt)
+            entry = self._capture(key, name, state, q0, u, adapt)
+            if entry is None:                          # capture refused: eager from now on
+                return self._sample_generic(name, state, q0, p0, own_p, u, accepted, adapt)
+        g, q_in, p_in, u_in, acc, q_out, e_b, e_a = entry
+        q_in.copy_(q0)
+        p_in.copy_(p0)
+        u_in.copy_(u.reshape(u_in.shape))
+        g.replay()
+        accepted.copy_(acc)
+        self.last_e_before, self.last_e_after = e_b.clone(), e_a.clone()
+        return q_out.clone()
+
+    def _graph_gives_up(self, why):
+        """Every call a new configuration (e.g. a Gibbs loop that REPLACES parameter tensors
+        instead of updating them in place), or a PDF that cannot be captured: eager launches
+        from now on, said once."""
+        import warnings
+        warnings.warn('HMCSampler(graph=%r): %s; graph mode switched off for this sampler'
+                      % (self.graph, why))
+        self.graph = False
+        self.reset_graph()
+
+    def _capture(self, key, name, state, q0, u, adapt):
+        if self._graph_captures >= 4 * GRAPH_MAX_CAPTURES:
+            self._graph_gives_up('%d captures' % self._graph_captures)
+            return None
+        q_in, p_in = torch.empty_like(q0), torch.empty_like(q0)
+        u_in = torch.empty_like(u.reshape(-1))
+        acc = torch.empty(q0.shape[0], dtype=torch.uint8, device=q0.device)
+        g = torch.cuda.CUDAGraph()
+        try:
+            with torch.cuda.graph(g):
+                q_out = self._sample_generic(name, q_in.view(state.shape), q_in, p_in, True, u_in,
+                                             acc, adapt)
+                e_b, e_a = self.last_e_before, self.last_e_after
+        except Exception as e:                          # noqa: BLE001 -- whatever the PDF did
+            torch.cuda.synchronize()
+            self._graph_gives_up('the transition could not be captured (%s: %s) -- does the PDF '
+                                 'synchronise with the host?' % (type(e).__name__, str(e).split('\n')[0][:200]))
+            return None
+        self._graph_captures += 1
+        if len(self._graphs) >= GRAPH_MAX_CAPTURES:
+            self._graphs.pop(next(iter(self._graphs)))
+        entry = (g, q_in, p_in, u_in, acc, q_out, e_b, e_a)
+        self._graphs[key] = entry
+        return entry
+
+
+# graph=True captures batches up to this many elements (beyond it the kernels, not their
+# launches, are the cost: 4096 x 1024 measured 0.98x), and keeps at most this many graphs
+GRAPH_MAX_ELEMENTS = 1 << 21
+GRAPH_MAX_CAPTURES = 8
+
+
+def _graph_signature(pdf, depth=0):
+    """What a captured transition froze of ``pdf``: the numbers and the tensor ADDRESSES of
+    its registered parameters, through a Posterior's components and a Likelihood's models."""
+    sig = []
+    names = getattr(pdf, 'parameters', None)
+    if names is not None and depth < 4:
+        try:
+            for n in names:
+                v = pdf[n].value
+                if isinstance(v, torch.Tensor):
+                    sig.append((n, v.data_ptr(), tuple(v.shape)))
+                elif isinstance(v, (int, float)):
+                    sig.append((n, float(v)))
+                else:
+                    sig.append((n, id(v)))
+        except Exception:                               # noqa: BLE001 -- a duck-typed pdf
+            sig.append(('?', id(pdf)))
+    for attr in ('_components', '_likelihoods', '_priors'):
+        comps = getattr(pdf, attr, None)
+        if isinstance(comps, dict):
+            for n in sorted(comps):
+                sig.append((attr, n, _graph_signature(comps[n], depth + 1)))
+            break
+    for attr in ('forward_model', 'error_model'):
+        m = getattr(pdf, attr, None)
+        if m is not None and depth < 4:
+            sig.append((attr, _graph_signature(m, depth + 1)))
+    return (id(pdf), tuple(sig))
 
 
 # From this many chains on, kinds that can lay a chain out either over a lane group or on

@@ -13,6 +13,7 @@ which no built-in pdf covers.  Each coordinate should end up near +1 or -1 and
 hop between the two.
 
   python examples/custom_pdf.py --chains 2048 --dims 64 --draws 400
+  python examples/custom_pdf.py --graph      # the transition's launches replayed from one HIP graph
 """
 import argparse
 import os
@@ -52,22 +53,30 @@ def main(argv=None):
     ap.add_argument('--timestep', type=float, default=0.08)
     ap.add_argument('--a', type=float, default=2.0)
     ap.add_argument('--seed', type=int, default=0)
+    ap.add_argument('--graph', action='store_true',
+                    help='capture the transition once as a HIP graph and replay it (same bits)')
     args = ap.parse_args(argv)
 
     dev = torch.device('cuda', torch.cuda.current_device())
     rng = DeviceRNG(args.seed, dev)
     state = rng.normal((args.chains, args.dims), dev)
     sampler = HMCSampler(DoubleWell(args.a), state, args.timestep, args.nsteps,
-                         variable_name='x', rng=rng)
+                         variable_name='x', rng=rng, graph=args.graph)
     right = torch.zeros((), dtype=torch.float64, device=dev)
     absx = torch.zeros((), dtype=torch.float64, device=dev)
     kept = 0
+    import time
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
     for i in range(args.draws):
         x = sampler.sample()
         if i >= args.draws // 2:
             right += (x > 0).double().mean()
             absx += x.abs().mean()
             kept += 1
+    torch.cuda.synchronize()
+    print('{:.3f} ms per sample() ({})'.format((time.perf_counter() - t0) / args.draws * 1e3,
+                                             'HIP graph replay' if sampler._graphs else 'eager launches'))
     print('acceptance rate          : {:.3f}'.format(float(sampler.acceptance_rate.mean())))
     print('fraction in the right well: {:.3f} (target 0.5)'.format(float(right) / kept))
     print('mean |x|                 : {:.3f} (wells at 1)'.format(float(absx) / kept))
