@@ -12,7 +12,19 @@ sweep advances all C chains at once; the state's values are device tensors.
 from collections import OrderedDict
 
 
+def _is_tensor(x):
+    import torch
+    return isinstance(x, torch.Tensor)
+
+
 class GibbsSampler(object):
+
+    # Keep the conditional PDFs' tensor-valued parameters at FIXED ADDRESSES: private copies
+    # made at set-up and refreshed IN PLACE before every sub-step (one small copy each),
+    # instead of handing the conditionals the state's own tensors -- so that a subsampler
+    # which replays its transition from a HIP graph (``HMCSampler(graph=True)``) finds what it
+    # captured.  Same values, same bits.  None = exactly when a subsampler asks for a graph.
+    stable_parameters = None
 
     def __init__(self, pdf, state, subsamplers):
         self._state = state
@@ -30,19 +42,33 @@ class GibbsSampler(object):
         current = self._state.variables
         already_fixed = {x: self._pdf[x].value for x in self._pdf.parameters
                          if x in self._pdf._original_variables}
+        stable = self._stable()
         for var in current:
-            fixed = {x: v for x, v in current.items() if x != var}
+            fixed = {x: (v.clone() if stable and _is_tensor(v) else v)
+                     for x, v in current.items() if x != var}
             fixed.update(already_fixed)
             cond = self._pdf.conditional_factory(**fixed)
             self._conditional_pdfs[var] = cond
             self._subsamplers[var].pdf = cond
 
+    def _stable(self):
+        if self.stable_parameters is not None:
+            return bool(self.stable_parameters)
+        return any(getattr(s, 'graph', False) for s in self._subsamplers.values())
+
     def _update_conditional_pdf_params(self):
         current = self._state.variables
+        stable = self._stable()
         for cond in self._conditional_pdfs.values():
             for param in cond.parameters:
                 if param in current:
-                    cond[param].set(current[param])
+                    new, old = current[param], cond[param].value
+                    if stable and _is_tensor(new) and _is_tensor(old) and old is not new and \
+                            old.shape == new.shape and old.dtype == new.dtype and \
+                            old.device == new.device:
+                        old.copy_(new)          # the conditional's own buffer (see stable_parameters)
+                        new = old
+                    cond[param].set(new)
 
     def _checkstate(self, state):
         if not type(state) == dict:

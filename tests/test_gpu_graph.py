@@ -152,3 +152,48 @@ def test_big_batches_stay_eager_and_the_flag_is_validated(device):
     for _ in range(3):
         f.sample()
     assert not f._graphs
+
+
+def test_gibbs_keeps_conditional_parameters_in_place_for_a_graphed_subsampler(device):
+    """Gibbs-within-HMC on the per-step tier (the polynomial model with its whole-transition
+    kernel switched off): with ``graph=True`` on the HMC subsampler the GibbsSampler refreshes the
+    conditionals' tensors in place, the transition is captured once and replayed every sweep --
+    and every sweep equals the eager run's, bit for bit."""
+    from binf_amd.example.likelihood import POLYVAL
+    from binf_amd.example.misc import make_posterior
+    from binf_amd.example.samplers import make_hmc_sampler
+    from binf_amd.samplers import BinfState
+    from binf_amd.samplers.rng import DeviceRNG
+    rs = np.random.RandomState(5)
+    xs = np.linspace(-2, 2, 20)
+    ys = POLYVAL(xs, np.array([2.0, -4.0, 1.0, 1.5])) + 0.6 * rs.standard_normal(20)
+    C = 48
+
+    def run(graph, sweeps=9):
+        start = BinfState(dict(coefficients=torch.ones((C, 4), dtype=torch.float64, device=device),
+                               precision=torch.ones(C, dtype=torch.float64, device=device)))
+        g = make_hmc_sampler(make_posterior(xs, ys, POLYVAL), 0.02, 12, start, rng=DeviceRNG(3, device),
+                             graph=graph)
+        g.fused_sweep = False
+        hmc = g.subsamplers['coefficients']
+        hmc.fused_polynomial = False                 # the per-step tier: gradient launches + kick / drift
+        rows = []
+        for _ in range(sweeps):
+            st = g.sample()
+            rows.append((st.variables['coefficients'].clone(), st.variables['precision'].clone()))
+        return g, hmc, rows
+
+    ge, he, eager = run(False)
+    gg, hg, graph = run(True)
+    assert not he._graphs and len(hg._graphs) == 1 and hg.graph is True
+    assert gg._stable() and not ge._stable()
+    for (ca, pa), (cb, pb) in zip(eager, graph):
+        assert torch.equal(ca, cb) and torch.equal(pa, pb)
+    assert torch.equal(he.n_accepted, hg.n_accepted) and 0 < int(hg.n_accepted.sum())
+    # the state's tensors are not the conditionals' buffers: nothing handed out is written again
+    cond = gg._conditional_pdfs['coefficients']
+    ptr = cond['precision'].value.data_ptr()
+    assert ptr != gg.state.variables['precision'].data_ptr()
+    gg._update_conditional_pdf_params()                     # what the next sub-step does first
+    assert cond['precision'].value.data_ptr() == ptr
+    assert torch.equal(cond['precision'].value, gg.state.variables['precision'])
