@@ -89,7 +89,9 @@ def test_gaussian_hmc_kernels_stay_inside_their_buffers(device, D, C, n):
 
 
 @pytest.mark.parametrize('K,N,C', [(1, 1, 1), (4, 20, 70), (17, 100, 33), (33, 1000, 20), (33, 4099, 130),
-                                   (34, 257, 65), (50, 64, 3), (64, 8200, 2), (5, 7700, 3)])
+                                   (34, 257, 65), (50, 64, 3), (64, 8200, 2), (5, 7700, 3),
+                                   # N a multiple of 16: the whole-tile MFMA gradient kernel (buffer loads)
+                                   (4, 32, 70), (33, 1024, 20), (17, 4096, 33), (33, 16384, 130), (64, 16, 1)])
 def test_polynomial_kernels_stay_inside_their_buffers(device, K, N, C):
     rs = np.random.RandomState(K + N)
     xs, ys = np.linspace(-1, 1, N), rs.standard_normal(N)
@@ -340,3 +342,18 @@ def test_long_chain_loop_from_one_call_stays_inside_its_buffers(device, D, C, n,
     for a, b in zip(*res):
         assert torch.equal(a, b)
     assert bool(torch.isfinite(res[0][0]).all())
+
+
+@pytest.mark.parametrize('S,nx,ny', [(1, 1, 1), (5, 3, 7), (16, 16, 8), (17, 17, 9), (100, 33, 150), (1000, 5, 31)])
+def test_predictive_density_stays_inside_its_buffers(device, S, nx, ny):
+    rs = np.random.RandomState(S + nx + ny)
+    mock, tau, ys = rs.standard_normal((S, nx)), rs.gamma(4.0, 0.5, size=S), rs.standard_normal((nx, ny)) * 2
+    h = 0.5 * np.log(2 * np.pi)
+    outs = []
+    for make in (Guarded(device), None):
+        t = make if make is not None else (lambda a, dtype=torch.float64: plain(a, device, dtype))
+        r = _native.predictive_density(t(mock), t(tau), t(ys), h)
+        if make is not None:
+            make.check()
+        outs.append(r.clone().cpu())
+    assert torch.equal(outs[0], outs[1]) and not torch.isnan(outs[0]).any() and bool((outs[0] > 0).all())
