@@ -30,13 +30,14 @@ def lib():
         _lib.oracle_pairwise_sum.argtypes = [ctypes.c_void_p, ctypes.c_int64]
         _lib.oracle_np_sum.restype = ctypes.c_double
         _lib.oracle_np_sum.argtypes = [ctypes.c_void_p, ctypes.c_int64]
-        _lib.oracle_hmc_sample_gauss.restype = ctypes.c_int
-        _lib.oracle_hmc_sample_gauss.argtypes = (
-            [ctypes.c_void_p] * 8 + [ctypes.c_int64, ctypes.c_int64,
-                                     ctypes.c_int32, ctypes.c_double,
-                                     ctypes.c_double, ctypes.c_int32,
-                                     ctypes.c_double, ctypes.c_double,
-                                     ctypes.c_int32])
+        for fn in (_lib.oracle_hmc_sample_gauss, _lib.oracle_hmc_sample_gauss_fma):
+            fn.restype = ctypes.c_int
+            fn.argtypes = (
+                [ctypes.c_void_p] * 8 + [ctypes.c_int64, ctypes.c_int64,
+                                         ctypes.c_int32, ctypes.c_double,
+                                         ctypes.c_double, ctypes.c_int32,
+                                         ctypes.c_double, ctypes.c_double,
+                                         ctypes.c_int32])
     return _lib
 
 
@@ -46,7 +47,8 @@ def np_sum(a):
 
 
 def hmc_sample_gauss(q0, p0, u, timestep, nsteps, k=1.0, x0=0.0, adapt=False,
-                     uprate=1.05, downrate=0.95, nthreads=1):
+                     uprate=1.05, downrate=0.95, nthreads=1, fma=False):
+    """``fma=True``: the package's FMA mode (each leapfrog update one C99 ``fma``)."""
     q0 = np.ascontiguousarray(q0, dtype=np.float64)
     p0 = np.ascontiguousarray(p0, dtype=np.float64)
     u = np.ascontiguousarray(u, dtype=np.float64)
@@ -58,7 +60,8 @@ def hmc_sample_gauss(q0, p0, u, timestep, nsteps, k=1.0, x0=0.0, adapt=False,
     acc = np.zeros(C, dtype=np.uint8)
     eb = np.empty(C)
     ea = np.empty(C)
-    rc = lib().oracle_hmc_sample_gauss(
+    fn = lib().oracle_hmc_sample_gauss_fma if fma else lib().oracle_hmc_sample_gauss
+    rc = fn(
         q0.ctypes.data, p0.ctypes.data, u.ctypes.data, q_out.ctypes.data,
         acc.ctypes.data, eb.ctypes.data, ea.ctypes.data, dt.ctypes.data,
         C, D, int(nsteps), float(k), float(x0), int(bool(adapt)),

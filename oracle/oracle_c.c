@@ -2,10 +2,12 @@
  * TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).  Plain-C restatement of
  * the batched HMC transition, held bit-for-bit to oracle/ref_numpy.py.
  *
- * Parity status: **parity unpinned** for the HMC numerics -- no reference test
- * executes binf/samplers/hmc.py:92-164 and the reference cannot be imported in
- * the build container (csb absent).  This file is checked against the numpy
- * restatement, which is what the reference's own code reduces to.
+ * Parity status: held bit for bit to the numpy restatement AND to outputs of the
+ * reference's own code (tests/golden/ref_leapfrog_*.npz, ref_sample_*.npz,
+ * ref_adapt_timestep_*.npz -- oracle/gen_ref_leapfrog.py runs binf/samplers/hmc.py
+ * itself, minus its one csb import): integrator, energies, bookkeeping, adaption.
+ * Still **parity unpinned**: the definition of csb.numeric.exp (the clip bounds of
+ * clipped_exp below), csb being absent from the reference tree.
  *
  * Build: see oracle/Makefile (-O2 -ffp-contract=off: numpy rounds every
  * multiply and add separately, so no FMA contraction is allowed).
@@ -100,11 +102,21 @@ static inline double gauss_grad(double x, double k, double x0)
  *               (hmc.py:183-191: *uprate on accept, *downrate on reject)
  *   q_out[c]  : the returned sample (proposal if accepted, else q0[c])
  */
-int oracle_hmc_sample_gauss(const double *q0, const double *p0, const double *u,
+static inline double kick(double p, double dt, double g, int fused)
+{
+    return fused ? fma(-dt, g, p) : p - dt * g;            /* hmc.py:116,120,123 */
+}
+
+static inline double drift(double q, double p, double dt, int fused)
+{
+    return fused ? fma(p, dt, q) : q + p * dt;             /* hmc.py:119,122 */
+}
+
+static int hmc_sample_gauss(const double *q0, const double *p0, const double *u,
                             double *q_out, uint8_t *accepted, double *e_before,
                             double *e_after, double *dt, int64_t C, int64_t D,
                             int32_t nsteps, double k, double x0, int32_t adapt,
-                            double uprate, double downrate, int32_t nthreads)
+                            double uprate, double downrate, int32_t nthreads, int fused)
 {
     if (C < 0 || D < 1 || nsteps < 1) return -1;
     if (nthreads < 1) nthreads = 1;
@@ -122,15 +134,15 @@ int oracle_hmc_sample_gauss(const double *q0, const double *p0, const double *u,
             /* _leapfrog, hmc.py:116-123 */
             const double hts = 0.5 * ts;
             for (int64_t i = 0; i < D; i++)
-                p[i] = p[i] - hts * gauss_grad(q[i], k, x0);
+                p[i] = kick(p[i], hts, gauss_grad(q[i], k, x0), fused);
             for (int32_t s = 0; s < nsteps - 1; s++) {
-                for (int64_t i = 0; i < D; i++) q[i] = q[i] + p[i] * ts;
+                for (int64_t i = 0; i < D; i++) q[i] = drift(q[i], p[i], ts, fused);
                 for (int64_t i = 0; i < D; i++)
-                    p[i] = p[i] - ts * gauss_grad(q[i], k, x0);
+                    p[i] = kick(p[i], ts, gauss_grad(q[i], k, x0), fused);
             }
-            for (int64_t i = 0; i < D; i++) q[i] = q[i] + p[i] * ts;
+            for (int64_t i = 0; i < D; i++) q[i] = drift(q[i], p[i], ts, fused);
             for (int64_t i = 0; i < D; i++)
-                p[i] = p[i] - hts * gauss_grad(q[i], k, x0);
+                p[i] = kick(p[i], hts, gauss_grad(q[i], k, x0), fused);
             double Ea = gauss_V(q, D, k, x0, tmp) + kinetic(p, D, tmp);
             int acc = u[c] < clipped_exp(-(Ea - Eb));      /* hmc.py:151 */
             e_before[c] = Eb;
@@ -144,4 +156,31 @@ int oracle_hmc_sample_gauss(const double *q0, const double *p0, const double *u,
         free(tmp);
     }
     return 0;
+}
+
+int oracle_hmc_sample_gauss(const double *q0, const double *p0, const double *u,
+                            double *q_out, uint8_t *accepted, double *e_before,
+                            double *e_after, double *dt, int64_t C, int64_t D,
+                            int32_t nsteps, double k, double x0, int32_t adapt,
+                            double uprate, double downrate, int32_t nthreads)
+{
+    return hmc_sample_gauss(q0, p0, u, q_out, accepted, e_before, e_after, dt, C, D, nsteps, k, x0,
+                            adapt, uprate, downrate, nthreads, 0);
+}
+
+/*
+ * The package's FMA mode (BINF_MODE_FMA, not a mode of the reference): the same
+ * transition with each of the two leapfrog updates -- p -= dt * grad and q += p * dt --
+ * as ONE correctly rounded fused multiply-add (C99 fma); the gradient k * (x - x0), the
+ * half step 0.5 * dt, the energies and the accept test rounded as before.  Pins the
+ * kernels' FMA arithmetic bit for bit (tests/test_gpu_hmc_gauss.py).
+ */
+int oracle_hmc_sample_gauss_fma(const double *q0, const double *p0, const double *u,
+                                double *q_out, uint8_t *accepted, double *e_before,
+                                double *e_after, double *dt, int64_t C, int64_t D,
+                                int32_t nsteps, double k, double x0, int32_t adapt,
+                                double uprate, double downrate, int32_t nthreads)
+{
+    return hmc_sample_gauss(q0, p0, u, q_out, accepted, e_before, e_after, dt, C, D, nsteps, k, x0,
+                            adapt, uprate, downrate, nthreads, 1);
 }

@@ -46,13 +46,15 @@ for case in range(n_cases):
     n = int(rs.randint(1, 5))
     thin = int(rs.randint(1, n + 1))
     limit = int(rs.choice([0, 0, 2, 10]))
+    mode = 'fma' if rs.rand() < 0.3 else 'exact'       # FMA mode: bit for bit the fused oracle
+    fma = mode == 'fma'
     k, x0 = (1.0, 0.0) if rs.rand() < 0.5 else (float(rs.uniform(0.2, 3)), float(rs.normal()))
     dt = float(rs.uniform(0.01, 0.6)) / np.sqrt(k)
     q0 = rs.standard_normal((C, D)) / np.sqrt(k) + x0
     p0 = rs.standard_normal((n, C, D))
     u = rs.uniform(size=(n, C))
     s = HMCSampler(IsotropicGaussian(k, x0), torch.from_numpy(q0).to(dev), dt, L,
-                   timestep_adaption_limit=limit, variable_name='x', record_energies=True)
+                   timestep_adaption_limit=limit, variable_name='x', record_energies=True, mode=mode)
     rec = s.sample_n(n, thin=thin, p0=torch.from_numpy(p0).to(dev), u=torch.from_numpy(u).to(dev))
     torch.cuda.synchronize()
     acc = s.accepted_history.cpu().numpy()
@@ -61,7 +63,7 @@ for case in range(n_cases):
     ok = True
     for i in range(n):
         adapt = (i + 1) < limit
-        w = c_oracle.hmc_sample_gauss(q, p0[i], u[i], dtc, L, k, x0, adapt=adapt, nthreads=8)
+        w = c_oracle.hmc_sample_gauss(q, p0[i], u[i], dtc, L, k, x0, adapt=adapt, nthreads=8, fma=fma)
         ok &= np.array_equal(acc[i], w['accepted'].astype(bool))
         ok &= np.array_equal(eb[i], w['e_before']) and np.array_equal(ea[i], w['e_after'])
         if (i + 1) % thin == 0:
@@ -76,10 +78,10 @@ for case in range(n_cases):
         pdf = IsotropicGaussian(k, x0)
         pdf.native_hmc_spec = lambda name: None
         g = HMCSampler(pdf, torch.from_numpy(q0).to(dev), dt, L, timestep_adaption_limit=limit,
-                       variable_name='x')
+                       variable_name='x', mode=mode)
         xg = g.sample(p0=torch.from_numpy(p0[0]).to(dev), u=torch.from_numpy(u[0]).to(dev))
         w = c_oracle.hmc_sample_gauss(q0, p0[0], u[0], np.full(C, dt), L, k, x0, adapt=1 < limit,
-                                      nthreads=8)
+                                      nthreads=8, fma=fma)
         ok &= np.array_equal(xg.cpu().numpy(), w['q_out'])
         ok &= np.array_equal(g.last_e_after.cpu().numpy(), w['e_after'])
         ok &= np.array_equal(g.last_move_accepted.cpu().numpy(), w['accepted'].astype(bool))
@@ -99,7 +101,7 @@ for case in range(n_cases):
         ok &= bool(torch.isfinite(pd).all()) and float(pd.abs().max()) < 9.0
     if not ok:
         bad += 1
-        print('MISMATCH', dict(D=D, C=C, L=L, n=n, thin=thin, limit=limit, k=k, x0=x0, dt=dt), flush=True)
+        print('MISMATCH', dict(D=D, C=C, L=L, n=n, thin=thin, limit=limit, k=k, x0=x0, dt=dt, fma=fma), flush=True)
     if case % 50 == 49:
         print('%d cases, %d mismatches, %.0f s' % (case + 1, bad, time.time() - t0), flush=True)
 print('done: %d cases, %d mismatches' % (n_cases, bad))

@@ -161,6 +161,54 @@ def test_fused_kernel_bitwise_vs_oracle(device, D, C, L, k, x0, dt):
     assert 0 < want['accepted'].mean() or C < 8     # sweep has accepts ...
 
 
+@pytest.mark.parametrize('D,C,L,k,x0,dt', SWEEP)
+def test_fma_mode_bitwise_vs_the_fused_oracle(device, D, C, L, k, x0, dt):
+    """FMA mode is not "EXACT within a tolerance" but an arithmetic of its own: each leapfrog
+    update one correctly rounded fused multiply-add (``c_oracle.hmc_sample_gauss(fma=True)``,
+    re-derived in rational arithmetic in tests/test_oracle.py).  Every kernel layout gives those
+    bits -- states, energies, flags -- and stays within 1e-10 of EXACT mode."""
+    rs = np.random.RandomState(1000 + D * 7 + C)
+    q0, p0, u = rs.standard_normal((C, D)) + x0, rs.standard_normal((C, D)), rs.uniform(size=C)
+    want = c_oracle.hmc_sample_gauss(q0, p0, u, dt, L, k=k, x0=x0, fma=True)
+    assert_bitwise(run_fused(device, q0, p0, u, dt, L, k=k, x0=x0, mode=_native.MODE_FMA), want)
+    exact = c_oracle.hmc_sample_gauss(q0, p0, u, dt, L, k=k, x0=x0)
+    same = want['accepted'] == exact['accepted']
+    assert np.abs(want['q_out'][same] - exact['q_out'][same]).max() <= REL_TOL_FMA * np.abs(exact['q_out']).max()
+
+
+def test_fma_mode_bitwise_with_adaption_on_the_per_step_tier_and_for_long_chains(device):
+    rs = np.random.RandomState(77)
+    # per-chain step sizes + adaption, the persistent kernel
+    C, D, L = 70, 768, 5
+    q0, p0, u, dts = rs.standard_normal((C, D)), rs.standard_normal((C, D)), rs.uniform(size=C), rs.uniform(0.05, 0.4, size=C)
+    want = c_oracle.hmc_sample_gauss(q0, p0, u, dts, L, adapt=True, fma=True)
+    got = run_fused(device, q0, p0, u, 9.0, L, dt_chain=dts, adapt=True, mode=_native.MODE_FMA)
+    assert_bitwise(got, want)
+    assert np.array_equal(got['timestep_out'], want['timestep_out'])
+    # several transitions per launch
+    n, C, D, L = 4, 2100, 256, 3
+    q0, p0, u = rs.standard_normal((C, D)), rs.standard_normal((n, C, D)), rs.uniform(size=(n, C))
+    s = HMCSampler(IsotropicGaussian(2.5, 0.3), dev_t(q0, device), 0.15, L, variable_name='x', mode='fma')
+    rec = s.sample_n(n, p0=dev_t(p0, device), u=dev_t(u, device)).cpu().numpy()
+    q = q0
+    for i in range(n):
+        q = c_oracle.hmc_sample_gauss(q, p0[i], u[i], 0.15, L, k=2.5, x0=0.3, fma=True, nthreads=8)['q_out']
+        assert np.array_equal(rec[i], q), i
+    # the per-step tier (kick / drift kernels) and the long-chain kernels
+    for D, C in ((300, 16), (9000, 3), (16384, 2)):
+        q0, p0, u = rs.standard_normal((C, D)), rs.standard_normal((C, D)), rs.uniform(size=C)
+        want = c_oracle.hmc_sample_gauss(q0, p0, u, 0.02, 4, k=2.5, x0=0.3, fma=True)
+        for generic in (False, True):
+            pdf = IsotropicGaussian(2.5, 0.3)
+            if generic:
+                pdf.native_hmc_spec = lambda name: None
+            s = HMCSampler(pdf, dev_t(q0, device), 0.02, 4, variable_name='x', mode='fma', record_energies=True)
+            out = s.sample(p0=dev_t(p0, device), u=dev_t(u, device)).cpu().numpy()
+            assert np.array_equal(out, want['q_out']), (D, generic)
+            assert np.array_equal(s.last_e_after.cpu().numpy(), want['e_after'])
+            assert np.array_equal(s.last_move_accepted.cpu().numpy(), want['accepted'].astype(bool))
+
+
 def test_sweep_contains_rejections(device):
     rs = np.random.RandomState(5)
     C, D, L, dt = 256, 1024, 20, 0.2

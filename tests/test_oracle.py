@@ -78,6 +78,38 @@ def test_c_oracle_equals_numpy_restatement(D, L, k, x0, dt):
         assert np.array_equal(a[key], b[key]), key
 
 
+def test_c_oracle_fma_mode_is_one_correctly_rounded_fused_multiply_add_per_update():
+    """The checker of the package's FMA mode (``c_oracle.hmc_sample_gauss(fma=True)``): each leapfrog
+    update ``p -= dt * g`` / ``q += p * dt`` as ONE fused multiply-add, everything else rounded as in
+    EXACT mode.  Re-derived here in exact rational arithmetic (``float(Fraction)`` rounds correctly),
+    sharing no code with the C file: same bits."""
+    from fractions import Fraction as F
+
+    def fma(a, b, c):
+        return float(F(a) * F(b) + F(c))
+
+    rs = np.random.RandomState(12)
+    C, D, L, k, x0, dt = 3, 9, 4, 2.5, 0.3, 0.37
+    q0, p0 = rs.standard_normal((C, D)), rs.standard_normal((C, D))
+    got = c_oracle.hmc_sample_gauss(q0, p0, np.zeros(C), dt, L, k=k, x0=x0, fma=True)   # u = 0: accepted
+    plain = c_oracle.hmc_sample_gauss(q0, p0, np.zeros(C), dt, L, k=k, x0=x0)
+    assert got['accepted'].all() and not np.array_equal(got['q_out'], plain['q_out'])
+    assert np.abs(got['q_out'] - plain['q_out']).max() < 1e-14
+    for c in range(C):
+        q, p = [float(v) for v in q0[c]], [float(v) for v in p0[c]]
+        grad = lambda x: k * (x - x0)
+        h = 0.5 * dt
+        p = [fma(-h, grad(x), m) for x, m in zip(q, p)]
+        for _ in range(L - 1):
+            q = [fma(m, dt, x) for x, m in zip(q, p)]
+            p = [fma(-dt, grad(x), m) for x, m in zip(q, p)]
+        q = [fma(m, dt, x) for x, m in zip(q, p)]
+        p = [fma(-h, grad(x), m) for x, m in zip(q, p)]
+        assert np.array_equal(np.array(q), got['q_out'][c])
+        want_e = 0.5 * k * np.sum((np.array(q) - x0) ** 2) + 0.5 * np.sum(np.array(p) ** 2)
+        assert got['e_after'][c] == want_e
+
+
 def test_adaption_multiplies_uprate_on_accept():
     # quirk Q3: reference hmc.py:188-191 (docstring says the opposite)
     s = R.RefHMCSampler(R.GaussianPDF(), np.zeros(4), 0.1, 1,
