@@ -732,6 +732,11 @@ def main():
                     'hbm_frac_measured': hbm_meas,
                     'fp64_valu_frac': valu_frac,
                     'single_sample_call_frac': None if single is None else single['frac'],
+                    # the other arithmetic mode beside the headline's (other_mode below): 'fma' = each
+                    # leapfrog update one fused multiply-add, bit for bit the fused C oracle, within
+                    # north_star's 1e-10 of 'exact' with the same golden accept flags
+                    'other_mode': None if other is None else other['mode'],
+                    'other_mode_contract_frac': None if other is None else other['roofline_frac'],
                     'in_one_sentence': 'north_star asks for >= 0.60 of the HBM roofline: met by the '
                                        'contract reading only (SURVEY 8(d) prices every transition at the '
                                        'bytes of a stand-alone sample()); the persistent kernel keeps q in '
