@@ -13,7 +13,7 @@ step() {                                  # step <seconds> <name> <args...>
     tail -1 $O/$name.log
     return $rc
 }
-step 300 fuzz_models 700 81 && step 300 fuzz_gauss 9000 82 && step 120 fuzz_reductions 5000 83 && step 200 fuzz_gibbs_n 10000 84
+step 300 fuzz_models 700 81 && step 300 fuzz_gauss 9000 82 && step 120 fuzz_reductions 5000 83 && step 200 fuzz_gibbs_n 10000 84 && step 200 fuzz_graph 8000 85
 rc=$?
 grep -c MISMATCH $O/*.log || true
 exit $rc
