@@ -184,7 +184,11 @@ class HMCSampler(object):
             if drawn is not None:
                 return drawn
         both = getattr(self.rng, 'normal_uniform', None)
-        if p0 is None and u is None and both is not None:
+        graphed = (kind is None or kind.hmc is None) and self.graph and q0.is_cuda and \
+            (self.graph == 'always' or q0.numel() <= GRAPH_MAX_ELEMENTS)
+        if graphed and p0 is None and u is None and hasattr(self.rng, 'fill_normal_uniform'):
+            own_p = True                           # drawn straight into the graph's input buffers
+        elif p0 is None and u is None and both is not None:
             p0, u = both((C, D), C, dev)           # one launch for the transition's two draws
             own_p = True
         elif p0 is None:
@@ -193,7 +197,7 @@ class HMCSampler(object):
         else:
             p0 = (p0 if p0.dim() == 2 else p0.reshape(1, -1)).contiguous()
             own_p = False
-        if u is None:
+        if u is None and p0 is not None:
             u = self.rng.uniform(C, dev)
 
         adapt = (self.counter + 1) < self.timestep_adaption_limit
@@ -206,8 +210,7 @@ class HMCSampler(object):
         accepted = torch.empty(C, dtype=torch.uint8, device=dev)
         if kind is not None and kind.hmc is not None:
             q_out = kind.hmc(self, spec, q0, p0, u, accepted, adapt)
-        elif self.graph and q0.is_cuda and (self.graph == 'always' or
-                                            q0.numel() <= GRAPH_MAX_ELEMENTS):
+        elif graphed:
             q_out = self._sample_graphed(name, state, q0, p0, own_p, u, accepted, adapt)
         else:
             q_out = self._sample_generic(name, state, q0, p0, own_p, u,
@@ -680,22 +683,31 @@ class HMCSampler(object):
         out of them, so no tensor handed out is ever written again."""
         key = self._graph_key(state, q0, adapt)
         entry = self._graphs.get(key)
+        if entry is None and key in self._graph_warm:
+            entry = self._capture(key, name, state, q0, adapt)
         if entry is None:
-            if key not in self._graph_warm:
+            # first call with this configuration (it also warms everything up), or graphs are off
+            if self.graph and key not in self._graph_warm:
                 self._graph_warm.add(key)
                 if len(self._graph_warm) > 4 * GRAPH_MAX_CAPTURES:
                     self._graph_gives_up('%d configurations seen, none twice' % len(self._graph_warm))
-                return self._sample_generic(name, state, q0, p0, own_p, u, accepted, adapt)
-            entry = self._capture(key, name, state, q0, u, adapt)
-            if entry is None:                          # capture refused: eager from now on
-                return self._sample_generic(name, state, q0, p0, own_p, u, accepted, adapt)
+            if p0 is None:                             # the draws sample() left to the graph's buffers
+                both = getattr(self.rng, 'normal_uniform', None)
+                p0, u = both(tuple(q0.shape), q0.shape[0], q0.device) if both is not None else \
+                    (self.rng.normal(tuple(q0.shape), q0.device), self.rng.uniform(q0.shape[0], q0.device))
+            return self._sample_generic(name, state, q0, p0, own_p, u, accepted, adapt)
         g, q_in, p_in, u_in, acc, q_out, e_b, e_a = entry
         q_in.copy_(q0)
-        p_in.copy_(p0)
-        u_in.copy_(u.reshape(u_in.shape))
+        if p0 is None:
+            self.rng.fill_normal_uniform(p_in, u_in)   # same values and stream positions as eager
+        else:
+            p_in.copy_(p0)
+            u_in.copy_(u.reshape(u_in.shape))
         g.replay()
         accepted.copy_(acc)
-        self.last_e_before, self.last_e_after = e_b.clone(), e_a.clone()
+        # (record_energies: private copies; otherwise the graph's own buffers, valid until the next call)
+        self.last_e_before, self.last_e_after = (e_b.clone(), e_a.clone()) if self.record_energies \
+            else (e_b, e_a)
         return q_out.clone()
 
     def _graph_gives_up(self, why):
@@ -708,12 +720,12 @@ class HMCSampler(object):
         self.graph = False
         self.reset_graph()
 
-    def _capture(self, key, name, state, q0, u, adapt):
+    def _capture(self, key, name, state, q0, adapt):
         if self._graph_captures >= 4 * GRAPH_MAX_CAPTURES:
             self._graph_gives_up('%d captures' % self._graph_captures)
             return None
         q_in, p_in = torch.empty_like(q0), torch.empty_like(q0)
-        u_in = torch.empty_like(u.reshape(-1))
+        u_in = torch.empty(q0.shape[0], dtype=torch.float64, device=q0.device)
         acc = torch.empty(q0.shape[0], dtype=torch.uint8, device=q0.device)
         g = torch.cuda.CUDAGraph()
         try:

@@ -138,6 +138,18 @@ class DeviceRNG(object):
         self.offset += 2
         return p, u
 
+    def fill_normal_uniform(self, p, u):
+        """:meth:`normal_uniform` into the caller's contiguous buffers ``p`` ``[C x D]`` and ``u``
+        ``[C]`` (the input buffers of a captured HIP graph): same values, same stream positions."""
+        if self._normal_kind != 'normal_zig':
+            self.fill_normal(p)
+            self.fill_uniform(u)
+            return
+        from binf_amd import _native
+        _native.rng_fill_normal_zig_uniform(p, u, self.seed, self.offset, self.offset + 1,
+                                            self._elem_offset(p.shape), self._elem_offset(u.shape))
+        self.offset += 2
+
     def gamma(self, shape, n, device):
         """Gamma(shape, 1) variates, one per chain (GammaSampler's ``gamma=``)."""
         return self._fill('gamma', (int(n),), device, 128, shape=shape)

@@ -197,3 +197,22 @@ def test_gibbs_keeps_conditional_parameters_in_place_for_a_graphed_subsampler(de
     gg._update_conditional_pdf_params()                     # what the next sub-step does first
     assert cond['precision'].value.data_ptr() == ptr
     assert torch.equal(cond['precision'].value, gg.state.variables['precision'])
+
+
+def test_device_generator_draws_straight_into_the_graph_buffers(device):
+    """Without supplied draws a graphed sampler lets its DeviceRNG fill the graph's input buffers
+    directly (no copy): the same values and stream positions as the eager sampler's draws."""
+    from binf_amd.samplers.rng import DeviceRNG
+    q0 = torch.randn((50, 40), dtype=torch.float64, device=device) * 0.5
+    e = HMCSampler(DoubleWell(), q0.clone(), 0.1, 4, variable_name='x', rng=DeviceRNG(11, device),
+                   timestep_adaption_limit=3)
+    g = HMCSampler(DoubleWell(), q0.clone(), 0.1, 4, variable_name='x', rng=DeviceRNG(11, device),
+                   timestep_adaption_limit=3, graph=True)
+    for i in range(8):
+        assert torch.equal(e.sample(), g.sample()), i
+        assert torch.equal(e.last_move_accepted, g.last_move_accepted)
+        assert e.rng.offset == g.rng.offset
+    assert len(g._graphs) == 2 and torch.equal(e.n_accepted, g.n_accepted)
+    # sample_n on the per-step tier loops over sample(): graphed too
+    a, b = e.sample_n(5, thin=2), g.sample_n(5, thin=2)
+    assert torch.equal(a, b) and torch.equal(e.accepted_history, g.accepted_history)
