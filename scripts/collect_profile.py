@@ -34,6 +34,11 @@ for name in ('bench_gloo2', 'bench_gloo2_strong'):
     if os.path.exists(f) and open(f).read().strip():
         last = open(f).read().strip().splitlines()[-1]
         open(os.path.join(P, '%s_%s_rehearsal.json' % (tag, name)), 'w').write(last + '\n')
+for name, out in (('bench_force_dist_rccl', 'bench_force_dist_rccl_1rank'), ('bench_generic', 'bench_generic_graph')):
+    f = os.path.join(G, name + '.json')
+    if os.path.exists(f) and open(f).read().strip():
+        last = open(f).read().strip().splitlines()[-1]
+        open(os.path.join(P, '%s_%s.json' % (tag, out)), 'w').write(last + '\n')
 for name in ('pytest_tail.txt', 'smoke.txt'):
     shutil.copy(os.path.join(G, name), os.path.join(P, '%s_%s' % (tag, name)))
 b = json.load(open(os.path.join(G, 'bench.json')))

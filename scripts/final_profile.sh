@@ -59,6 +59,10 @@ timeout -k 10 300 $R/scripts/mfma64_duty 1.0 > $O/mfma64_duty.jsonl
 # the multi-rank control flow with the C4 / C5 legs: 2 gloo ranks sharing this GPU (a rehearsal)
 (cd $R && BINF_BENCH_BACKEND=gloo python3 bench.py --gpus 2 --no-cpu-baseline > $O/bench_gloo2.json 2> $O/bench_gloo2.err)
 (cd $R && BINF_BENCH_BACKEND=gloo python3 bench.py --gpus 2 --scaling strong --no-cpu-baseline > $O/bench_gloo2_strong.json 2>> $O/bench_gloo2.err)
+# ... and the same control flow through RCCL itself with the one rank this box allows
+(cd $R && BINF_BENCH_FORCE_DIST=1 python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_force_dist_rccl.json 2> $O/bench_force_dist.err)
+# the per-step tier on a user's torch PDF, eager launches and HIP-graph replay
+(cd $R && python3 scripts/bench_generic.py > $O/bench_generic.json 2>/dev/null)
 # C5 (pair-distance model)
 for C in 256 2048; do
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_dist_$C -- python3 $R/scripts/bench_distance.py $C > $O/bench_distance_$C.json 2>/dev/null
