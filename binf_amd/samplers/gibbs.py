@@ -42,10 +42,9 @@ class GibbsSampler(object):
         current = self._state.variables
         already_fixed = {x: self._pdf[x].value for x in self._pdf.parameters
                          if x in self._pdf._original_variables}
-        stable = self._stable()
+        self._own = {}                    # (variable, parameter) -> the conditional's private buffer
         for var in current:
-            fixed = {x: (v.clone() if stable and _is_tensor(v) else v)
-                     for x, v in current.items() if x != var}
+            fixed = {x: v for x, v in current.items() if x != var}
             fixed.update(already_fixed)
             cond = self._pdf.conditional_factory(**fixed)
             self._conditional_pdfs[var] = cond
@@ -59,15 +58,23 @@ class GibbsSampler(object):
     def _update_conditional_pdf_params(self):
         current = self._state.variables
         stable = self._stable()
-        for cond in self._conditional_pdfs.values():
+        own = getattr(self, '_own', None)
+        if own is None:
+            own = self._own = {}
+        for var, cond in self._conditional_pdfs.items():
             for param in cond.parameters:
                 if param in current:
-                    new, old = current[param], cond[param].value
-                    if stable and _is_tensor(new) and _is_tensor(old) and old is not new and \
-                            old.shape == new.shape and old.dtype == new.dtype and \
-                            old.device == new.device:
-                        old.copy_(new)          # the conditional's own buffer (see stable_parameters)
-                        new = old
+                    new = current[param]
+                    if stable and _is_tensor(new):
+                        # the conditional's OWN buffer, refreshed in place (see stable_parameters);
+                        # never a tensor of the state, which callers may hold
+                        buf = own.get((var, param))
+                        if buf is None or buf.shape != new.shape or buf.dtype != new.dtype or \
+                                buf.device != new.device:
+                            buf = own[(var, param)] = new.clone()
+                        elif buf is not new:
+                            buf.copy_(new)
+                        new = buf
                     cond[param].set(new)
 
     def _checkstate(self, state):

@@ -194,6 +194,15 @@ def test_gibbs_keeps_conditional_parameters_in_place_for_a_graphed_subsampler(de
     cond = gg._conditional_pdfs['coefficients']
     ptr = cond['precision'].value.data_ptr()
     assert ptr != gg.state.variables['precision'].data_ptr()
+    # switching graph mode on AFTER the Gibbs sampler exists must not turn a state tensor into a
+    # buffer either: the first refresh gives the conditional a private copy
+    first = ge.state.variables['precision']
+    keep = first.clone()
+    he.graph = True
+    for _ in range(3):
+        ge.sample()
+    assert torch.equal(first, keep) and ge._stable()
+    assert ge._conditional_pdfs['coefficients']['precision'].value.data_ptr() != first.data_ptr()
     gg._update_conditional_pdf_params()                     # what the next sub-step does first
     assert cond['precision'].value.data_ptr() == ptr
     assert torch.equal(cond['precision'].value, gg.state.variables['precision'])
