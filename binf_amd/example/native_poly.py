@@ -139,14 +139,16 @@ def _params(fn):
 # HMCSampler hooks of the kind (binf_amd/native.py)
 # ---------------------------------------------------------------------------
 _POLY_WAVE_MAX_WORK = 2.0e8    # chains x data points x coefficients (see covers)
+# from this many chains on the fused transition lays a chain out on ONE lane (see lane_layout)
+LANE_MIN_CHAINS = 65536
 
 
 def covers(sampler, spec, D, C=None):
     """Is the fused small-data transition the right launch for ``D`` coefficients
-    (and, when given, ``C`` chains)?  ``sampler.fused_polynomial``: True (layout by the
+    (and, when given, ``C`` chains)?  ``sampler.fused_transition``: True (layout by the
     batch), 'group' / 'lane' (one layout whatever the batch), 'always' (fused even where
     the per-step tier is faster) or False."""
-    mode = getattr(sampler, 'fused_polynomial', True)
+    mode = getattr(sampler, 'fused_transition', True)
     if not mode or D > FUSED_MAX_COEFFS:
         return False
     n_data = len(spec[2].ys)
@@ -165,19 +167,18 @@ def lane_layout(sampler, spec, C):
     """One lane per chain (csrc/hmc_poly.hip) instead of a lane group
     (csrc/poly_chain_kernel.hpp) for the fused polynomial transition?  A lane
     group fills the chip from a few thousand chains (20.7 vs 42 us per
-    transition at 4096 chains); with POLY_LANE_MIN_CHAINS chains and more every
+    transition at 4096 chains); with LANE_MIN_CHAINS chains and more every
     SIMD has work either way and one lane per chain does half the instructions
     (2^20 chains: 0.5 vs ~2 ms).  The energies are the same bits in both; the
     force is summed in data order vs partial sums + butterfly, so a chain's
     trajectory differs at rounding level between batches on either side of the
     threshold (like the MFMA gradient's batch-dependent order)."""
-    from binf_amd.samplers import hmc
-    mode = getattr(sampler, 'fused_polynomial', True)
+    mode = getattr(sampler, 'fused_transition', True)
     if mode == 'lane':
         return True
     if mode in ('group', False):
         return False
-    return len(spec[2].ys) <= 128 and C >= hmc.POLY_LANE_MIN_CHAINS
+    return len(spec[2].ys) <= 128 and C >= LANE_MIN_CHAINS
 
 
 def hmc_sample(sampler, spec, q0, p0, u, accepted, adapt):
@@ -349,7 +350,7 @@ def gibbs_sample_n(gibbs, n, thin, record):
     # per sampler pair and batch shape: a sweep per launch would otherwise spend more
     # time recognising itself than running
     key = (id(cs), id(ps), id(cs.pdf), id(ps.pdf), C, K, dev,
-           getattr(cs, 'fused_polynomial', None), getattr(cs, '_variable_name', None))
+           getattr(cs, 'fused_transition', None), getattr(cs, '_variable_name', None))
     cache = gibbs.__dict__.setdefault('_fused_structure', {})
     st = cache.get(key)
     if st is None:

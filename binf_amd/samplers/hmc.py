@@ -10,9 +10,8 @@ tensor (a ``[D]`` tensor is one chain).  All arithmetic runs in HIP kernels:
 * fused tier  -- the PDF advertises a native trajectory kernel
   (``pdf.native_hmc_spec(name) -> (kind, *params)``, a kind registered with
   ``binf_amd.native``): the whole transition is one launch with q, p held in
-  registers.  The sampler never names a model: the isotropic Gaussian's kernels
-  are the built-in kind ``'gauss'`` (registered at the bottom of this module),
-  everything else registers itself (``binf_amd/native.py``);
+  registers.  The sampler never names a model: every kind registers itself
+  (``binf_amd/native.py``) from the module that defines its model;
 * generic tier -- any PDF with ``log_prob`` / ``gradient`` returning batched
   tensors: kick / drift / energy / accept are separate launches around the
   user's gradient.
@@ -95,12 +94,10 @@ class HMCSampler(object):
         self.accepted_history = None      # [n x C] flags of the last sample_n()
         self.fused_leapfrog = True        # use a PDF's fused leapfrog kernel if it has one
         self.fused_energy = True          # ... and its one-launch energy (native_energy_spec)
-        # ... and the fused small-data polynomial transition: True (layout by the batch:
-        # a chain's data spread over a lane group up to POLY_LANE_MIN_CHAINS chains, one
-        # lane per chain from there on when there are <= 128 data points -- same energies,
-        # the force summed in another order), 'group' / 'lane' (one layout whatever the
-        # batch), 'always' (fused even where the per-step tier is faster) or False
-        self.fused_polynomial = True
+        # ... and a registered kind's whole-transition kernel: True (the kind decides where it is
+        # the right launch), False (never: the per-step tier), or a value of the kind's own
+        # (read by its hooks; the polynomial kind: 'group' / 'lane' / 'always')
+        self.fused_transition = True
 
     # -- reference attributes ----------------------------------------------
     @property
@@ -299,245 +296,13 @@ class HMCSampler(object):
         """``sample_n(n, thin)`` with ``thin > n`` records nothing: ``[0, *state shape]``."""
         return torch.empty((0,) + tuple(shape), dtype=torch.float64, device=dev)
 
-    # -- the built-in kind 'gauss': n transitions ------------------------------------
-    def _gauss_sample_n(self, spec, n, thin, p0, u, record, out, q0, shape):
-        """``hmc_n`` hook of the isotropic Gaussian: ONE launch of the persistent
-        kernel (state kept in registers between transitions; D <= 8192), the chunked
-        kernels for longer chains.  Returns ``(True, (q_out, samples))``."""
-        C, D = q0.shape
-        dev = q0.device
-        nrec = n // thin
-        persist = _native.gauss_persist_covers(D)
-        fused_rng = p0 is None and u is None and self._fused_rng(spec) and persist
-        if fused_rng and not self._draws_in_kernel(C, D):
-            # a small batch: the split kernel with the draws in HBM is the faster
-            # launch, so the SAME lane-stream draws are written out first (a seed
-            # identifies the draws whatever the batch size)
-            p0, u = _native.hmc_gauss_rng_draws(n, C, D, self.rng.seed, self.rng.offset,
-                                                dev, chain_offset=self._chain_offset())
-            self._take_positions(n)             # taken once the launch is in
-            fused_rng = False
-        if persist and not fused_rng and (p0 is None or u is None):
-            # the draws of n sample() calls in the order those calls consume the
-            # generator: normal, uniform, normal, uniform, ... (hmc.py:146,151)
-            dp = torch.empty((n, C, D), dtype=torch.float64, device=dev) if p0 is None else None
-            du = torch.empty((n, C), dtype=torch.float64, device=dev) if u is None else None
-            for i in range(n):
-                if dp is not None:
-                    _fill(self.rng, 'normal', dp[i])
-                if du is not None:
-                    _fill(self.rng, 'uniform', du[i])
-            p0 = dp if p0 is None else p0
-            u = du if u is None else u
-        if not persist:
-            return True, self._sample_n_long(spec, n, thin, p0, u, record, out, q0, shape, nrec)
-
-        _, k, x0 = spec
-        n_adapt = max(0, min(n, self.timestep_adaption_limit - 1 - self.counter))
-        if n_adapt > 0 and self._dt_chain is None:
-            self._dt_chain = torch.full((C,), float(self._timestep),
-                                        dtype=torch.float64, device=dev)
-        if not isinstance(self.n_accepted, torch.Tensor):
-            self.n_accepted = torch.zeros(C, dtype=torch.int64, device=dev)
-        q_out = torch.empty_like(q0)
-        if out is not None:
-            samples = out.view(nrec, C, D)
-        else:
-            samples = torch.empty((nrec, C, D), dtype=torch.float64, device=dev) \
-                if (record and nrec > 0) else None
-        accepted = torch.empty((n, C), dtype=torch.uint8, device=dev)
-        eb = ea = None
-        if self.record_energies:
-            eb = torch.empty((n, C), dtype=torch.float64, device=dev)
-            ea = torch.empty((n, C), dtype=torch.float64, device=dev)
-        if fused_rng:
-            _native.hmc_sample_n_gauss_rng(q0, q_out, samples, accepted, self.n_accepted,
-                                           eb, ea, self._timestep, self._dt_chain,
-                                           self.leapfrog_steps, n, thin, k, x0, n_adapt,
-                                           self.adaption_uprate, self.adaption_downrate,
-                                           _MODES[self.mode], self.rng.seed,
-                                           self.rng.offset,
-                                           chain_offset=self._chain_offset())
-            self._take_positions(n)             # taken once the launch is in
-        else:
-            _native.hmc_sample_n_gauss(q0, p0.contiguous(), u.contiguous(), q_out,
-                                       samples, accepted, self.n_accepted, eb, ea,
-                                       self._timestep, self._dt_chain, self.leapfrog_steps,
-                                       n, thin, k, x0, n_adapt,
-                                       self.adaption_uprate,
-                                       self.adaption_downrate, _MODES[self.mode])
-        self.last_e_before, self.last_e_after = eb, ea
-        self._last_move_accepted = accepted[-1].view(torch.bool)
-        self.accepted_history = accepted.view(torch.bool)
-        self.counter += n
-        return True, (q_out, samples)
-
-    def _gauss_sample_rng(self, spec, q0, shape):
-        """``hmc_rng`` hook of the isotropic Gaussian: with a generator whose draws are
-        the lane streams of the fused kernels, sample() is one launch that draws for
-        itself; None with any other generator."""
-        if not self._fused_rng(spec):
-            return None
-        if _native.gauss_persist_covers(q0.shape[1]):
-            return self._sample_n_fused_rng(1)
-        return self._sample_long_fused_rng(spec, q0, shape)
-
-    # -- fused tier ----------------------------------------------------------
-    def _fused_rng(self, name_or_spec, D=None, spec=False):
-        """True if this sampler's draws are the lane streams of the fused Gaussian
-        kernels (csrc/xoshiro.hpp): a device generator that allows it and a PDF of the
-        built-in kind.  Depends on the PDF only, never on the number of chains -- so a
-        shard of a run draws what the whole run draws for its chains.  Called with the
-        PDF's spec, or with ``(variable name, D)`` to look it up."""
-        if not getattr(self.rng, 'fused', False):
-            return False
-        if isinstance(name_or_spec, str):
-            if spec is False:
-                spec = self._fused_spec(name_or_spec, D)
-        else:
-            spec = name_or_spec
-        return spec is not None and spec[0] == GAUSS
-
-    def _draws_in_kernel(self, C, D):
-        """Lane-stream draws: generated inside the sampling kernel (True) or
-        written out first by the draw kernel and read back (False)?  Same draws
-        either way; this only picks the faster launch.  Up to 1024 chains of
-        D = 768 / 1024 the library spreads a chain over 4 waves when the draws
-        come from HBM (hmc_gauss_split.hip); that beats the one-wave kernel with
-        its own generator (512 chains: 4.0 vs 10.5 us per transition,
-        scripts/probe_small_batch_rng.py)."""
-        if getattr(self.rng, 'fused', False) == 'always':
-            return True
-        return D > 1024 or _native.gauss_waves_per_chain(C, D) < 4
-
-    def _chain_offset(self):
-        return int(getattr(self.rng, 'chain_offset', 0))
-
-    def _take_positions(self, n):
-        """Reserve the lane streams' positions of ``n`` transitions -- one per
-        ``sample()`` call, whatever the call shape: ``sample_n(n)`` draws what n
-        ``sample()`` calls draw.  Returns the first."""
-        first = self.rng.offset
-        self.rng.offset += int(n)
-        return first
-
-    def _sample_long_fused_rng(self, spec, q0, shape):
-        """sample() for chains beyond the persistent kernel's reach with the
-        draws generated in the kernels (csrc/hmc_gauss_big.hip)."""
-        _, k, x0 = spec
-        C = q0.shape[0]
-        dev = q0.device
-        adapt = (self.counter + 1) < self.timestep_adaption_limit
-        if adapt and self._dt_chain is None:
-            self._dt_chain = torch.full((C,), float(self._timestep), dtype=torch.float64,
-                                        device=dev)
-        if not isinstance(self.n_accepted, torch.Tensor):
-            self.n_accepted = torch.zeros(C, dtype=torch.int64, device=dev)
-        accepted = torch.empty(C, dtype=torch.uint8, device=dev)
-        q_out = torch.empty_like(q0)
-        eb = ea = None
-        if self.record_energies:
-            eb = torch.empty(C, dtype=torch.float64, device=dev)
-            ea = torch.empty(C, dtype=torch.float64, device=dev)
-        _native.hmc_sample_gauss_big_rng(q0, q_out, accepted, self.n_accepted, eb, ea,
-                                         self._timestep, self._dt_chain, self.leapfrog_steps, k, x0,
-                                         adapt, self.adaption_uprate, self.adaption_downrate,
-                                         _MODES[self.mode], self.rng.seed,
-                                         self.rng.offset,
-                                         chain_offset=self._chain_offset())
-        self._take_positions(1)
-        self.last_e_before, self.last_e_after = eb, ea
-        self._last_move_accepted = accepted.view(torch.bool)
-        self.counter += 1
-        self.state = q_out.view(shape)
-        return self.state
-
-    def _sample_n_long(self, spec, n, thin, p0, u, record, out, q0, shape, nrec):
-        """sample_n for chains beyond the persistent kernel's reach
-        (csrc/hmc_gauss_big.hip): n transitions from one call, every recorded
-        state written where it is kept; the draws are supplied, generated in the
-        kernels (a generator with lane streams: exactly the draws of n sample()
-        calls) or drawn a block of transitions at a time."""
-        _, k, x0 = spec
-        C, D = q0.shape
-        dev = q0.device
-        n_adapt = max(0, min(n, self.timestep_adaption_limit - 1 - self.counter))
-        if n_adapt > 0 and self._dt_chain is None:
-            self._dt_chain = torch.full((C,), float(self._timestep), dtype=torch.float64, device=dev)
-        if not isinstance(self.n_accepted, torch.Tensor):
-            self.n_accepted = torch.zeros(C, dtype=torch.int64, device=dev)
-        samples = None
-        if record and nrec > 0:
-            samples = out.view(nrec, C, D) if out is not None else \
-                torch.empty((nrec, C, D), dtype=torch.float64, device=dev)
-        accepted = torch.empty((n, C), dtype=torch.uint8, device=dev)
-        eb = ea = None
-        if self.record_energies:
-            eb = torch.empty((n, C), dtype=torch.float64, device=dev)
-            ea = torch.empty((n, C), dtype=torch.float64, device=dev)
-        q_out = torch.empty_like(q0)
-        args = (self._timestep, self._dt_chain, self.leapfrog_steps)
-        tail = (k, x0, n_adapt, self.adaption_uprate, self.adaption_downrate, _MODES[self.mode])
-        if p0 is None and u is None and self._fused_rng(spec):
-            _native.hmc_sample_n_gauss_big(q0, None, None, q_out, samples, accepted, self.n_accepted,
-                                           eb, ea, *args, n, thin, *tail,
-                                           rng=(self.rng.seed, self.rng.offset, self._chain_offset()))
-            self._take_positions(n)                 # n sample() calls take n stream positions
-        elif p0 is not None and u is not None:
-            _native.hmc_sample_n_gauss_big(q0, p0.reshape(n, C, D).contiguous(),
-                                           u.reshape(n, C).contiguous(), q_out, samples, accepted,
-                                           self.n_accepted, eb, ea, *args, n, thin, *tail)
-        else:
-            # draws from the sampler's generator, a block of transitions at a time (<= 1 GiB
-            # of momenta), in the order n sample() calls consume it: normal, uniform, ...
-            block = max(1, min(n, (1 << 27) // max(1, C * D)))
-            if samples is not None:
-                block = max(thin, block // thin * thin)
-            done, cur = 0, q0
-            while done < n:
-                m = min(block, n - done)
-                dp = p0[done:done + m] if p0 is not None else \
-                    torch.empty((m, C, D), dtype=torch.float64, device=dev)
-                du = u[done:done + m] if u is not None else \
-                    torch.empty((m, C), dtype=torch.float64, device=dev)
-                for i in range(m):
-                    if p0 is None:
-                        _fill(self.rng, 'normal', dp[i])
-                    if u is None:
-                        _fill(self.rng, 'uniform', du[i])
-                nxt = torch.empty_like(q0)
-                r0, r1 = done // thin, (done + m) // thin
-                _native.hmc_sample_n_gauss_big(
-                    cur, dp.contiguous(), du.contiguous(), nxt,
-                    samples[r0:r1] if samples is not None and r1 > r0 else None,
-                    accepted[done:done + m], self.n_accepted,
-                    eb[done:done + m] if eb is not None else None,
-                    ea[done:done + m] if ea is not None else None, *args, m, thin, k, x0,
-                    max(0, min(m, n_adapt - done)), self.adaption_uprate, self.adaption_downrate,
-                    _MODES[self.mode])
-                cur = nxt
-                done += m
-            q_out = cur
-        self.last_e_before, self.last_e_after = eb, ea
-        self._last_move_accepted = accepted[-1].view(torch.bool)
-        self.accepted_history = accepted.view(torch.bool)
-        self.counter += n
-        return q_out, samples
-
-    def _sample_n_fused_rng(self, n):
-        """sample() with in-kernel draws: one transition, the new state."""
-        self.sample_n(n, record=False)
-        if n == 1 and self.last_e_before is not None:
-            self.last_e_before, self.last_e_after = self.last_e_before[0], self.last_e_after[0]
-        return self.state
-
     def _fused_spec(self, name, D, C=None):
         """The PDF's fused-kernel descriptor ``(kind, *params)`` if a registered kind
         covers this shape (and, for ``C`` chains, if its kernel is the faster
         choice -- the kind's ``covers`` hook decides), else None (generic per-step
         tier)."""
         get_spec = getattr(self.pdf, 'native_hmc_spec', None)
-        spec = get_spec(name) if get_spec is not None else None
+        spec = get_spec(name) if (get_spec is not None and self.fused_transition is not False) else None
         if spec is None:
             return None
         kind = native.get(spec)
@@ -546,28 +311,6 @@ class HMCSampler(object):
         if kind.covers is not None and not kind.covers(self, spec, D, C):
             return None
         return spec
-
-    def _poly_lane_layout(self, spec, C):
-        """The layout choice of the fused small-data polynomial transition (kept here
-        for its callers; the decision is the registered kind's: ``extras['lane_layout']``
-        of the module that registers the polynomial kind)."""
-        return native.get(spec).extras['lane_layout'](self, spec, C)
-
-    def _sample_fused_gauss(self, spec, q0, p0, u, accepted, adapt):
-        _, k, x0 = spec
-        C, D = q0.shape
-        q_out = torch.empty_like(q0)
-        eb = ea = None
-        if self.record_energies:
-            eb = torch.empty(C, dtype=torch.float64, device=q0.device)
-            ea = torch.empty(C, dtype=torch.float64, device=q0.device)
-        launch = _native.hmc_sample_gauss if _native.gauss_persist_covers(D) \
-            else _native.hmc_sample_gauss_big       # chains of any length, chunked
-        launch(q0, p0, u, q_out, accepted, self.n_accepted, eb, ea, self._timestep,
-               self._dt_chain, self.leapfrog_steps, k, x0, adapt, self.adaption_uprate,
-               self.adaption_downrate, _MODES[self.mode])
-        self.last_e_before, self.last_e_after = eb, ea
-        return q_out
 
     # -- generic tier --------------------------------------------------------
     def _leapfrog(self, q, p, timestep, nsteps, q_from=None):
@@ -782,11 +525,6 @@ def _graph_signature(pdf, depth=0):
     return (id(pdf), tuple(sig))
 
 
-# From this many chains on, kinds that can lay a chain out either over a lane group or on
-# one lane choose the lane (read by the polynomial kind's lane_layout)
-POLY_LANE_MIN_CHAINS = 65536
-
-
 def _device_state(state):
     """The sampler state as it is -- except a numpy array, refused by name (the reference's
     states are numpy arrays; here they are ROCm tensors and there is no CPU path).  Anything
@@ -818,17 +556,3 @@ def _as_chain_vector(x):
         raise TypeError('pdf.log_prob must return a tensor with one value per '
                         'chain, got %r' % type(x))
     return x.reshape(-1)
-
-
-# ---------------------------------------------------------------------------
-# the built-in kind: the isotropic Gaussian (``binf_amd.pdf.IsotropicGaussian``
-# returns ``('gauss', k, x0)`` from ``native_hmc_spec``), SURVEY 8(a) rows a1-a5, a16
-# ---------------------------------------------------------------------------
-GAUSS = 'gauss'
-native.register(
-    GAUSS, replace=True,
-    hmc=lambda sampler, spec, q0, p0, u, accepted, adapt:
-        sampler._sample_fused_gauss(spec, q0, p0, u, accepted, adapt),
-    hmc_rng=lambda sampler, spec, q0, shape: sampler._gauss_sample_rng(spec, q0, shape),
-    hmc_n=lambda sampler, spec, n, thin, p0, u, record, out, q0, shape:
-        sampler._gauss_sample_n(spec, n, thin, p0, u, record, out, q0, shape))

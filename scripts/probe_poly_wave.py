@@ -29,6 +29,6 @@ for K, N, L in ((4, 200, 50), (8, 512, 20), (16, 1024, 20)):
         row = []
         for fused in (True, False):
             s = HMCSampler(cond, q0, 1e-3 / K, L, variable_name='coefficients', rng=DeviceRNG(1, dev))
-            s.fused_polynomial = fused
+            s.fused_transition = fused
             row.append(timed(s.sample))
         print('K=%2d N=%4d L=%d C=%6d  fused %.3f ms  per-step %.3f ms  x%.1f' % (K, N, L, C, row[0], row[1], row[1] / row[0]))

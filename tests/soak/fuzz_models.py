@@ -160,7 +160,7 @@ for case in range(n_cases):
     for fused in (True, False):
         s = HMCSampler(cond, t(q0), dt, int(rs.randint(1, 12)) if False else 5,
                        variable_name='coefficients')
-        s.fused_polynomial = fused
+        s.fused_transition = fused
         o = s.sample(p0=t(p0), u=t(u))
         res.append((o.cpu().numpy(), s.last_move_accepted.cpu().numpy(),
                     s.last_e_before.cpu().numpy(), s.last_e_after.cpu().numpy()))

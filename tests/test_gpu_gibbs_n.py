@@ -14,7 +14,8 @@ import numpy as np
 import pytest
 import torch
 
-from binf_amd import _native
+from binf_amd import _native, native
+from binf_amd.example import native_poly
 from binf_amd.example.likelihood import POLYVAL, ForwardModel, GaussianErrorModel
 from binf_amd.example.misc import make_posterior
 from binf_amd.example.priors import GammaPrior, GaussianPrior
@@ -363,22 +364,21 @@ def test_hmc_sample_n_on_the_coefficient_conditional_is_n_sample_calls(device, K
 
 
 def test_layout_of_the_fused_transition_follows_the_batch_consistently(device):
-    """Up to POLY_LANE_MIN_CHAINS chains a chain's data are spread over a lane group,
+    """Up to LANE_MIN_CHAINS chains a chain's data are spread over a lane group,
     from there on (<= 128 data points) a chain is one lane -- for sample(), for the
     one-launch sweep and for sample_n alike, so the three agree bit for bit at any
     batch size; the two layouts differ at rounding level only (the force's order)."""
-    from binf_amd.samplers import hmc as H
-    assert H.POLY_LANE_MIN_CHAINS == 65536
-    old = H.POLY_LANE_MIN_CHAINS
-    H.POLY_LANE_MIN_CHAINS = 64              # the rule with a threshold a test can afford
+    assert native_poly.LANE_MIN_CHAINS == 65536
+    old = native_poly.LANE_MIN_CHAINS
+    native_poly.LANE_MIN_CHAINS = 64              # the rule with a threshold a test can afford
     try:
         K, N, n = 4, 20, 4
         for C in (63, 64):
             a = build(device, 'hmc', K, N, C, 1, DeviceRNG(2, device))
             b = build(device, 'hmc', K, N, C, 1, DeviceRNG(2, device))
             c = build(device, 'hmc', K, N, C, 1, DeviceRNG(2, device))
-            assert a.subsamplers['coefficients']._poly_lane_layout(
-                a.subsamplers['coefficients'].pdf.native_hmc_spec('coefficients'), C) is (C >= 64)
+            spec = a.subsamplers['coefficients'].pdf.native_hmc_spec('coefficients')
+            assert native.get(spec).extras['lane_layout'](a.subsamplers['coefficients'], spec, C) is (C >= 64)
             cs, ts, _ = run_loop(a, n)                      # per-variable sweeps
             rec = b.sample_n(n)                             # one call
             for _ in range(n):
@@ -387,8 +387,8 @@ def test_layout_of_the_fused_transition_follows_the_batch_consistently(device):
             assert torch.equal(c.state.variables['coefficients'], cs[-1])
         # the same chains under the two layouts: equal to 1e-12, not to the bit
         g = build(device, 'hmc', K, N, 64, 1, DeviceRNG(2, device))
-        g.subsamplers['coefficients'].fused_polynomial = 'group'
+        g.subsamplers['coefficients'].fused_transition = 'group'
         x = g.sample_n(n)['coefficients']
         assert not torch.equal(x, cs) and torch.allclose(x, cs, rtol=1e-10, atol=1e-12)
     finally:
-        H.POLY_LANE_MIN_CHAINS = old
+        native_poly.LANE_MIN_CHAINS = old

@@ -176,7 +176,7 @@ def test_gibbs_keeps_conditional_parameters_in_place_for_a_graphed_subsampler(de
                              graph=graph)
         g.fused_sweep = False
         hmc = g.subsamplers['coefficients']
-        hmc.fused_polynomial = False                 # the per-step tier: gradient launches + kick / drift
+        hmc.fused_transition = False                 # the per-step tier: gradient launches + kick / drift
         rows = []
         for _ in range(sweeps):
             st = g.sample()

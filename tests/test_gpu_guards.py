@@ -111,7 +111,7 @@ def test_polynomial_kernels_stay_inside_their_buffers(device, K, N, C):
 
 
 @pytest.mark.parametrize('K,N,C', [(1, 1, 1), (4, 20, 70), (9, 100, 65), (16, 128, 3)])
-def test_fused_polynomial_transition_stays_inside_its_buffers(device, K, N, C):
+def test_fused_transition_transition_stays_inside_its_buffers(device, K, N, C):
     rs = np.random.RandomState(K * N)
     xs, ys = np.linspace(-1, 1, N), rs.standard_normal(N)
     q0, p0, u = 0.2 * rs.standard_normal((C, K)), rs.standard_normal((C, K)), rs.uniform(size=C)
@@ -304,7 +304,7 @@ def test_contraction_and_term_sum_stay_inside_their_buffers(device, K, N, C, bat
 
 
 @pytest.mark.parametrize('K,N,C,L', [(4, 20, 5, 3), (33, 1000, 20, 2), (33, 16384, 130, 1), (17, 50, 2100, 2)])
-def test_fused_polynomial_leapfrog_stays_inside_its_buffers(device, K, N, C, L):
+def test_fused_transition_leapfrog_stays_inside_its_buffers(device, K, N, C, L):
     rs = np.random.RandomState(K + C)
     xs = np.linspace(-1, 1, N)
     A = np.vstack([xs ** i for i in range(K)])

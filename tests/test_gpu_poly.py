@@ -213,7 +213,7 @@ def test_hmc_on_polynomial_posterior_vs_restatement(device, K, N, C, L, dt, xlim
                           'coefficients_prior': GaussianPrior(np.zeros(K), np.ones(K) * 5)})
     cond = post.conditional_factory(precision=2.5)
     s = HMCSampler(cond, dev_t(q0, device), dt, L, variable_name='coefficients')
-    s.fused_polynomial = False                    # this test is the per-step tier
+    s.fused_transition = False                    # this test is the per-step tier
     out = s.sample(p0=dev_t(p0, device), u=dev_t(u, device)).cpu().numpy()
     acc = s.last_move_accepted.cpu().numpy()
     eb, ea = s.last_e_before.cpu().numpy(), s.last_e_after.cpu().numpy()
@@ -287,7 +287,7 @@ def test_fused_small_polynomial_transition_vs_per_step_tier(device, K, N, C, L, 
     for fused in (True, False):
         s = HMCSampler(cond, dev_t(q0, device), dt, L, timestep_adaption_limit=10,
                        variable_name='coefficients', mode=mode)
-        s.fused_polynomial = fused
+        s.fused_transition = fused
         res = []
         for i in range(2):
             out = s.sample(p0=dev_t(p0[i], device), u=dev_t(u[i], device))
@@ -371,7 +371,7 @@ def test_fused_small_polynomial_transition_vs_oracle(device, K, N, C, L, prior, 
     cond = post.conditional_factory(precision=dev_t(tau, device))
     s = HMCSampler(cond, dev_t(q0, device), dt, L, timestep_adaption_limit=10,
                    variable_name='coefficients')
-    assert s._fused_spec('coefficients', K) is not None and s.fused_polynomial
+    assert s._fused_spec('coefficients', K) is not None and s.fused_transition
     got = []
     for i in range(2):
         out = s.sample(p0=dev_t(p0[i], device), u=dev_t(u[i], device))
@@ -436,7 +436,7 @@ def test_fused_small_polynomial_limits_and_fallback(device):
     assert s._fused_spec('coefficients', 16, 1024) is not None
     assert s._fused_spec('coefficients', 16, 8192) is not None
     assert s._fused_spec('coefficients', 16, 65536) is None
-    s.fused_polynomial = 'always'
+    s.fused_transition = 'always'
     assert s._fused_spec('coefficients', 16, 65536) is not None
     # a posterior with another free variable is not the conditional the kernel integrates
     full = _small_posterior(np.linspace(-1, 1, 20), rs.standard_normal(20), 4, True)
@@ -834,7 +834,7 @@ def test_gamma_prior_log_prob_kernel_equals_the_expression(device):
     (4, 20, 5, 3, 'exact', False), (33, 1000, 20, 4, 'exact', True), (33, 16384, 130, 2, 'exact', False),
     (8, 300, 2100, 3, 'fma', True), (17, 50, 3, 1, 'exact', False), (64, 129, 70, 2, 'fma', False),
     (33, 4096, 2050, 2, 'exact', True)])
-def test_fused_polynomial_leapfrog_is_bit_identical_to_the_per_step_tier(device, K, N, C, L, mode,
+def test_fused_transition_leapfrog_is_bit_identical_to_the_per_step_tier(device, K, N, C, L, mode,
                                                                          per_chain):
     """binf_poly_leapfrog_f64 (gradient + partial-sum reduction + kick + drift per
     launch, the last workgroup of a chain tile combining it) against the per-step
@@ -857,7 +857,7 @@ def test_fused_polynomial_leapfrog_is_bit_identical_to_the_per_step_tier(device,
     for fused in (True, False, True):
         s = HMCSampler(cond, dev_t(theta, device), dt, L, variable_name='coefficients', mode=mode)
         s.fused_leapfrog = fused
-        s.fused_polynomial = False
+        s.fused_transition = False
         q, p = dev_t(theta, device), dev_t(p0, device)
         s._leapfrog(q, p, dts, L)
         outs.append((q, p))
@@ -870,14 +870,14 @@ def test_fused_polynomial_leapfrog_is_bit_identical_to_the_per_step_tier(device,
         s = HMCSampler(cond, dev_t(theta, device), dt, L, variable_name='coefficients', mode=mode,
                        record_energies=True)
         s.fused_leapfrog = fused
-        s.fused_polynomial = False
+        s.fused_transition = False
         x = s.sample(p0=dev_t(p0, device), u=dev_t(rs.uniform(size=C) * 0 + 0.5, device))
         res.append((x, s.last_e_after, s.last_move_accepted))
     for a, b in zip(*res):
         assert torch.equal(a, b)
 
 
-def test_fused_polynomial_leapfrog_argument_checks(device):
+def test_fused_transition_leapfrog_argument_checks(device):
     C, K, N = 8, 4, 20
     q = torch.zeros((C, K), dtype=torch.float64, device=device)
     A = torch.ones((K, N), dtype=torch.float64, device=device)

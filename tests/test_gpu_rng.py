@@ -6,6 +6,7 @@ import pytest
 import torch
 
 from binf_amd import _native
+from binf_amd.pdf import native_gauss
 from binf_amd.pdf import IsotropicGaussian
 from binf_amd.samplers.hmc import HMCSampler
 from binf_amd.samplers.rng import DeviceRNG
@@ -214,7 +215,7 @@ def test_fused_generator_equals_sampling_from_its_own_dump(device, C, D, L, k, x
     dt = 0.9 / np.sqrt(k * max(D, 4))
     kw = dict(timestep_adaption_limit=4, variable_name='x', mode=mode, record_energies=True)
     a = HMCSampler(IsotropicGaussian(k, x0), q0, dt, L, rng=DeviceRNG(seed, device, fused='always'), **kw)
-    assert a._fused_rng('x', D) and a._draws_in_kernel(C, D)
+    assert native_gauss.fused_rng(a, 'x', D) and native_gauss.draws_in_kernel(a, C, D)
     rec_a = a.sample_n(n)                                    # stream positions 0 .. n - 1
     rec_a2 = a.sample_n(2, thin=2)                           # positions n, n + 1 (one per TRANSITION, ABI 5)
     assert a.rng.offset == n + 2
@@ -283,7 +284,7 @@ def test_fused_generator_limits_and_fallback(device):
         _native.hmc_gauss_rng_draws(1, 3, 9000, 0, 0, device)      # the persistent kernel's entry
     # longer chains draw inside the chunked kernels (test below)
     s = HMCSampler(IsotropicGaussian(), z, 0.02, 3, variable_name='x', rng=DeviceRNG(1, device))
-    assert s._fused_rng('x', 9000)
+    assert native_gauss.fused_rng(s, 'x', 9000)
     assert s.sample_n(2).shape == (2, 3, 9000) and s.rng.offset == 2
     # few chains of D = 1024: a chain is spread over 4 waves with draws from HBM, which beats
     # the one-wave kernel with its own generator -> the SAME lane-stream draws, written out
@@ -291,7 +292,7 @@ def test_fused_generator_limits_and_fallback(device):
     for C, want in ((64, False), (1024, False), (1025, True), (2100, True), (5000, True)):
         s = HMCSampler(IsotropicGaussian(), torch.zeros((C, 1024), dtype=torch.float64, device=device),
                        0.02, 3, variable_name='x', rng=DeviceRNG(1, device))
-        assert s._fused_rng('x', 1024) and s._draws_in_kernel(C, 1024) is want, C
+        assert native_gauss.fused_rng(s, 'x', 1024) and native_gauss.draws_in_kernel(s, C, 1024) is want, C
     assert _native.gauss_waves_per_chain(512, 1024) == 4
     assert _native.gauss_waves_per_chain(2048, 1024) == 2
     assert _native.gauss_waves_per_chain(4096, 1024) == 1
@@ -299,7 +300,7 @@ def test_fused_generator_limits_and_fallback(device):
     # ... and so does a generator that was told not to fuse
     s = HMCSampler(IsotropicGaussian(), z[:, :64].contiguous(), 0.02, 3, variable_name='x',
                    rng=DeviceRNG(1, device, fused=False))
-    assert not s._fused_rng('x', 64)
+    assert not native_gauss.fused_rng(s, 'x', 64)
     assert s.sample().shape == (3, 64)
 
 
@@ -318,7 +319,7 @@ def test_long_chain_generator_equals_sampling_from_its_own_dump(device, C, D, L,
               record_energies=True)
     a = HMCSampler(IsotropicGaussian(k, x0), q0, dt, L, rng=DeviceRNG(seed, device), **kw)
     b = HMCSampler(IsotropicGaussian(k, x0), q0, dt, L, **kw)
-    assert a._fused_rng('x', D) and not _native.gauss_persist_covers(D)
+    assert native_gauss.fused_rng(a, 'x', D) and not _native.gauss_persist_covers(D)
     for call in range(3):
         xa = a.sample()
         p0, u = _native.hmc_gauss_big_rng_draws(C, D, seed, call, device)

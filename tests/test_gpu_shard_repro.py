@@ -12,6 +12,7 @@ import pytest
 import torch
 
 from binf_amd import _native
+from binf_amd.pdf import native_gauss
 from binf_amd.dist import shard_chains
 from binf_amd.pdf import IsotropicGaussian
 from binf_amd.samplers.hmc import HMCSampler
@@ -68,8 +69,8 @@ def test_c2_halves_and_eighths_reproduce_the_full_batch(device):
     rng = DeviceRNG(1, device)
     s = HMCSampler(IsotropicGaussian(), torch.zeros((8, D), dtype=torch.float64, device=device),
                    0.02, 3, variable_name='x', rng=rng)
-    assert s._draws_in_kernel(4096, D) and s._draws_in_kernel(2048, D)
-    assert not s._draws_in_kernel(512, D) and _native.gauss_waves_per_chain(512, D) == 4
+    assert native_gauss.draws_in_kernel(s, 4096, D) and native_gauss.draws_in_kernel(s, 2048, D)
+    assert not native_gauss.draws_in_kernel(s, 512, D) and _native.gauss_waves_per_chain(512, D) == 4
     assert_shards_equal_full(device, C, D, 2, n=3, dt=0.05, L=20)
     assert_shards_equal_full(device, C, D, 8, n=2, dt=0.05, L=20)
 

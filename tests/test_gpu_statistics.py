@@ -75,7 +75,7 @@ def test_polynomial_conditional_matches_its_analytic_gaussian(device, fused):
     rng = DeviceRNG(3, device)
     start = torch.from_numpy(mean + rs.standard_normal((C, K)) @ np.linalg.cholesky(cov).T).to(device)
     s = HMCSampler(cond, start, 0.02, 50, variable_name='coefficients', rng=rng)
-    s.fused_polynomial = fused
+    s.fused_transition = fused
     assert (s._fused_spec('coefficients', K) is not None) == fused
     kept = []
     for i in range(sweeps):

@@ -55,7 +55,8 @@ def test_the_core_never_names_a_model():
     assert r.stdout.decode() == ''
     for rel in ('samplers/hmc.py', 'samplers/gibbs.py', 'pdf/posteriors.py', 'pdf/likelihoods.py'):
         src = open(os.path.join(ROOT, 'binf_amd', rel)).read()
-        for name in ("'poly'", "'pairdist'", "'polynomial'", "'gaussian_pairdist'"):
+        for name in ("'poly'", "'pairdist'", "'polynomial'", "'gaussian_pairdist'", "'gauss'", 'GAUSS',
+                     'IsotropicGaussian(', 'hmc_sample_gauss', 'hmc_sample_n_gauss'):
             assert name not in src, (rel, name)
 
 
