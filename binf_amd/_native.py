@@ -94,7 +94,8 @@ SIGNATURES = {
     'binf_row_sumsq_diff_f64': (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _f64,
                                        _vp]),
     'binf_poly_forward_f64': (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _vp]),
-    'binf_predictive_density_f64': (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _f64, _vp]),
+    'binf_predictive_density_workspace_bytes': (_i64, [_i64, _i64, _i64]),
+    'binf_predictive_density_f64': (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _f64, _vp, _i64, _vp]),
     'binf_gauss_err_grad_f64': (_i32, [_vp, _vp, _f64, _vp, _vp, _i64, _i64,
                                        _vp]),
     'binf_gauss_err_logp_f64': (_i32, [_vp, _vp, _f64, _vp, _vp, _i64, _i64,
@@ -480,10 +481,13 @@ def predictive_density(mock, precision, ys, half_log_2pi):
         raise ValueError('predictive_density: ys must be [nx x ny] with nx = %d' % nx)
     ny = ys.shape[1]
     out = torch.empty((nx, ny), dtype=torch.float64, device=mock.device)
+    need = lib().binf_predictive_density_workspace_bytes(S, nx, ny)
+    ws = torch.empty(need // 8, dtype=torch.float64, device=mock.device) if need > 0 else None
     rc = lib().binf_predictive_density_f64(dptr(mock, numel=S * nx, name='mock'),
                                            dptr(precision, numel=S, name='precision'),
                                            dptr(ys, numel=nx * ny, name='ys'), dptr(out),
                                            S, nx, ny, float(half_log_2pi),
+                                           None if ws is None else ws.data_ptr(), need,
                                            stream_handle(mock.device))
     check(rc, 'binf_predictive_density_f64')
     return out

@@ -46,7 +46,7 @@ extern "C" {
  *    tensor never has to be read back to the host); binf_hmc_sample_n_gauss_rng_f64 /
  *    binf_hmc_gauss_rng_draws_f64 take one stream position per TRANSITION (offset + i),
  *    as the long-chain entry points always did.
- * 6: binf_predictive_density_f64 (the consumer side of the sample store: the
+ * 6: binf_predictive_density_f64 / _workspace_bytes (the consumer side of the sample store: the
  *    posterior-predictive density over a grid of points in one launch). */
 #define BINF_ABI_VERSION 6
 
@@ -689,10 +689,15 @@ int32_t binf_rwmc_accept_f64(const double *proposal, const double *state,
  * NaN / inf follow numpy (a negative precision gives NaN, S >= 1 required: the
  * reference's max() of no samples raises).  Lane-strided sums and the device
  * library's log / exp: ~1e-14 relative to the numpy restatement, not bit-identical.
+ * workspace: binf_predictive_density_workspace_bytes(S, nx, ny) bytes of device
+ * memory (0 for grids that fill the chip by themselves: NULL is then accepted) --
+ * a small grid with many samples is computed chunk of samples by chunk and joined.
  * ---------------------------------------------------------------------- */
+int64_t binf_predictive_density_workspace_bytes(int64_t S, int64_t nx, int64_t ny);
 int32_t binf_predictive_density_f64(const double *mock, const double *precision,
                                     const double *ys, double *out, int64_t S,
                                     int64_t nx, int64_t ny, double half_log_2pi,
+                                    void *workspace, int64_t workspace_bytes,
                                     void *stream);
 
 /* ------------------------------------------------------------------------

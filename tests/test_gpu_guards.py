@@ -344,7 +344,8 @@ def test_long_chain_loop_from_one_call_stays_inside_its_buffers(device, D, C, n,
     assert bool(torch.isfinite(res[0][0]).all())
 
 
-@pytest.mark.parametrize('S,nx,ny', [(1, 1, 1), (5, 3, 7), (16, 16, 8), (17, 17, 9), (100, 33, 150), (1000, 5, 31)])
+@pytest.mark.parametrize('S,nx,ny', [(1, 1, 1), (5, 3, 7), (16, 16, 8), (17, 17, 9), (100, 33, 150), (1000, 5, 31),
+                                     (5001, 3, 7), (700, 1, 1)])
 def test_predictive_density_stays_inside_its_buffers(device, S, nx, ny):
     rs = np.random.RandomState(S + nx + ny)
     mock, tau, ys = rs.standard_normal((S, nx)), rs.gamma(4.0, 0.5, size=S), rs.standard_normal((nx, ny)) * 2

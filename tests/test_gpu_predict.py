@@ -50,7 +50,9 @@ def test_tube_and_points_against_the_restatement(device, path):
 
 
 @pytest.mark.parametrize('S,K,nx,ny', [(1, 1, 1, 1), (5, 3, 1, 7), (16, 4, 16, 8), (17, 4, 17, 9),
-                                       (257, 33, 33, 150), (3000, 4, 100, 31)])
+                                       (257, 33, 33, 150), (3000, 4, 100, 31),
+                                       # few points, many samples: the samples are cut into chunks
+                                       (5000, 4, 3, 7), (511, 4, 1, 1), (512, 4, 1, 1), (20000, 4, 33, 17)])
 def test_grid_shapes_against_the_restatement(device, S, K, nx, ny):
     rs = np.random.RandomState(S + nx)
     c = rs.standard_normal((S, K)) * 0.3
@@ -116,6 +118,19 @@ def test_nan_and_inf_follow_numpy(device):
             assert np.array_equal(np.isnan(got), np.isnan(want))
             ok = ~np.isnan(want)
             assert np.all(np.abs(got[ok] - want[ok]) <= RTOL * np.abs(want[ok]))
+    # many samples on a small grid (chunks of samples joined by a second launch): a chunk whose
+    # terms are all -inf drops out, all chunks -inf give NaN, one NaN term poisons the point
+    S = 4000
+    assert _native.lib().binf_predictive_density_workspace_bytes(S, 2, 2) > 0
+    cs = np.zeros((S, 2))
+    with np.errstate(all='ignore'):
+        for tau in (np.where(np.arange(S) < 1500, 0.0, 2.0), np.zeros(S),
+                    np.where(np.arange(S) == 3999, -1.0, 1.0), np.where(np.arange(S) % 2 == 0, 0.0, 3.0)):
+            got = misc.predict_grid(xs, ys, (dev_t(cs, device), dev_t(tau, device)), POLYVAL).cpu().numpy()
+            want = np.array([[E.predict(xs[i], ys[i, j], cs, tau) for j in range(2)] for i in range(2)])
+            assert np.array_equal(np.isnan(got), np.isnan(want))
+            ok = ~np.isnan(want)
+            assert np.all(np.abs(got[ok] - want[ok]) <= RTOL * np.abs(want[ok]))
     # far tails underflow to 0 without NaN
     got = misc.predict_grid([0.0], [[1e6]], (dev_t(c, device), dev_t(np.ones(4), device)), POLYVAL)
     assert float(got[0, 0]) == 0.0
@@ -128,12 +143,24 @@ def test_c_abi_refusals(device):
     ys = dev_t(np.zeros((3, 5)), device)
     out = torch.empty((3, 5), dtype=torch.float64, device=device)
     h = 0.5 * np.log(2 * np.pi)
-    args = lambda m, t, y, o, S=4, nx=3, ny=5: (m, t, y, o, S, nx, ny, h, None)
+    args = lambda m, t, y, o, S=4, nx=3, ny=5, ws=None, wb=0: (m, t, y, o, S, nx, ny, h, ws, wb, None)
     p = lambda t: ctypes.c_void_p(t.data_ptr())
     assert lib.binf_predictive_density_f64(*args(p(mock), p(tau), p(ys), p(out), S=0)) == _native.E_ARG
     assert lib.binf_predictive_density_f64(*args(None, p(tau), p(ys), p(out))) == _native.E_ARG
     assert lib.binf_predictive_density_f64(*args(p(mock), p(tau), p(ys), p(ys))) == _native.E_ALIAS
     assert lib.binf_predictive_density_f64(*args(p(mock), p(tau), p(ys), p(out), nx=0)) == 0
     assert lib.binf_predictive_density_f64(*args(p(mock), p(tau), p(ys), p(out))) == 0
+    torch.cuda.synchronize()
+    assert torch.all(out > 0)
+    # many samples on a small grid need the workspace the library asks for
+    S = 4096
+    big, taus = dev_t(np.zeros((S, 3)), device), dev_t(np.ones(S), device)
+    need = lib.binf_predictive_density_workspace_bytes(S, 3, 5)
+    assert need > 0 and lib.binf_predictive_density_workspace_bytes(4, 3, 5) == 0
+    ws = torch.empty(need // 8, dtype=torch.float64, device=device)
+    assert lib.binf_predictive_density_f64(*args(p(big), p(taus), p(ys), p(out), S=S)) == _native.E_ARG
+    assert lib.binf_predictive_density_f64(*args(p(big), p(taus), p(ys), p(out), S=S, ws=p(ws), wb=need - 8)) == _native.E_ARG
+    assert lib.binf_predictive_density_f64(*args(p(big), p(taus), p(ys), p(out), S=S, ws=p(out), wb=need)) == _native.E_ALIAS
+    assert lib.binf_predictive_density_f64(*args(p(big), p(taus), p(ys), p(out), S=S, ws=p(ws), wb=need)) == 0
     torch.cuda.synchronize()
     assert torch.all(out > 0)
