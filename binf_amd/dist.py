@@ -173,6 +173,21 @@ class SampleStore(object):
         self.n_kept += 1
         return True
 
+    # -- checkpoint / resume (binf_amd/checkpoint.py) ----------------------------------
+    def state_dict(self):
+        return {'kept': self.buffer[:self.n_kept], 'n_seen': int(self.n_seen), 'n_kept': int(self.n_kept),
+                'thin': int(self.thin), 'burn_in': int(self.burn_in)}
+
+    def load_state_dict(self, d):
+        if int(d['thin']) != self.thin or int(d['burn_in']) != self.burn_in:
+            raise ValueError('SampleStore checkpoint has thin=%s, burn_in=%s' % (d['thin'], d['burn_in']))
+        n = int(d['n_kept'])
+        if n > self.buffer.shape[0] or tuple(d['kept'].shape[1:]) != tuple(self.buffer.shape[1:]):
+            raise ValueError('SampleStore checkpoint of shape %s does not fit a store of %s'
+                             % (tuple(d['kept'].shape), tuple(self.buffer.shape)))
+        self.buffer[:n].copy_(d['kept'].to(self.buffer.device))
+        self.n_seen, self.n_kept = int(d['n_seen']), n
+
     def to(self, device):
         """A store on ``device`` holding the draws kept so far (a host copy is what
         the ``gloo`` backend can move; RCCL gathers straight from HBM)."""

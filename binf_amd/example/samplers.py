@@ -42,6 +42,19 @@ class GammaSampler(object):
                 raise TypeError('GammaSampler: rng has no gamma(shape, n, device) method')
         self.gamma = gamma
 
+    # -- checkpoint / resume (binf_amd/checkpoint.py) ----------------------------------
+    def state_dict(self):
+        rng = getattr(self.gamma, '__self__', None)            # the generator whose gamma() draws
+        fn = getattr(rng, 'state_dict', None)
+        return {'state': self.state, 'rng': fn() if fn is not None else None}
+
+    def load_state_dict(self, d):
+        from binf_amd.checkpoint import like
+        self.state = like(d['state'], self.state)
+        rng = getattr(self.gamma, '__self__', None)
+        if d.get('rng') is not None and hasattr(rng, 'load_state_dict'):
+            rng.load_state_dict(d['rng'])
+
     def _get_prior(self):
         from binf_amd.example.priors import GammaPrior
         prior = [p for p in self.pdf.priors.values()
@@ -103,6 +116,25 @@ class RWMCSampler(object):
     @property
     def last_draw_stats(self):
         return {'coefficients': RWMCSampleStats(self.acceptance_rate)}
+
+    # -- checkpoint / resume (binf_amd/checkpoint.py; a run on the host stream also saves a
+    # ``HostLegacyRNG()``, which IS that stream) ------------------------------------------
+    def state_dict(self):
+        fn = getattr(self.rng, 'state_dict', None)
+        return {'state': self.state, 'stepsize': float(self.stepsize), 'n_moves': int(self._n_moves),
+                'n_accepted_moves': self._n_accepted_moves, 'last_move_accepted': self.last_move_accepted,
+                'rng': fn() if fn is not None else None}
+
+    def load_state_dict(self, d):
+        from binf_amd.checkpoint import like
+        ref = self.state
+        self.state = like(d['state'], ref)
+        self.stepsize, self._n_moves = float(d['stepsize']), int(d['n_moves'])
+        n, a = d['n_accepted_moves'], d['last_move_accepted']
+        self._n_accepted_moves = n.to(ref.device) if isinstance(n, torch.Tensor) else n
+        self.last_move_accepted = a.to(ref.device) if isinstance(a, torch.Tensor) else a
+        if d.get('rng') is not None and hasattr(self.rng, 'load_state_dict'):
+            self.rng.load_state_dict(d['rng'])
 
     @property
     def acceptance_rate(self):

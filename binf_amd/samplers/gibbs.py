@@ -164,6 +164,25 @@ class GibbsSampler(object):
         return {k: (torch.stack(v) if isinstance(v[0], torch.Tensor) else v)
                 for k, v in kept.items()}
 
+    # -- checkpoint / resume (binf_amd/checkpoint.py) ----------------------------------
+    def state_dict(self):
+        subs = {}
+        for var, sub in self._subsamplers.items():
+            fn = getattr(sub, 'state_dict', None)
+            subs[var] = fn() if fn is not None else None
+        return {'variables': self._state.variables, 'subsamplers': subs}
+
+    def load_state_dict(self, d):
+        from binf_amd.checkpoint import like
+        current = self._state.variables
+        self._state.update_variables(**{k: like(v, current.get(k)) for k, v in d['variables'].items()})
+        for var, sd in d['subsamplers'].items():
+            sub = self._subsamplers[var]
+            if sd is not None and hasattr(sub, 'load_state_dict'):
+                sub.load_state_dict(sd)
+        self._update_subsampler_states()
+        self._update_conditional_pdf_params()
+
     # -- statistics ------------------------------------------------------------
     def _calc_pacc(self):
         """Not applicable (reference ``gibbs.py:153-157``)."""

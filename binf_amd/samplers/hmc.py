@@ -404,6 +404,31 @@ class HMCSampler(object):
         return q
 
 
+    # -- checkpoint / resume (binf_amd/checkpoint.py) ----------------------------------
+    def state_dict(self):
+        """What a fresh sampler built with the same arguments needs to continue this chain
+        bit for bit: state, step sizes, counters, the generator's position."""
+        rng = getattr(self.rng, 'state_dict', None)
+        return {'state': self.state, 'timestep': float(self._timestep), 'dt_chain': self._dt_chain,
+                'n_accepted': self.n_accepted, 'counter': int(self.counter),
+                'last_move_accepted': self._last_move_accepted,
+                'rng': rng() if rng is not None else None}
+
+    def load_state_dict(self, d):
+        from binf_amd.checkpoint import like
+        ref = self.state
+        self.state = like(d['state'], ref)
+        self._timestep = float(d['timestep'])
+        self._dt_chain = None if d['dt_chain'] is None else like(d['dt_chain'], ref)
+        n = d['n_accepted']
+        self.n_accepted = n.to(ref.device) if isinstance(n, torch.Tensor) else n
+        self.counter = int(d['counter'])
+        a = d['last_move_accepted']
+        self._last_move_accepted = a.to(ref.device) if isinstance(a, torch.Tensor) else a
+        if d.get('rng') is not None and hasattr(self.rng, 'load_state_dict'):
+            self.rng.load_state_dict(d['rng'])
+        self.reset_graph()
+
     # -- the per-step tier as one HIP graph --------------------------------------------
     def reset_graph(self):
         """Forget the captured graphs (after changing something the PDF reads that is not

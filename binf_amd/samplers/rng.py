@@ -28,6 +28,16 @@ class HostLegacyRNG(object):
     def fill_uniform(self, out):
         out.copy_(torch.from_numpy(np.random.uniform(size=out.numel())).reshape(out.shape))
 
+    # -- checkpoint (binf_amd/checkpoint.py): the global legacy stream itself ---------------
+    def state_dict(self):
+        name, key, pos, has_gauss, cached = np.random.get_state()
+        return {'generator': name, 'key': torch.from_numpy(key.astype(np.int64)), 'pos': int(pos),
+                'has_gauss': int(has_gauss), 'cached_gaussian': float(cached)}
+
+    def load_state_dict(self, d):
+        np.random.set_state((d['generator'], np.asarray(d['key'], dtype=np.uint32), int(d['pos']),
+                             int(d['has_gauss']), float(d['cached_gaussian'])))
+
 
 class DeviceRNG(object):
     """Throughput source: draws generated on the device, so nothing crosses
@@ -83,6 +93,17 @@ class DeviceRNG(object):
         from binf_amd.dist import shard_chains
         start, count = shard_chains(n_chains_total, rank, world_size)
         return cls(seed=seed, chain_offset=start, **kw), start, count
+
+    # -- checkpoint (binf_amd/checkpoint.py): a stream is its seed and its position ----------
+    def state_dict(self):
+        return {'seed': self.seed, 'offset': int(self.offset), 'chain_offset': self.chain_offset,
+                'normal': self._normal_kind, 'fused': self.fused}
+
+    def load_state_dict(self, d):
+        if d['normal'] != self._normal_kind or int(d['chain_offset']) != self.chain_offset:
+            raise ValueError('DeviceRNG checkpoint is of another stream layout (normal=%s, chain_offset=%s)'
+                             % (d['normal'], d['chain_offset']))
+        self.seed, self.offset = int(d['seed']), int(d['offset'])
 
     def next_offset(self):
         """Reserve one launch worth of the in-kernel generator's stream."""
