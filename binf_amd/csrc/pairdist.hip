@@ -14,6 +14,9 @@
 // need -- 200 MB per chain at n = 256 -- is never formed):
 //   32 <= n <= 256  every unordered pair once, target distances in registers, one
 //                   workgroup of 1 / 4 / 9 / 16 waves per chain (second half of this file);
+//   257 .. 1024     (with packed targets) every unordered pair once as well: the "ring"
+//                   scheme -- a wave per block of 64 row beads, block pairs walked in phases,
+//                   targets streamed from the packed array (end of the device code);
 //   other n         one-sided all-pairs loops, the chain's coordinates staged in LDS,
 //                   target distances read from a symmetric [n x n] matrix.
 // Each has a force-only kernel and a fused leapfrog (the whole _leapfrog() of
@@ -1145,6 +1148,258 @@ __global__ void __launch_bounds__(1024) pairdist_leapfrog_sym_kernel(const PairL
     }
 }
 
+// ---------------------------------------------------------------------------
+// 256 < n_beads <= 1024: every UNORDERED pair once as well -- the "ring" scheme.
+//
+// The scheme above keeps a bead's 2 NBLK partial sums in LDS and a wave's 32 target
+// distances in registers for the whole launch; neither scales past 256 beads (512
+// beads: 196 KB of partial sums, 128 targets per lane).  Here a workgroup of NBLK =
+// ceil(n / 64) waves owns a chain, wave b = the 64 ROW beads of block b, and the block
+// pairs are walked in PHASES that every wave takes together:
+//
+//   phase 0       the diagonal tile (b, b): 31.5 steps, partner l + 1 + m (as above)
+//   phase s >= 1  the tile (b, (b + s) mod NBLK): 64 steps, partner column l + m;
+//                 s runs to NBLK / 2.  For an even NBLK the last phase pairs antipodal
+//                 blocks, which see each other from both sides: the lower block takes
+//                 the column offsets 0..31, the upper one 1..32 (32 steps each) -- an
+//                 exact cover of the tile.
+//
+//  * In every phase each COLUMN block is visited by exactly one wave.  A lane adds
+//    w (x_i - x_j) to its row bead's sum F (a register for the whole evaluation) and
+//    subtracts it from the partner's sum R, which moves on by one lane per step
+//    (wave_rol1) and so stays with its bead; at the end of a phase R goes to ONE LDS
+//    slot per bead, and after a barrier the bead's owner adds it to a second register
+//    G.  The force is F + G: F summed in step order, G in phase order -- a fixed order
+//    that depends on n only, so results are bit-identical for any number of chains and
+//    the fused leapfrog is bit-identical to the per-step tier.  Half the arithmetic of
+//    the one-sided loops, one barrier per phase (5 at 512 beads, 9 at 1024).
+//  * The targets cannot stay in registers: they are read again for every force
+//    evaluation, 8 steps ahead of their use, from the packed array (ring_pack_targets_
+//    kernel: step t of wave b, lane l at ypk[(b T + t) 64 + l] -- coalesced, 1 MiB at
+//    512 beads, shared by all chains and resident in L2).
+// ---------------------------------------------------------------------------
+constexpr int RING_MAX_BEADS = 1024;
+constexpr int RING_CHUNK = 8;            // steps whose targets are in flight / in use at a time
+
+__host__ __device__ inline int ring_steps(int nblk)      // steps a wave walks per force evaluation
+{
+    return (nblk & 1) ? 32 + 64 * (nblk / 2) : 64 * (nblk / 2);
+}
+
+struct RingPhase {
+    int bj, off, steps;
+};
+
+__host__ __device__ inline RingPhase ring_phase(int nblk, int bi, int s)
+{
+    RingPhase ph;
+    if (s == 0) {
+        ph.bj = bi; ph.off = 1; ph.steps = 32;
+    } else {
+        const bool half = !(nblk & 1) && s == nblk / 2;
+        ph.bj = bi + s; if (ph.bj >= nblk) ph.bj -= nblk;
+        ph.off = (half && bi >= nblk / 2) ? 1 : 0;
+        ph.steps = half ? 32 : 64;
+    }
+    return ph;
+}
+
+template <int NBT>
+struct RingShared {
+    double sx[NBT][3][128];              // positions [block][axis][slot]; slots 64-127 repeat 0-63
+    double racc[2][NBT][3][64];          // a phase's column-side sums [buffer][block][axis][bead]
+};
+
+// The targets in the order the waves of the ring kernels read them.
+__global__ void __launch_bounds__(256) ring_pack_targets_kernel(const double *ymat, double *ypk, int n, int nblk)
+{
+    const int bi = blockIdx.x, lane = threadIdx.x & 63;
+    const int total = ring_steps(nblk);
+    const int i = 64 * bi + lane;
+    for (int t = threadIdx.x >> 6; t < total; t += blockDim.x >> 6) {
+        const int s = t < 32 ? 0 : 1 + (t - 32) / 64;
+        const int m = t < 32 ? t : (t - 32) % 64;
+        const RingPhase ph = ring_phase(nblk, bi, s);
+        const int j = 64 * ph.bj + ((lane + ph.off + m) & 63);
+        ypk[((int64_t)bi * total + t) * 64 + lane] = (i < n && j < n) ? ymat[(int64_t)i * n + j] : 0.0;
+    }
+}
+
+// RING_CHUNK steps of a phase.  MASK: some of this tile's pairs do not exist (the last half
+// step of a diagonal tile; beads beyond n when n is not a multiple of 64 and the row or the
+// column block is the last one) -- bit k of `live` says whether the pair of step m0 + k does.
+template <bool MASK>
+__device__ inline void ring_chunk(const double (&y)[RING_CHUNK], const double *pj0, const double *pj1,
+                                  const double *pj2, int m0, double x0, double x1, double x2,
+                                  unsigned live,
+                                  double &F0, double &F1, double &F2, double &R0, double &R1, double &R2)
+{
+#pragma unroll
+    for (int k = 0; k < RING_CHUNK; ++k) {
+        const int m = m0 + k;
+        const double d0 = x0 - pj0[m], d1 = x1 - pj1[m], d2 = x2 - pj2[m];
+        const double s2 = __builtin_fma(d2, d2, __builtin_fma(d1, d1, d0 * d0));
+        double r = __builtin_amdgcn_rsq(s2);
+        r = r * __builtin_fma(-0.5 * s2 * r, r, 1.5);
+        double w = __builtin_fma(-y[k], r, 1.0);
+        if (MASK) w = ((live >> k) & 1u) ? w : 0.0;     // also discards the NaN of a 0-distance ghost pair
+        F0 = __builtin_fma(w, d0, F0); F1 = __builtin_fma(w, d1, F1); F2 = __builtin_fma(w, d2, F2);
+        R0 = wave_rol1(__builtin_fma(-w, d0, R0));
+        R1 = wave_rol1(__builtin_fma(-w, d1, R1));
+        R2 = wave_rol1(__builtin_fma(-w, d2, R2));
+    }
+}
+
+// One force evaluation of the chain whose positions are in sh.sx (both copies): the force on
+// this thread's bead (wave = block, lane = bead in the block) in f.  Every wave of the
+// workgroup must call it; it ends behind the last phase's barrier, so the caller may
+// overwrite sh.sx at once (and must synchronise before the next evaluation).
+template <bool FULL, int NBT>
+__device__ inline void ring_force(RingShared<NBT> &sh, const double *ypk, int n, int nblk, int &buf,
+                                  double (&f)[3])
+{
+    const int bi = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    const int total = ring_steps(nblk);
+    const double *yp = ypk + (int64_t)bi * total * 64 + lane;
+    const double x0 = sh.sx[bi][0][lane], x1 = sh.sx[bi][1][lane], x2 = sh.sx[bi][2][lane];
+    const bool row_ok = 64 * bi + lane < n;
+    double F0 = 0.0, F1 = 0.0, F2 = 0.0, G0 = 0.0, G1 = 0.0, G2 = 0.0;
+    double y[RING_CHUNK], yn[RING_CHUNK];
+#pragma unroll
+    for (int k = 0; k < RING_CHUNK; ++k) y[k] = yp[k * 64];
+    int t = 0;
+    const int nph = nblk / 2;
+    for (int s = 0; s <= nph; ++s) {
+        const RingPhase ph = ring_phase(nblk, bi, s);
+        const double *pj0 = &sh.sx[ph.bj][0][lane + ph.off];
+        const double *pj1 = &sh.sx[ph.bj][1][lane + ph.off];
+        const double *pj2 = &sh.sx[ph.bj][2][lane + ph.off];
+        // which of the lane's pairs exist in this tile: bit m <-> step m (wave-uniform test)
+        const bool mask = s == 0 || (!FULL && (bi == nblk - 1 || ph.bj == nblk - 1));
+        unsigned long long live = ~0ull;
+        if (mask) {
+            const int col_lim = n - 64 * ph.bj;                               // columns that exist
+            const unsigned long long cols = col_lim >= 64 ? ~0ull : ((1ull << col_lim) - 1ull);
+            const int rot = (lane + ph.off) & 63;                             // bit m <- column (rot + m) mod 64
+            live = rot ? ((cols >> rot) | (cols << (64 - rot))) : cols;
+            if (!row_ok) live = 0ull;
+            if (s == 0 && lane >= 32) live &= ~(1ull << 31);                  // partner l + 32: lanes 0-31 only
+        }
+        double R0 = 0.0, R1 = 0.0, R2 = 0.0;
+        for (int m0 = 0; m0 < ph.steps; m0 += RING_CHUNK) {
+            const bool more = t + RING_CHUNK < total;                         // wave-uniform
+            if (more) {
+#pragma unroll
+                for (int k = 0; k < RING_CHUNK; ++k) yn[k] = yp[(int64_t)(t + RING_CHUNK + k) * 64];
+            }
+            if (mask) ring_chunk<true>(y, pj0, pj1, pj2, m0, x0, x1, x2, (unsigned)(live >> m0), F0, F1, F2, R0, R1, R2);
+            else      ring_chunk<false>(y, pj0, pj1, pj2, m0, x0, x1, x2, 0u, F0, F1, F2, R0, R1, R2);
+            if (more) {
+#pragma unroll
+                for (int k = 0; k < RING_CHUNK; ++k) y[k] = yn[k];
+            }
+            t += RING_CHUNK;
+        }
+        // the column-side sums of this phase to their beads' slots; one wave per column block
+        const int col = (lane + ph.off + ph.steps) & 63;
+        sh.racc[buf][ph.bj][0][col] = R0; sh.racc[buf][ph.bj][1][col] = R1; sh.racc[buf][ph.bj][2][col] = R2;
+        __syncthreads();
+        G0 = G0 + sh.racc[buf][bi][0][lane]; G1 = G1 + sh.racc[buf][bi][1][lane]; G2 = G2 + sh.racc[buf][bi][2][lane];
+        buf ^= 1;
+    }
+    f[0] = F0 + G0; f[1] = F1 + G1; f[2] = F2 + G2;
+}
+
+template <int NBT>
+__device__ inline void ring_publish(RingShared<NBT> &sh, int t, const double (&q)[3])
+{
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) {
+        sh.sx[t >> 6][ax][t & 63] = q[ax];
+        sh.sx[t >> 6][ax][(t & 63) + 64] = q[ax];
+    }
+}
+
+// One force evaluation per chain (the per-step tier's gradient): 64 NBLK threads per
+// workgroup, a workgroup walks chains blockIdx.x, blockIdx.x + gridDim.x, ...
+template <bool FULL, int NBT>
+__global__ void __launch_bounds__(1024)
+pairdist_grad_ring_kernel(const double *x, const double *ypk, double tau, const double *tau_chain,
+                          double *out, int32_t n_beads, int32_t nblk, int64_t n_chains)
+{
+    __shared__ RingShared<NBT> sh;
+    const int n = n_beads, t = threadIdx.x;
+    int buf = 0;
+    for (int64_t c = blockIdx.x; c < n_chains; c += gridDim.x) {
+        const double *xc = x + c * 3 * (int64_t)n;
+        double q[3];
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) q[ax] = (t < n) ? xc[3 * t + ax] : 0.0;
+        ring_publish<NBT>(sh, t, q);
+        __syncthreads();
+        double f[3];
+        ring_force<FULL, NBT>(sh, ypk, n, nblk, buf, f);
+        if (t < n) {
+            const double tc = tau_chain ? tau_chain[c] : tau;
+            double *o = out + c * 3 * (int64_t)n + 3 * t;
+            o[0] = tc * f[0]; o[1] = tc * f[1]; o[2] = tc * f[2];
+        }
+    }
+}
+
+// The whole _leapfrog() (binf/samplers/hmc.py:92-125) in one launch with the ring scheme:
+// every thread keeps q and p of its bead in registers.
+template <bool FMA, bool FULL, int NBT>
+__global__ void __launch_bounds__(1024) pairdist_leapfrog_ring_kernel(const PairLeapArgs a, int32_t nblk)
+{
+    __shared__ RingShared<NBT> sh;
+    const int n = a.n_beads, t = threadIdx.x;
+    const bool owner = t < n;
+    int buf = 0;
+    for (int64_t c = blockIdx.x; c < a.n_chains; c += gridDim.x) {
+        double *qc = a.q + c * 3 * (int64_t)n;
+        const double *qs = (a.q_from ? a.q_from : a.q) + c * 3 * (int64_t)n;
+        double *pc = a.p + c * 3 * (int64_t)n;
+        const double tau = a.tau_chain ? a.tau_chain[c] : a.tau;
+        const double dt = a.dt_chain ? a.dt_chain[c] : a.timestep;
+        const double hdt = 0.5 * dt;
+        double q[3] = {0.0, 0.0, 0.0}, p[3] = {0.0, 0.0, 0.0};
+        if (owner) {
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) { q[ax] = qs[3 * t + ax]; p[ax] = pc[3 * t + ax]; }
+        }
+        ring_publish<NBT>(sh, t, q);
+        __syncthreads();
+        // nsteps + 1 force evaluations: half kick, (nsteps - 1) x [drift, kick], drift, half kick
+        for (int e = 0; e <= a.nsteps; ++e) {
+            double f[3];
+            ring_force<FULL, NBT>(sh, a.ypk, n, nblk, buf, f);
+            if (owner) {
+                const double step = (e == 0 || e == a.nsteps) ? hdt : dt;
+#pragma unroll
+                for (int ax = 0; ax < 3; ++ax) {
+                    const double gl = tau * f[ax];
+                    double g = gl;
+                    if (a.has_prior) {
+                        const double gp = a.prior_k * (q[ax] - a.prior_x0);
+                        g = a.prior_first ? gp + gl : gl + gp;
+                    }
+                    p[ax] = FMA ? __builtin_fma(-step, g, p[ax]) : p[ax] - step * g;
+                    if (e < a.nsteps)
+                        q[ax] = FMA ? __builtin_fma(p[ax], dt, q[ax]) : q[ax] + p[ax] * dt;
+                }
+                if (e < a.nsteps) ring_publish<NBT>(sh, t, q);
+            }
+            __syncthreads();
+        }
+        if (owner) {
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) { qc[3 * t + ax] = q[ax]; pc[3 * t + ax] = p[ax]; }
+        }
+    }
+}
+
 }  // namespace binf
 
 using namespace binf;
@@ -1448,10 +1703,67 @@ static bool sym_serves(int64_t n_beads)
     return n_beads >= SYM_MIN_BEADS && n_beads <= SYM_MAX_BEADS && sym_enabled();
 }
 
+// 257 .. 1024 beads WITH packed targets: the ring kernels (development aid: BINF_PD_RING=0
+// keeps the one-sided loops)
+static bool ring_serves(int64_t n_beads)
+{
+    static std::atomic<int> on(-1);
+    int v = on.load(std::memory_order_relaxed);
+    if (v < 0) {
+        const char *e = getenv("BINF_PD_RING");
+        v = (e && e[0] == '0') ? 0 : 1;
+        on.store(v, std::memory_order_relaxed);
+    }
+    return v != 0 && n_beads > SYM_MAX_BEADS && n_beads <= RING_MAX_BEADS;
+}
+
+// workgroups of the ring kernels: as many as the chip holds at a time (NBLK <= 8: two
+// per CU, 16 waves; else one), each walks its share of the chains
+static unsigned ring_grid(int64_t C, int nblk)
+{
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+        cus = 256;
+    const int64_t slots = (int64_t)cus * (nblk <= 8 ? 2 : 1);
+    return (unsigned)(C < slots ? C : slots);
+}
+
+static void launch_grad_ring(const double *x, const double *ypk, double precision,
+                             const double *precision_chain, double *out, int64_t C, int64_t n,
+                             hipStream_t st)
+{
+    const int nblk = (int)((n + 63) / 64);
+    const dim3 grid(ring_grid(C, nblk)), block(64 * nblk);
+    const bool full = n == 64 * nblk;
+#define GRAD_RING(FULLV, NBTV) \
+    pairdist_grad_ring_kernel<FULLV, NBTV><<<grid, block, 0, st>>>(x, ypk, precision, precision_chain, out, \
+                                                                   (int32_t)n, nblk, C)
+    if (nblk <= 8) { if (full) GRAD_RING(true, 8); else GRAD_RING(false, 8); }
+    else           { if (full) GRAD_RING(true, 16); else GRAD_RING(false, 16); }
+#undef GRAD_RING
+}
+
+static void launch_leapfrog_ring(const PairLeapArgs &a, bool fma, hipStream_t st)
+{
+    const int nblk = (a.n_beads + 63) / 64;
+    const dim3 grid(ring_grid(a.n_chains, nblk)), block(64 * nblk);
+    const bool full = a.n_beads == 64 * nblk;
+#define LEAP_RING(FMAV, FULLV) \
+    do { \
+        if (nblk <= 8) pairdist_leapfrog_ring_kernel<FMAV, FULLV, 8><<<grid, block, 0, st>>>(a, nblk); \
+        else           pairdist_leapfrog_ring_kernel<FMAV, FULLV, 16><<<grid, block, 0, st>>>(a, nblk); \
+    } while (0)
+    if (fma) { if (full) LEAP_RING(true, true); else LEAP_RING(true, false); }
+    else     { if (full) LEAP_RING(false, true); else LEAP_RING(false, false); }
+#undef LEAP_RING
+}
+
 extern "C" int64_t binf_pairdist_packed_targets_bytes(int64_t n_beads)
 {
-    if (!sym_serves(n_beads)) return 0;
     const int64_t nblk = (n_beads + 63) / 64;
+    if (ring_serves(n_beads)) return nblk * ring_steps((int)nblk) * 64 * (int64_t)sizeof(double);
+    if (!sym_serves(n_beads)) return 0;
     return nblk * nblk * SYM_STEPS * 64 * (int64_t)sizeof(double);
 }
 
@@ -1459,12 +1771,18 @@ extern "C" int32_t binf_pairdist_pack_targets_f64(const double *ymat, double *pa
                                                   int64_t n_beads, void *stream)
 {
     if (n_beads < 1) return fail(BINF_E_ARG, "pairdist_pack_targets: bad size");
-    if (!sym_serves(n_beads))
+    if (!sym_serves(n_beads) && !ring_serves(n_beads))
         return fail(BINF_E_UNSUPPORTED, "pairdist_pack_targets: n_beads=%lld has no packed form "
                     "(binf_pairdist_packed_targets_bytes is 0)", (long long)n_beads);
     if (!ymat || !packed) return fail(BINF_E_ARG, "pairdist_pack_targets: null buffer");
     hipStream_t st = (hipStream_t)stream;
     const int nblk = (int)((n_beads + 63) / 64);
+    if (ring_serves(n_beads)) {
+        ring_pack_targets_kernel<<<dim3((unsigned)nblk), 256, 0, st>>>(ymat, packed, (int)n_beads, nblk);
+        const hipError_t er = hipGetLastError();
+        if (er != hipSuccess) return hip_fail(er, "pairdist_pack_targets launch");
+        return 0;
+    }
     const dim3 block(64 * nblk * nblk);
     if (nblk == 1)      sym_pack_targets_kernel<1><<<1, block, 0, st>>>(ymat, packed, (int)n_beads);
     else if (nblk == 2) sym_pack_targets_kernel<2><<<1, block, 0, st>>>(ymat, packed, (int)n_beads);
@@ -1505,6 +1823,8 @@ extern "C" int32_t binf_pairdist_gauss_grad_packed_f64(const double *x, const do
         else if (nblk == 3) launch_grad_sym<3>(x, ymat, packed, precision, precision_chain, out, C, n_beads, gst);
         else                launch_grad_sym<4>(x, ymat, packed, precision, precision_chain, out, C, n_beads, gst);
     }
+    else if (packed && ring_serves(n_beads))
+        launch_grad_ring(x, packed, precision, precision_chain, out, C, n_beads, gst);
     else if (n_beads <= 1024 && lanes_per_bead(C) == 4)
         pairdist_grad4_kernel<<<dim3((unsigned)C), 1024, lds, (hipStream_t)stream>>>(
             x, ymat, precision, precision_chain, out, (int32_t)n_beads);
@@ -1576,6 +1896,12 @@ extern "C" int32_t binf_pairdist_leapfrog_packed_f64(double *q, const double *q_
         else if (nblk == 2) launch_leapfrog_sym<2>(a, fma, st);
         else if (nblk == 3) launch_leapfrog_sym<3>(a, fma, st);
         else                launch_leapfrog_sym<4>(a, fma, st);
+        hipError_t es = hipGetLastError();
+        if (es != hipSuccess) return hip_fail(es, "pairdist_leapfrog launch");
+        return 0;
+    }
+    if (packed && ring_serves(n_beads)) {
+        launch_leapfrog_ring(a, fma, st);
         hipError_t es = hipGetLastError();
         if (es != hipSuccess) return hip_fail(es, "pairdist_leapfrog launch");
         return 0;

@@ -46,7 +46,8 @@ extern "C" {
  *    tensor never has to be read back to the host); binf_hmc_sample_n_gauss_rng_f64 /
  *    binf_hmc_gauss_rng_draws_f64 take one stream position per TRANSITION (offset + i),
  *    as the long-chain entry points always did.
- * 6: binf_predictive_density_f64 / _workspace_bytes (the consumer side of the sample store: the
+ * 6: packed targets and the ring kernels for 257..1024 beads (binf_pairdist_packed_targets_bytes
+ *    is no longer 0 there); binf_predictive_density_f64 / _workspace_bytes (the consumer side of the sample store: the
  *    posterior-predictive density over a grid of points in one launch). */
 #define BINF_ABI_VERSION 6
 
@@ -784,8 +785,14 @@ int32_t binf_pairdist_gauss_grad_f64(const double *x, const double *ymat,
  * [n x n] matrix tile by tile through LDS (once per workgroup: ~10 of the 175 us of
  * a 20-step trajectory at 256 chains).  binf_pairdist_packed_targets_bytes: size of
  * the packed form, 0 for bead counts the one-sided kernels serve (then there is
- * nothing to pack and `packed` must be null).  The results are the same bits with
- * and without `packed`; `packed` must have been made from the same ymat. */
+ * nothing to pack and `packed` must be null).  For 32..256 beads the results are the
+ * same bits with and without `packed`; `packed` must have been made from the same ymat.
+ * 257..1024 beads (ABI 6): the packed form is the step order of the ring kernels, which
+ * compute every unordered pair once (2-4x the one-sided loops) and read their targets
+ * from it for every force evaluation; WITH `packed` these bead counts take the ring
+ * kernels, without it the one-sided loops -- the two agree to ~1e-15 relative (another
+ * summation order), each is bit-identical between its force kernel and its fused
+ * leapfrog and for any number of chains. */
 int64_t binf_pairdist_packed_targets_bytes(int64_t n_beads);
 int32_t binf_pairdist_pack_targets_f64(const double *ymat, double *packed, int64_t n_beads,
                                        void *stream);

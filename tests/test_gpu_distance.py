@@ -326,8 +326,62 @@ def test_packed_targets_change_no_bit(device, n):
             assert torch.equal(qa, qb) and torch.equal(pa, pb)
 
 
+@pytest.mark.parametrize('n', [257, 300, 320, 384, 448, 500, 512, 513, 576, 700, 1000, 1023, 1024])
+def test_ring_kernels_every_unordered_pair_once_from_257_to_1024_beads(device, n):
+    """With packed targets 257..1024 beads take the ring kernels (csrc/pairdist.hip: a wave per
+    block of 64 row beads, block pairs walked in phases, every unordered pair once; odd and even
+    block counts, with and without ghost beads).  The force against numpy to 1e-12 and against
+    the one-sided loops (no packed targets) to 1e-13; the fused leapfrog bit for bit the
+    per-step sequence over the ring gradient, in both arithmetic modes; the same bits for
+    workgroups that walk several chains."""
+    ys, x = synth(n, 3, 11 * n)
+    lik = make_distance_likelihood(ys, n)
+    ymat = lik.error_model.ymat_device(device)
+    packed = _native.pairdist_pack_targets(ymat)
+    assert packed is not None and packed.numel() * 8 == _native.lib().binf_pairdist_packed_targets_bytes(n)
+    rs = np.random.RandomState(n)
+    C = 3
+    xx = dev_t(x, device)
+    tau = dev_t(rs.uniform(0.5, 3.0, size=C), device)
+    g = _native.pairdist_gauss_grad(xx, ymat, tau, packed=packed)
+    one_sided = _native.pairdist_gauss_grad(xx, ymat, tau)
+    scale = float(one_sided.abs().max())
+    assert float((g - one_sided).abs().max()) <= 1e-13 * scale
+    ym = ymat.cpu().numpy()
+    for c in range(C):
+        xc = x[c].reshape(n, 3)
+        dd = xc[:, None, :] - xc[None, :, :]
+        r = np.sqrt((dd ** 2).sum(-1))
+        np.fill_diagonal(r, 1.0)
+        w = 1.0 - ym / r
+        np.fill_diagonal(w, 0.0)
+        want = float(tau[c]) * (w[:, :, None] * dd).sum(1).reshape(-1)
+        assert np.abs(g[c].cpu().numpy() - want).max() <= 1e-12 * np.abs(want).max()
+    # many chains per workgroup: the same bits (the order of a bead's sums depends on n only)
+    many = xx[:1].repeat(600, 1)
+    gm = _native.pairdist_gauss_grad(many, ymat, float(tau[0]), packed=packed)
+    assert torch.equal(gm, g[:1].repeat(600, 1))
+    # fused leapfrog == kick / drift around the ring gradient
+    p0 = dev_t(rs.standard_normal((C, 3 * n)), device)
+    L, dt = 3, 2e-3
+    for mode in (_native.MODE_EXACT, _native.MODE_FMA):
+        qa, pa = xx.clone(), p0.clone()
+        _native.pairdist_leapfrog(qa, pa, ymat, tau, (0.05, 0.1), True, dt, None, L, mode, packed=packed)
+        qb, pb = xx.clone(), p0.clone()
+
+        def force(q):
+            return _native.sum_terms([_native.gauss_grad(q, 0.05, 0.1),
+                                      _native.pairdist_gauss_grad(q, ymat, tau, packed=packed)])
+        _native.leapfrog_kick(pb, force(qb), dt, None, half=True, mode=mode)
+        _native.leapfrog_drift(qb, pb, dt, None, mode=mode)
+        for _ in range(L - 1):
+            _native.leapfrog_kick_drift(qb, pb, force(qb), dt, None, mode=mode)
+        _native.leapfrog_kick(pb, force(qb), dt, None, half=True, mode=mode)
+        assert torch.equal(qa, qb) and torch.equal(pa, pb), mode
+
+
 def test_bead_counts_without_a_packed_form(device):
-    for n in (8, 31, 257, 300):
+    for n in (8, 31, 1025, 1500):
         assert _native.lib().binf_pairdist_packed_targets_bytes(n) == 0
         ys, _ = synth(n, 1, n)
         em = make_distance_likelihood(ys, n).error_model

@@ -133,7 +133,8 @@ def test_fused_transition_transition_stays_inside_its_buffers(device, K, N, C):
         assert torch.equal(a, b) and not torch.isnan(a.double()).any()
 
 
-@pytest.mark.parametrize('n,C', [(2, 1), (3, 5), (17, 9), (100, 3), (256, 2), (257, 2), (513, 2), (1030, 1)])
+@pytest.mark.parametrize('n,C', [(2, 1), (3, 5), (17, 9), (100, 3), (256, 2), (257, 2), (513, 2), (1030, 1),
+                                 (320, 3), (512, 2), (640, 2), (1000, 2), (1024, 2), (300, 700)])
 def test_distance_kernels_stay_inside_their_buffers(device, n, C):
     rs = np.random.RandomState(n)
     x = rs.standard_normal((C, 3 * n)) * 2
@@ -152,6 +153,17 @@ def test_distance_kernels_stay_inside_their_buffers(device, n, C):
             q2, p2 = t(x), t(p)
             _native.pairdist_leapfrog(q2, p2, tym, ttau, (0.05, 0.1), True, 0.002, None, 3)
             r += [q2, p2]
+        nbytes = _native.lib().binf_pairdist_packed_targets_bytes(n)
+        if nbytes:
+            # the packed targets (32..256 beads: one load per launch; 257..1024: the ring kernels
+            # stream them for every force evaluation) as a guarded window of their own
+            tpk = t(np.zeros(nbytes // 8))
+            rc = _native.lib().binf_pairdist_pack_targets_f64(tym.data_ptr(), tpk.data_ptr(), n,
+                                                              _native.stream_handle(device))
+            assert rc == 0
+            q3, p3 = t(x), t(p)
+            _native.pairdist_leapfrog(q3, p3, tym, ttau, (0.05, 0.1), True, 0.002, None, 3, packed=tpk)
+            r += [_native.pairdist_gauss_grad(tx, tym, ttau, packed=tpk), q3, p3, tpk]
         if make is not None:
             make.check()
         outs.append([z.clone().cpu() for z in r])
