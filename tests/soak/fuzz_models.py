@@ -46,7 +46,7 @@ def report(what, **kw):
 
 for case in range(n_cases):
     # ---- pair distances ---------------------------------------------------
-    n = int(rs.choice([2, 3, 5, 17, 64, 100, 255, 256, 257, 400, 513, 700]))
+    n = int(rs.choice([2, 3, 5, 17, 64, 100, 255, 256, 257, 320, 400, 512, 513, 700, 1000, 1024]))   # 257..1024: the ring kernels
     C = int(rs.choice([1, 3, 9]))
     truth = rs.standard_normal((n, 3)) * 2.0
     ys = np.abs(RD.forward(truth.reshape(-1), n) + 0.05 * rs.standard_normal(n * (n - 1) // 2))
