@@ -1180,6 +1180,7 @@ __global__ void __launch_bounds__(1024) pairdist_leapfrog_sym_kernel(const PairL
 // ---------------------------------------------------------------------------
 constexpr int RING_MAX_BEADS = 1024;
 constexpr int RING_CHUNK = 8;            // steps whose targets are in flight / in use at a time
+                                         // (4: -2 %, 16: -8 % at 512 .. 1024 beads, same-box A/B)
 
 __host__ __device__ inline int ring_steps(int nblk)      // steps a wave walks per force evaluation
 {
@@ -1422,10 +1423,7 @@ static bool sym_enabled()
     return v != 0;
 }
 
-// workgroups of the n <= 256 kernels: as many as the chip holds at a time (16 waves per
-// CU at 126 VGPRs: 16 / 4 / 1 / 1 workgroups of 1 / 4 / 9 / 16 waves); each walks its
-// share of the chains
-static unsigned sym_grid(int64_t C, int nblk)
+static int cu_count()
 {
     // CU count of the CURRENT device (the wrappers make the stream's device current),
     // cached per device id; atomics make the first calls of several threads harmless
@@ -1438,7 +1436,15 @@ static unsigned sym_grid(int64_t C, int nblk)
             cus = 256;
         cu_cache[dev].store(cus, std::memory_order_relaxed);
     }
-    const int64_t slots = (int64_t)cus * (nblk == 1 ? 16 : (nblk == 2 ? 4 : 1));
+    return cus;
+}
+
+// workgroups of the n <= 256 kernels: as many as the chip holds at a time (16 waves per
+// CU at 126 VGPRs: 16 / 4 / 1 / 1 workgroups of 1 / 4 / 9 / 16 waves); each walks its
+// share of the chains
+static unsigned sym_grid(int64_t C, int nblk)
+{
+    const int64_t slots = (int64_t)cu_count() * (nblk == 1 ? 16 : (nblk == 2 ? 4 : 1));
     return (unsigned)(C < slots ? C : slots);
 }
 
@@ -1721,11 +1727,7 @@ static bool ring_serves(int64_t n_beads)
 // per CU, 16 waves; else one), each walks its share of the chains
 static unsigned ring_grid(int64_t C, int nblk)
 {
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
-    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
-        cus = 256;
-    const int64_t slots = (int64_t)cus * (nblk <= 8 ? 2 : 1);
+    const int64_t slots = (int64_t)cu_count() * (nblk <= 8 ? 2 : 1);
     return (unsigned)(C < slots ? C : slots);
 }
 
