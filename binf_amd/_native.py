@@ -127,11 +127,12 @@ SIGNATURES = {
                                             _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp]),
     'binf_pairdist_packed_targets_bytes': (_i64, [_i64]),
     'binf_pairdist_pack_targets_f64': (_i32, [_vp, _vp, _i64, _vp]),
+    'binf_pairdist_tiles_workspace_bytes': (_i64, [_i64, _i64]),
     'binf_pairdist_gauss_grad_packed_f64': (_i32, [_vp, _vp, _vp, _f64, _vp, _vp, _i64,
-                                                   _i64, _vp]),
+                                                   _i64, _vp, _i64, _vp]),
     'binf_pairdist_leapfrog_packed_f64': (_i32, [_vp, _vp, _vp, _vp, _vp, _f64, _vp, _i32, _f64,
                                                  _f64, _i32, _f64, _vp, _i32, _i64,
-                                                 _i64, _i32, _vp]),
+                                                 _i64, _i32, _vp, _i64, _vp]),
     'binf_rng_uniform_f64': (_i32, [_vp, _i64, ctypes.c_uint64, ctypes.c_uint64,
                                     _i64, _vp]),
     'binf_rng_normal_f64': (_i32, [_vp, _i64, ctypes.c_uint64, ctypes.c_uint64,
@@ -1108,6 +1109,25 @@ def _packed_ptr(packed, n):
     return dptr(packed, numel=lib().binf_pairdist_packed_targets_bytes(n) // 8, name='packed')
 
 
+_tiles_ws = {}
+
+
+def _pairdist_tiles_workspace(C, n, packed, device):
+    """(pointer, bytes) of the scratch for the tiles' partial sums (few chains of 257..1024 beads:
+    binf_pairdist_tiles_workspace_bytes), one buffer per device and stream, grown on demand;
+    ``(None, 0)`` when the library does not ask for one."""
+    if packed is None:
+        return None, 0
+    need = lib().binf_pairdist_tiles_workspace_bytes(C, n)
+    if need <= 0:
+        return None, 0
+    key = (device, stream_handle(device))
+    ws = _tiles_ws.get(key)
+    if ws is None or ws.numel() * 8 < need:
+        ws = _tiles_ws[key] = torch.empty(need // 8, dtype=torch.float64, device=device)
+    return ws.data_ptr(), ws.numel() * 8
+
+
 @_launcher
 def pairdist_gauss_grad(x, ymat, precision, packed=None):
     C, D = _cd(x)
@@ -1116,10 +1136,11 @@ def pairdist_gauss_grad(x, ymat, precision, packed=None):
     n = D // 3
     tau, tau_chain = _precision_args(precision, C, x.device)
     out = torch.empty_like(x)
+    ws, ws_bytes = _pairdist_tiles_workspace(C, n, packed, x.device)
     rc = lib().binf_pairdist_gauss_grad_packed_f64(
         dptr(x, numel=C * D, name='x'), dptr(ymat, numel=n * n, name='ymat'),
         _packed_ptr(packed, n), tau, dptr(tau_chain, numel=C, name='precision'), dptr(out), C, n,
-        stream_handle(x.device))
+        ws, ws_bytes, stream_handle(x.device))
     check(rc, 'binf_pairdist_gauss_grad_packed_f64')
     return out
 
@@ -1215,6 +1236,7 @@ def pairdist_leapfrog(q, p, ymat, precision, prior, prior_first, timestep,
     n = D // 3
     tau, tau_chain = _precision_args(precision, C, q.device)
     k, x0 = prior if prior is not None else (0.0, 0.0)
+    ws, ws_bytes = _pairdist_tiles_workspace(C, n, packed, q.device)
     rc = lib().binf_pairdist_leapfrog_packed_f64(
         dptr(q, numel=C * D, name='q'), dptr(q_from, numel=C * D, name='q_from'),
         dptr(p, numel=C * D, name='p'),
@@ -1222,5 +1244,5 @@ def pairdist_leapfrog(q, p, ymat, precision, prior, prior_first, timestep,
         dptr(tau_chain, numel=C, name='precision'), int(prior is not None),
         float(k), float(x0), int(bool(prior_first)), float(timestep),
         dptr(dt_chain, numel=C, name='dt_chain'), int(nsteps), C, n, int(mode),
-        stream_handle(q.device))
+        ws, ws_bytes, stream_handle(q.device))
     check(rc, 'binf_pairdist_leapfrog_packed_f64')

@@ -1287,21 +1287,25 @@ __device__ inline void ring_force(RingShared<NBT> &sh, const double *ypk, int n,
             if (!row_ok) live = 0ull;
             if (s == 0 && lane >= 32) live &= ~(1ull << 31);                  // partner l + 32: lanes 0-31 only
         }
-        double R0 = 0.0, R1 = 0.0, R2 = 0.0;
+        double P0 = 0.0, P1 = 0.0, P2 = 0.0, R0 = 0.0, R1 = 0.0, R2 = 0.0;   // this TILE's row / column sums
         for (int m0 = 0; m0 < ph.steps; m0 += RING_CHUNK) {
             const bool more = t + RING_CHUNK < total;                         // wave-uniform
             if (more) {
 #pragma unroll
                 for (int k = 0; k < RING_CHUNK; ++k) yn[k] = yp[(int64_t)(t + RING_CHUNK + k) * 64];
             }
-            if (mask) ring_chunk<true>(y, pj0, pj1, pj2, m0, x0, x1, x2, (unsigned)(live >> m0), F0, F1, F2, R0, R1, R2);
-            else      ring_chunk<false>(y, pj0, pj1, pj2, m0, x0, x1, x2, 0u, F0, F1, F2, R0, R1, R2);
+            if (mask) ring_chunk<true>(y, pj0, pj1, pj2, m0, x0, x1, x2, (unsigned)(live >> m0), P0, P1, P2, R0, R1, R2);
+            else      ring_chunk<false>(y, pj0, pj1, pj2, m0, x0, x1, x2, 0u, P0, P1, P2, R0, R1, R2);
             if (more) {
 #pragma unroll
                 for (int k = 0; k < RING_CHUNK; ++k) y[k] = yn[k];
             }
             t += RING_CHUNK;
         }
+        // a bead's force is the sum of its tiles' partial sums in phase order (row side F, column
+        // side G) -- the same numbers whether one workgroup walks the phases (here) or every tile
+        // is a wave of its own (pairdist_tiles_kernel below)
+        F0 = s == 0 ? P0 : F0 + P0; F1 = s == 0 ? P1 : F1 + P1; F2 = s == 0 ? P2 : F2 + P2;
         // the column-side sums of this phase to their beads' slots; one wave per column block
         const int col = (lane + ph.off + ph.steps) & 63;
         sh.racc[buf][ph.bj][0][col] = R0; sh.racc[buf][ph.bj][1][col] = R1; sh.racc[buf][ph.bj][2][col] = R2;
@@ -1398,6 +1402,151 @@ __global__ void __launch_bounds__(1024) pairdist_leapfrog_ring_kernel(const Pair
 #pragma unroll
             for (int ax = 0; ax < 3; ++ax) { qc[3 * t + ax] = q[ax]; pc[3 * t + ax] = p[ax]; }
         }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// The same tiles with FEW chains: a workgroup per chain (above) leaves the chip idle
+// when there are fewer chains than CUs -- 32 replicas of a 1000-bead model use an eighth
+// of it.  Here every tile (row block b, phase s) is a wave of its own, whatever chain it
+// belongs to: the tile's row-side and column-side sums go to a workspace
+// (part[chain][tile][side][axis][bead in block]) and a second launch adds a bead's
+// partial sums in the ring kernels' order -- the same bits -- and scales, kicks or drifts.
+// ---------------------------------------------------------------------------
+constexpr int TILE_WAVES = 4;            // tiles per workgroup
+
+__host__ __device__ inline int ring_tiles(int nblk) { return nblk * (nblk / 2 + 1); }
+
+template <bool FULL>
+__global__ void __launch_bounds__(64 * TILE_WAVES)
+pairdist_tiles_kernel(const double *x, const double *ypk, double *part, int32_t n, int32_t nblk)
+{
+    __shared__ double sxw[TILE_WAVES][3][128];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    const int nph = nblk / 2, ntiles = ring_tiles(nblk);
+    const int tile = blockIdx.x * TILE_WAVES + wave;
+    if (tile >= ntiles) return;                      // no workgroup barrier below
+    const int bi = tile / (nph + 1), s = tile - bi * (nph + 1);
+    const int64_t c = blockIdx.y;
+    const double *xc = x + c * 3 * (int64_t)n;
+    const RingPhase ph = ring_phase(nblk, bi, s);
+    const int i = 64 * bi + lane, jb = 64 * ph.bj + lane;
+    const bool row_ok = i < n;
+    double x0 = 0.0, x1 = 0.0, x2 = 0.0;
+    if (row_ok) { x0 = xc[3 * i]; x1 = xc[3 * i + 1]; x2 = xc[3 * i + 2]; }
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) {
+        const double v = jb < n ? xc[3 * jb + ax] : 0.0;
+        sxw[wave][ax][lane] = v;
+        sxw[wave][ax][lane + 64] = v;
+    }
+    // the wave's own scratch: LDS serves a wave's instructions in order, wave-level fences do
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const double *pj0 = &sxw[wave][0][lane + ph.off];
+    const double *pj1 = &sxw[wave][1][lane + ph.off];
+    const double *pj2 = &sxw[wave][2][lane + ph.off];
+    const bool mask = s == 0 || (!FULL && (bi == nblk - 1 || ph.bj == nblk - 1));
+    unsigned long long live = ~0ull;
+    if (mask) {
+        const int col_lim = n - 64 * ph.bj;
+        const unsigned long long cols = col_lim >= 64 ? ~0ull : ((1ull << col_lim) - 1ull);
+        const int rot = (lane + ph.off) & 63;
+        live = rot ? ((cols >> rot) | (cols << (64 - rot))) : cols;
+        if (!row_ok) live = 0ull;
+        if (s == 0 && lane >= 32) live &= ~(1ull << 31);
+    }
+    const int t0 = s == 0 ? 0 : 32 + 64 * (s - 1);
+    const double *yp = ypk + ((int64_t)bi * ring_steps(nblk) + t0) * 64 + lane;
+    double y[RING_CHUNK], yn[RING_CHUNK];
+#pragma unroll
+    for (int k = 0; k < RING_CHUNK; ++k) y[k] = yp[k * 64];
+    double P0 = 0.0, P1 = 0.0, P2 = 0.0, R0 = 0.0, R1 = 0.0, R2 = 0.0;
+    for (int m0 = 0; m0 < ph.steps; m0 += RING_CHUNK) {
+        const bool more = m0 + RING_CHUNK < ph.steps;
+        if (more) {
+#pragma unroll
+            for (int k = 0; k < RING_CHUNK; ++k) yn[k] = yp[(int64_t)(m0 + RING_CHUNK + k) * 64];
+        }
+        if (mask) ring_chunk<true>(y, pj0, pj1, pj2, m0, x0, x1, x2, (unsigned)(live >> m0), P0, P1, P2, R0, R1, R2);
+        else      ring_chunk<false>(y, pj0, pj1, pj2, m0, x0, x1, x2, 0u, P0, P1, P2, R0, R1, R2);
+        if (more) {
+#pragma unroll
+            for (int k = 0; k < RING_CHUNK; ++k) y[k] = yn[k];
+        }
+    }
+    double *o = part + ((c * ntiles + tile) * 2) * 3 * 64;
+    const int col = (lane + ph.off + ph.steps) & 63;
+    o[0 * 64 + lane] = P0; o[1 * 64 + lane] = P1; o[2 * 64 + lane] = P2;
+    o[3 * 64 + col] = R0; o[4 * 64 + col] = R1; o[5 * 64 + col] = R2;
+}
+
+// A bead's force from the tiles' partial sums, in the ring kernels' order.
+__device__ inline void tiles_force(const double *part, int64_t c, int bead, int nblk, double (&f)[3])
+{
+    const int nph = nblk / 2, ntiles = ring_tiles(nblk);
+    const int b = bead >> 6, l = bead & 63;
+    const double *pc = part + c * ntiles * 2 * 3 * 64;
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) {
+        double F = 0.0, G = 0.0;
+        for (int s = 0; s <= nph; ++s) {
+            const double v = pc[((int64_t)(b * (nph + 1) + s) * 2) * 192 + ax * 64 + l];
+            F = s == 0 ? v : F + v;
+        }
+        for (int s = 0; s <= nph; ++s) {
+            int bi = b - s; if (bi < 0) bi += nblk;
+            G = G + pc[((int64_t)(bi * (nph + 1) + s) * 2 + 1) * 192 + ax * 64 + l];
+        }
+        f[ax] = F + G;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+pairdist_tiles_grad_kernel(const double *part, double tau, const double *tau_chain, double *out,
+                           int32_t n, int32_t nblk)
+{
+    const int bead = blockIdx.x * 256 + threadIdx.x;
+    const int64_t c = blockIdx.y;
+    if (bead >= n) return;
+    double f[3];
+    tiles_force(part, c, bead, nblk, f);
+    const double tc = tau_chain ? tau_chain[c] : tau;
+    double *o = out + c * 3 * (int64_t)n + 3 * bead;
+    o[0] = tc * f[0]; o[1] = tc * f[1]; o[2] = tc * f[2];
+}
+
+// Force evaluation e of a trajectory: the kick (and, before the last one, the drift) of
+// pairdist_leapfrog_ring_kernel's owner threads, on q and p in memory.
+template <bool FMA>
+__global__ void __launch_bounds__(256)
+pairdist_tiles_update_kernel(const double *part, const PairLeapArgs a, const double *q_in, int32_t nblk, int32_t e)
+{
+    const int n = a.n_beads;
+    const int bead = blockIdx.x * 256 + threadIdx.x;
+    const int64_t c = blockIdx.y;
+    if (bead >= n) return;
+    double f[3];
+    tiles_force(part, c, bead, nblk, f);
+    const double tau = a.tau_chain ? a.tau_chain[c] : a.tau;
+    const double dt = a.dt_chain ? a.dt_chain[c] : a.timestep;
+    const double step = (e == 0 || e == a.nsteps) ? 0.5 * dt : dt;
+    const int64_t o = c * 3 * (int64_t)n + 3 * bead;
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) {
+        double q = q_in[o + ax], p = a.p[o + ax];
+        const double gl = tau * f[ax];
+        double g = gl;
+        if (a.has_prior) {
+            const double gp = a.prior_k * (q - a.prior_x0);
+            g = a.prior_first ? gp + gl : gl + gp;
+        }
+        p = FMA ? __builtin_fma(-step, g, p) : p - step * g;
+        if (e < a.nsteps) q = FMA ? __builtin_fma(p, dt, q) : q + p * dt;
+        a.p[o + ax] = p;
+        a.q[o + ax] = q;
     }
 }
 
@@ -1731,6 +1880,38 @@ static unsigned ring_grid(int64_t C, int nblk)
     return (unsigned)(C < slots ? C : slots);
 }
 
+// Few chains of 257..1024 beads: every tile a wave of its own (pairdist_tiles_kernel) when the
+// caller brings the workspace for the tiles' partial sums -- same bits as the ring kernels,
+// which serve every other case.  A workgroup per chain keeps 64 NBLK threads busy per chain:
+// tiles pay while that leaves most of the chip idle (development aid: BINF_PD_TILES=0 / 1
+// forces the choice).
+static bool tiles_pay(int64_t C, int64_t n_beads)
+{
+    static std::atomic<int> forced(-2);
+    int v = forced.load(std::memory_order_relaxed);
+    if (v == -2) {
+        const char *e = getenv("BINF_PD_TILES");
+        v = e ? (e[0] == '0' ? 0 : 1) : -1;
+        forced.store(v, std::memory_order_relaxed);
+    }
+    if (!ring_serves(n_beads) || C > 65535) return false;
+    if (v >= 0) return v == 1;
+    // measured cross-over (scripts/probe_pairdist_few_chains.py, 256 CUs): a sample() of L = 20
+    // costs 0.52 / 0.87 / 2.9 ms with a workgroup per chain at 320 / 512 / 1024 beads whatever
+    // the number of chains up to ~256, and 0.35 + 0.0013 C / 0.43 + 0.0033 C / 0.82 + 0.0105 C ms
+    // with a wave per tile: tiles win up to ~140 / 130 / 195 chains
+    const int64_t nblk = (n_beads + 63) / 64;
+    return C <= (96 + 6 * nblk) * (int64_t)cu_count() / 256;
+}
+
+static void launch_tiles(const double *x, const double *ypk, double *part, int64_t C, int64_t n, hipStream_t st)
+{
+    const int nblk = (int)((n + 63) / 64);
+    const dim3 grid((unsigned)((ring_tiles(nblk) + TILE_WAVES - 1) / TILE_WAVES), (unsigned)C);
+    if (n == 64 * nblk) pairdist_tiles_kernel<true><<<grid, 64 * TILE_WAVES, 0, st>>>(x, ypk, part, (int32_t)n, nblk);
+    else                pairdist_tiles_kernel<false><<<grid, 64 * TILE_WAVES, 0, st>>>(x, ypk, part, (int32_t)n, nblk);
+}
+
 static void launch_grad_ring(const double *x, const double *ypk, double precision,
                              const double *precision_chain, double *out, int64_t C, int64_t n,
                              hipStream_t st)
@@ -1759,6 +1940,13 @@ static void launch_leapfrog_ring(const PairLeapArgs &a, bool fma, hipStream_t st
     if (fma) { if (full) LEAP_RING(true, true); else LEAP_RING(true, false); }
     else     { if (full) LEAP_RING(false, true); else LEAP_RING(false, false); }
 #undef LEAP_RING
+}
+
+extern "C" int64_t binf_pairdist_tiles_workspace_bytes(int64_t C, int64_t n_beads)
+{
+    if (C < 1 || n_beads < 1 || !tiles_pay(C, n_beads)) return 0;
+    const int64_t nblk = (n_beads + 63) / 64;
+    return C * ring_tiles((int)nblk) * 2 * 3 * 64 * (int64_t)sizeof(double);
 }
 
 extern "C" int64_t binf_pairdist_packed_targets_bytes(int64_t n_beads)
@@ -1802,14 +1990,15 @@ extern "C" int32_t binf_pairdist_gauss_grad_f64(const double *x, const double *y
                                                 int64_t n_beads, void *stream)
 {
     return binf_pairdist_gauss_grad_packed_f64(x, ymat, nullptr, precision, precision_chain, out, C,
-                                               n_beads, stream);
+                                               n_beads, nullptr, 0, stream);
 }
 
 extern "C" int32_t binf_pairdist_gauss_grad_packed_f64(const double *x, const double *ymat,
                                                        const double *packed, double precision,
                                                        const double *precision_chain,
                                                        double *out, int64_t C,
-                                                       int64_t n_beads, void *stream)
+                                                       int64_t n_beads, void *workspace,
+                                                       int64_t workspace_bytes, void *stream)
 {
     if (C < 0 || n_beads < 1) return fail(BINF_E_ARG, "pairdist_gauss_grad: bad sizes");
     if (C == 0) return 0;
@@ -1825,8 +2014,19 @@ extern "C" int32_t binf_pairdist_gauss_grad_packed_f64(const double *x, const do
         else if (nblk == 3) launch_grad_sym<3>(x, ymat, packed, precision, precision_chain, out, C, n_beads, gst);
         else                launch_grad_sym<4>(x, ymat, packed, precision, precision_chain, out, C, n_beads, gst);
     }
-    else if (packed && ring_serves(n_beads))
-        launch_grad_ring(x, packed, precision, precision_chain, out, C, n_beads, gst);
+    else if (packed && ring_serves(n_beads)) {
+        const int64_t need = binf_pairdist_tiles_workspace_bytes(C, n_beads);
+        if (need > 0 && workspace && workspace_bytes >= need) {
+            if (overlap_f64(workspace, need / 8, x, C * 3 * n_beads) || overlap_f64(workspace, need / 8, out, C * 3 * n_beads))
+                return fail(BINF_E_ALIAS, "pairdist_gauss_grad: the workspace overlaps x or out");
+            launch_tiles(x, packed, (double *)workspace, C, n_beads, gst);
+            pairdist_tiles_grad_kernel<<<dim3((unsigned)((n_beads + 255) / 256), (unsigned)C), 256, 0, gst>>>(
+                (const double *)workspace, precision, precision_chain, out, (int32_t)n_beads,
+                (int32_t)((n_beads + 63) / 64));
+        } else {
+            launch_grad_ring(x, packed, precision, precision_chain, out, C, n_beads, gst);
+        }
+    }
     else if (n_beads <= 1024 && lanes_per_bead(C) == 4)
         pairdist_grad4_kernel<<<dim3((unsigned)C), 1024, lds, (hipStream_t)stream>>>(
             x, ymat, precision, precision_chain, out, (int32_t)n_beads);
@@ -1850,7 +2050,7 @@ extern "C" int32_t binf_pairdist_leapfrog_f64(double *q, double *p, const double
 {
     return binf_pairdist_leapfrog_packed_f64(q, nullptr, p, ymat, nullptr, precision, precision_chain,
                                              has_prior, prior_k, prior_x0, prior_first, timestep, dt_chain,
-                                             nsteps, C, n_beads, mode, stream);
+                                             nsteps, C, n_beads, mode, nullptr, 0, stream);
 }
 
 extern "C" int32_t binf_pairdist_leapfrog_packed_f64(double *q, const double *q_from, double *p,
@@ -1860,7 +2060,8 @@ extern "C" int32_t binf_pairdist_leapfrog_packed_f64(double *q, const double *q_
                                                      int32_t has_prior, double prior_k, double prior_x0,
                                                      int32_t prior_first, double timestep,
                                                      const double *dt_chain, int32_t nsteps, int64_t C,
-                                                     int64_t n_beads, int32_t mode, void *stream)
+                                                     int64_t n_beads, int32_t mode, void *workspace,
+                                                     int64_t workspace_bytes, void *stream)
 {
     if (C < 0 || n_beads < 1 || nsteps < 1)
         return fail(BINF_E_ARG, "pairdist_leapfrog: need C>=0, n_beads>=1, nsteps>=1");
@@ -1903,7 +2104,25 @@ extern "C" int32_t binf_pairdist_leapfrog_packed_f64(double *q, const double *q_
         return 0;
     }
     if (packed && ring_serves(n_beads)) {
-        launch_leapfrog_ring(a, fma, st);
+        const int64_t need = binf_pairdist_tiles_workspace_bytes(C, n_beads);
+        if (need > 0 && workspace && workspace_bytes >= need) {
+            const int64_t nq = C * 3 * n_beads;
+            if (overlap_f64(workspace, need / 8, q, nq) || overlap_f64(workspace, need / 8, p, nq) ||
+                (q_from && overlap_f64(workspace, need / 8, q_from, nq)))
+                return fail(BINF_E_ALIAS, "pairdist_leapfrog: the workspace overlaps q, q_from or p");
+            // few chains: per force evaluation one launch of a wave per tile and one that adds the
+            // partial sums and kicks / drifts -- the ring kernel's arithmetic, bit for bit
+            const int nblk = (int)((n_beads + 63) / 64);
+            const dim3 ug((unsigned)((n_beads + 255) / 256), (unsigned)C);
+            for (int e = 0; e <= nsteps; ++e) {
+                const double *qin = (e == 0 && a.q_from) ? a.q_from : q;
+                launch_tiles(qin, packed, (double *)workspace, C, n_beads, st);
+                if (fma) pairdist_tiles_update_kernel<true><<<ug, 256, 0, st>>>((const double *)workspace, a, qin, nblk, e);
+                else     pairdist_tiles_update_kernel<false><<<ug, 256, 0, st>>>((const double *)workspace, a, qin, nblk, e);
+            }
+        } else {
+            launch_leapfrog_ring(a, fma, st);
+        }
         hipError_t es = hipGetLastError();
         if (es != hipSuccess) return hip_fail(es, "pairdist_leapfrog launch");
         return 0;

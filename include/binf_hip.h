@@ -47,7 +47,8 @@ extern "C" {
  *    binf_hmc_gauss_rng_draws_f64 take one stream position per TRANSITION (offset + i),
  *    as the long-chain entry points always did.
  * 6: packed targets and the ring kernels for 257..1024 beads (binf_pairdist_packed_targets_bytes
- *    is no longer 0 there); binf_predictive_density_f64 / _workspace_bytes (the consumer side of the sample store: the
+ *    is no longer 0 there), the `_packed_` entry points take an optional workspace
+ *    (binf_pairdist_tiles_workspace_bytes: a wave per tile when there are few chains); binf_predictive_density_f64 / _workspace_bytes (the consumer side of the sample store: the
  *    posterior-predictive density over a grid of points in one launch). */
 #define BINF_ABI_VERSION 6
 
@@ -796,10 +797,18 @@ int32_t binf_pairdist_gauss_grad_f64(const double *x, const double *ymat,
 int64_t binf_pairdist_packed_targets_bytes(int64_t n_beads);
 int32_t binf_pairdist_pack_targets_f64(const double *ymat, double *packed, int64_t n_beads,
                                        void *stream);
+/* workspace (ABI 6): for FEW chains of 257..1024 beads a workgroup per chain would leave most
+ * of the chip idle; given binf_pairdist_tiles_workspace_bytes(C, n_beads) bytes of device
+ * memory (0 when that does not apply: NULL is then fine, and it is always accepted -- only the
+ * speed changes) every 64 x 64 tile of pairs becomes a wave of its own and a second launch adds
+ * a bead's partial sums in the ring kernels' order: the same bits, ~5x at 32 chains of 1024
+ * beads. */
+int64_t binf_pairdist_tiles_workspace_bytes(int64_t C, int64_t n_beads);
 int32_t binf_pairdist_gauss_grad_packed_f64(const double *x, const double *ymat,
                                             const double *packed, double precision,
                                             const double *precision_chain, double *out,
-                                            int64_t C, int64_t n_beads, void *stream);
+                                            int64_t C, int64_t n_beads, void *workspace,
+                                            int64_t workspace_bytes, void *stream);
 
 /* The whole leapfrog integration HMCSampler._leapfrog (binf/samplers/hmc.py:92-125)
  * for the restraint posterior in one launch: q, p device [C * 3n], integrated in
@@ -825,7 +834,8 @@ int32_t binf_pairdist_leapfrog_packed_f64(double *q, const double *q_from, doubl
                                           double prior_k, double prior_x0, int32_t prior_first,
                                           double timestep, const double *dt_chain,
                                           int32_t nsteps, int64_t C, int64_t n_beads,
-                                          int32_t mode, void *stream);
+                                          int32_t mode, void *workspace,
+                                          int64_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------------
  * Device random draws (throughput mode): counter-based Philox4x32-10, key =

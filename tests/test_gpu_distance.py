@@ -380,6 +380,57 @@ def test_ring_kernels_every_unordered_pair_once_from_257_to_1024_beads(device, n
         assert torch.equal(qa, qb) and torch.equal(pa, pb), mode
 
 
+@pytest.mark.parametrize('n', [257, 320, 384, 500, 512, 576, 1000, 1024])
+def test_few_chains_take_a_wave_per_tile_same_bits_as_the_ring_kernels(device, n):
+    """Few chains of 257..1024 beads (32 replicas of a 1000-bead model use an eighth of the chip with
+    a workgroup per chain): with the workspace the library asks for every 64 x 64 tile of pairs is a
+    wave of its own and a second launch adds a bead's partial sums in the ring kernels' order --
+    force and fused leapfrog bit for bit what the ring kernels give (forced here through the C ABI
+    by withholding the workspace), in both arithmetic modes, with a separate start buffer too."""
+    import ctypes
+    ys, x = synth(n, 5, 13 * n)
+    lik = make_distance_likelihood(ys, n)
+    ymat = lik.error_model.ymat_device(device)
+    packed = _native.pairdist_pack_targets(ymat)
+    L = _native.lib()
+    C = 5
+    need = L.binf_pairdist_tiles_workspace_bytes(C, n)
+    assert need > 0 and L.binf_pairdist_tiles_workspace_bytes(100000, n) == 0
+    assert L.binf_pairdist_tiles_workspace_bytes(C, 256) == 0 and L.binf_pairdist_tiles_workspace_bytes(C, 1025) == 0
+    rs = np.random.RandomState(n)
+    xx, tau = dev_t(x, device), dev_t(rs.uniform(0.5, 3.0, size=C), device)
+    pp = lambda t: ctypes.c_void_p(t.data_ptr())
+    st = _native.stream_handle(device)
+    ws = torch.empty(need // 8, dtype=torch.float64, device=device)
+
+    def grad(with_ws):
+        out = torch.empty_like(xx)
+        rc = L.binf_pairdist_gauss_grad_packed_f64(pp(xx), pp(ymat), pp(packed), 0.0, pp(tau), pp(out), C, n,
+                                                   pp(ws) if with_ws else None, need if with_ws else 0, st)
+        assert rc == 0
+        return out
+
+    assert torch.equal(grad(True), grad(False))
+    assert torch.equal(_native.pairdist_gauss_grad(xx, ymat, tau, packed=packed), grad(False))   # the wrapper brings it
+    p0 = dev_t(rs.standard_normal((C, 3 * n)), device)
+    for mode in (_native.MODE_EXACT, _native.MODE_FMA):
+        runs = []
+        for with_ws in (True, False):
+            for sep in (False, True):
+                q = torch.empty_like(xx) if sep else xx.clone()
+                p = p0.clone()
+                rc = L.binf_pairdist_leapfrog_packed_f64(pp(q), pp(xx) if sep else None, pp(p), pp(ymat), pp(packed),
+                                                         0.0, pp(tau), 1, 0.05, 0.1, 1, 2e-3, None, 4, C, n, mode,
+                                                         pp(ws) if with_ws else None, need if with_ws else 0, st)
+                assert rc == 0
+                runs.append((q, p))
+        for q, p in runs[1:]:
+            assert torch.equal(q, runs[0][0]) and torch.equal(p, runs[0][1]), mode
+    # the workspace may not overlap what the launch reads or writes
+    assert L.binf_pairdist_gauss_grad_packed_f64(pp(xx), pp(ymat), pp(packed), 1.0, None, pp(ws), C, n, pp(ws), need,
+                                                 st) == _native.E_ALIAS
+
+
 def test_bead_counts_without_a_packed_form(device):
     for n in (8, 31, 1025, 1500):
         assert _native.lib().binf_pairdist_packed_targets_bytes(n) == 0

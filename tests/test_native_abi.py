@@ -137,7 +137,7 @@ def test_alias_refusals_without_gpu():
     # the pair-distance leapfrog's start buffer
     nb = 10
     q, p, qf, ymat = base, base + (1 << 30), base + (2 << 30), base + (3 << 30)
-    args = lambda qf_, p_=p: (q, qf_, p_, ymat, None, 1.0, None, 0, 0.0, 0.0, 0, 0.01, None, 2, C, nb, 0, None)
+    args = lambda qf_, p_=p: (q, qf_, p_, ymat, None, 1.0, None, 0, 0.0, 0.0, 0, 0.01, None, 2, C, nb, 0, None, 0, None)
     assert L.binf_pairdist_leapfrog_packed_f64(*args(q + 8)) == _native.E_ALIAS
     assert L.binf_pairdist_leapfrog_packed_f64(*args(p + 8)) == _native.E_ALIAS
     assert L.binf_pairdist_leapfrog_packed_f64(*args(qf, p_=q + 16)) == _native.E_ALIAS
