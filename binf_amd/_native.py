@@ -111,10 +111,11 @@ SIGNATURES = {
     'binf_poly_leapfrog_workspace_bytes': (_i64, [_i64, _i64, _i64]),
     'binf_poly_leapfrog_f64': (_i32, [_vp, _vp, _vp, _vp, _f64, _vp, _vp, _i64, _i64, _i64, _i64,
                                       _f64, _vp, _i32, _i32, _vp]),
+    'binf_pairdist_chi2_workspace_bytes': (_i64, [_i64, _i64, _i64]),
     'binf_pairdist_gauss_logp_f64': (_i32, [_vp, _vp, _vp, _vp, _f64, _vp, _vp, _i64,
-                                            _i64, _i64, _vp]),
+                                            _i64, _i64, _vp, _i64, _vp]),
     'binf_pairdist_gauss_logp_memo_f64': (_i32, [_vp, _vp, _vp, _vp, _f64, _vp, _vp, _vp, _vp, _vp,
-                                                 _i64, _i64, _i64, _vp]),
+                                                 _i64, _i64, _i64, _vp, _i64, _vp]),
     'binf_pairdist_forward_f64': (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i64,
                                          _vp]),
     'binf_pairdist_gauss_grad_f64': (_i32, [_vp, _vp, _f64, _vp, _vp, _i64,
@@ -124,7 +125,7 @@ SIGNATURES = {
                                           _i64, _i32, _vp]),
     'binf_pairdist_hmc_energy_f64': (_i32, [_vp, _vp, _vp, _vp, _vp, _f64, _vp, _f64, _f64, _i32,
                                             ctypes.POINTER(_i32), _vp, _f64, _vp, _f64,
-                                            _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp]),
+                                            _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _i64, _vp]),
     'binf_pairdist_packed_targets_bytes': (_i64, [_i64]),
     'binf_pairdist_pack_targets_f64': (_i32, [_vp, _vp, _i64, _vp]),
     'binf_pairdist_tiles_workspace_bytes': (_i64, [_i64, _i64]),
@@ -997,6 +998,23 @@ def pairdist_forward(x, pair_i, pair_j):
     return out
 
 
+_chi2_ws = {}
+
+
+def _pairdist_chi2_workspace(C, n, P, device):
+    """(pointer, bytes) of the scratch for chi^2 by chunks (few chains, or more than 2048 beads:
+    binf_pairdist_chi2_workspace_bytes), one buffer per device and stream, grown on demand;
+    ``(None, 0)`` when the library does not ask for one."""
+    need = lib().binf_pairdist_chi2_workspace_bytes(C, n, P)
+    if need <= 0:
+        return None, 0
+    key = (device, stream_handle(device))
+    ws = _chi2_ws.get(key)
+    if ws is None or ws.numel() * 8 < need:
+        ws = _chi2_ws[key] = torch.empty(need // 8, dtype=torch.float64, device=device)
+    return ws.data_ptr(), ws.numel() * 8
+
+
 @_launcher
 def pairdist_gauss_logp(x, pair_i, pair_j, ys, precision):
     """Gaussian log-likelihood of the pair distances, fused (no [C x n_pairs]
@@ -1011,7 +1029,7 @@ def pairdist_gauss_logp(x, pair_i, pair_j, ys, precision):
         dptr(x, numel=C * D, name='x'), dptr(pair_i, torch.int32, P, 'pair_i'),
         dptr(pair_j, torch.int32, P, 'pair_j'), dptr(ys, numel=P, name='ys'), tau,
         dptr(tau_chain, numel=C, name='precision'), dptr(out), C, D // 3, P,
-        stream_handle(x.device))
+        *_pairdist_chi2_workspace(C, D // 3, P, x.device), stream_handle(x.device))
     check(rc, 'binf_pairdist_gauss_logp_f64')
     return out
 
@@ -1031,7 +1049,7 @@ def pairdist_gauss_logp_memo(x, pair_i, pair_j, ys, precision, memo):
         dptr(pair_j, torch.int32, P, 'pair_j'), dptr(ys, numel=P, name='ys'), tau,
         dptr(tau_chain, numel=C, name='precision'), dptr(out), dptr(mx, numel=2 * C * D, name='memo_x'),
         dptr(ms, numel=2 * C, name='memo_chi2'), dptr(sk, torch.uint8, 2 * C, 'memo_state'), C, D // 3, P,
-        stream_handle(x.device))
+        *_pairdist_chi2_workspace(C, D // 3, P, x.device), stream_handle(x.device))
     check(rc, 'binf_pairdist_gauss_logp_memo_f64')
     return out
 
@@ -1082,7 +1100,8 @@ def pairdist_hmc_energy(x, p, pair_i, pair_j, ys, precision, prior, prior_first,
         float(k), float(x0), len(kinds), kind_arr, ptrs[0], scalars[0], ptrs[1], scalars[1],
         dptr(energy), dptr(lp),
         dptr(mx, numel=2 * C * D, name='memo_x'), dptr(ms, numel=2 * C, name='memo_chi2'),
-        dptr(st, torch.uint8, 2 * C, 'memo_state'), C, D // 3, P, stream_handle(x.device))
+        dptr(st, torch.uint8, 2 * C, 'memo_state'), C, D // 3, P,
+        *_pairdist_chi2_workspace(C, D // 3, P, x.device), stream_handle(x.device))
     check(rc, 'binf_pairdist_hmc_energy_f64')
     return (energy, lp) if want_log_prob else energy
 

@@ -340,6 +340,68 @@ pairdist_chi2_rows_kernel(const PairArgs a, const RowGeom g, double *out)
     }
 }
 
+// ---- chi^2 with FEW chains: a workgroup per chain walks the whole pair list (0.3 ms at 1024
+// beads, 1.2 ms at 2048, whatever the number of chains up to the number of CUs).  np.sum works
+// in chunks of 8192 elements whose sums it adds one after the other, so the chunks are
+// independent: here every (chunk, chain) is a workgroup, the chunk sums go to a workspace and a
+// second launch adds them in order -- the same bits -- and applies the epilogue.  The
+// coordinates are read through the caches (no LDS copy: any number of beads).
+struct PairResidChunk {
+    const double *xc;
+    const int32_t *I;
+    const int32_t *J;
+    const double *ys;
+    int64_t base;
+    __device__ inline void operator()(int p, double (&v)[1]) const
+    {
+        const int64_t P = base + p;
+        const int i = I[P], j = J[P];
+        const double a = xc[3 * i] - xc[3 * j];
+        const double b = xc[3 * i + 1] - xc[3 * j + 1];
+        const double e = xc[3 * i + 2] - xc[3 * j + 2];
+        const double s = (a * a + b * b) + e * e;
+        const double d = sqrt_rn(s) - ys[P];
+        v[0] = d * d;
+    }
+};
+
+template <int U>
+__global__ void __launch_bounds__(256)
+pairdist_chi2_chunk_kernel(const PairArgs a, const RowGeom g, double *partial, int32_t nchunks)
+{
+    __shared__ BlockSumScratch sc;
+    const int64_t c = blockIdx.y;
+    const int k = blockIdx.x;
+    if (g.skip && g.skip[c]) return;             // the memo holds this chain's sum (workgroup-uniform)
+    int round = 0;
+    PairResidChunk f;
+    f.xc = a.x + c * 3 * a.n_beads; f.I = a.I; f.J = a.J; f.ys = a.ys;
+    f.base = (int64_t)k * NPY_BUFSIZE;
+    const int64_t left = (int64_t)g.D - f.base;
+    const int len = left < NPY_BUFSIZE ? (int)left : NPY_BUFSIZE;
+    double total[1];
+    block_sum_rows<1, U, 256>(f, len, g.H, sc, round, total);    // 0.0 + this chunk's sum
+    if (threadIdx.x == 0) partial[c * nchunks + k] = total[0];
+}
+
+// chunk sums in order, the memo, the epilogue; chi2_out (or null) receives the bare sums
+__global__ void __launch_bounds__(256)
+pairdist_chi2_join_kernel(const RowGeom g, const double *partial, int32_t nchunks, double *out, double *chi2_out)
+{
+    const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (row >= g.C) return;
+    double total;
+    if (g.skip && g.skip[row]) {
+        total = *row_memo_slot(g, row);
+    } else {
+        total = 0.0;                             // the reduction's identity
+        for (int k = 0; k < nchunks; ++k) total = total + partial[row * nchunks + k];
+        if (g.memo_sum) *row_memo_slot(g, row) = total;
+    }
+    if (chi2_out) chi2_out[row] = total;
+    if (out) out[row] = row_result(g, row, total);
+}
+
 // ---- the energy of HMCSampler.sample() (hmc.py:143,148,150) for the restraint posterior in
 // ONE launch:  E = 0.5 np.sum(p**2) - log_prob,  log_prob = the Posterior's sum of its
 // components in their order (binf/pdf/posteriors.py:147-151): the restraint likelihood
@@ -368,6 +430,7 @@ struct PairEnergyArgs {
     double extra_scalar[2];
     int32_t n_beads;
     int32_t H_d;             // tree height of a 3n-element sum
+    const double *chi2_in;   // [C] or null: the restraints' chi^2 already summed (few chains: by chunks)
 };
 
 template <int ROWS>
@@ -410,7 +473,8 @@ pairdist_energy_kernel(const PairEnergyArgs a, const RowGeom g)
 #pragma unroll
     for (int q = 0; q < ROWS; ++q) rows[q] = (row0 + q < g.C) ? row0 + q : g.C - 1;
     const int n3 = 3 * a.n_beads;
-    const bool memo = a.memo_x != nullptr;
+    const bool given = a.chi2_in != nullptr;     // then the memo was served by the launches before this one
+    const bool memo = a.memo_x != nullptr && !given;
     if (threadIdx.x < 2 * ROWS) differs[threadIdx.x >> 1][threadIdx.x & 1] = 0;
     __syncthreads();
     // coordinates to LDS; on the way, compared BIT FOR BIT with the memo's two entries
@@ -452,7 +516,10 @@ pairdist_energy_kernel(const PairEnergyArgs a, const RowGeom g)
         }
     }
     double chi2[ROWS];
-    if (!all_hit) {                              // uniform
+    if (given) {
+#pragma unroll
+        for (int q = 0; q < ROWS; ++q) chi2[q] = a.chi2_in[rows[q]];
+    } else if (!all_hit) {                       // uniform
         PairResidRows<ROWS> f;
         f.xl = row_lds; f.I = a.I; f.J = a.J; f.ys = a.ys;
         block_sum_rows<ROWS, U, THREADS>(f, g.D, g.H, sc, round, chi2);
@@ -1178,7 +1245,8 @@ __global__ void __launch_bounds__(1024) pairdist_leapfrog_sym_kernel(const PairL
 //    kernel: step t of wave b, lane l at ypk[(b T + t) 64 + l] -- coalesced, 1 MiB at
 //    512 beads, shared by all chains and resident in L2).
 // ---------------------------------------------------------------------------
-constexpr int RING_MAX_BEADS = 1024;
+constexpr int RING_MAX_BEADS = 1024;     // a workgroup (<= 16 waves) per chain
+constexpr int TILES_MAX_BEADS = 4096;    // a wave per tile: any number of blocks (packed targets: 64 MiB here)
 constexpr int RING_CHUNK = 8;            // steps whose targets are in flight / in use at a time
                                          // (4: -2 %, 16: -8 % at 512 .. 1024 beads, same-box A/B)
 
@@ -1650,17 +1718,57 @@ extern "C" int32_t binf_pairdist_forward_f64(const double *x, const int32_t *pai
 static int32_t pairdist_logp_run(const double *x, const int32_t *pair_i, const int32_t *pair_j,
                                  const double *ys, double precision, const double *precision_chain,
                                  double *out, const uint8_t *skip, double *memo_chi2, int64_t C,
-                                 int64_t n_beads, int64_t n_pairs, void *stream);
+                                 int64_t n_beads, int64_t n_pairs, void *workspace,
+                                 int64_t workspace_bytes, void *stream);
+
+// chi^2 by chunks (pairdist_chi2_chunk_kernel) pays while a workgroup per chain leaves CUs idle and
+// the pair list is long enough to split (development aid: BINF_PD_CHUNKS=0 / 1 forces the choice);
+// beyond 2048 beads it is the only form that keeps the coordinates out of HBM round trips
+static bool chunks_pay(int64_t C, int64_t n_beads, int64_t n_pairs)
+{
+    static std::atomic<int> forced(-2);
+    int v = forced.load(std::memory_order_relaxed);
+    if (v == -2) {
+        const char *e = getenv("BINF_PD_CHUNKS");
+        v = e ? (e[0] == '0' ? 0 : 1) : -1;
+        forced.store(v, std::memory_order_relaxed);
+    }
+    if (C < 1 || C > 65535 || n_pairs < 2 * NPY_BUFSIZE || n_pairs > 0x7fffffffLL) return false;
+    if (v >= 0) return v == 1;
+    return n_beads > 2048 || C < (int64_t)cu_count();
+}
+
+static int64_t chi2_chunks(int64_t n_pairs) { return (n_pairs + NPY_BUFSIZE - 1) / NPY_BUFSIZE; }
+
+// the chunk sums of every chain to workspace[0 .. C K), joined into out (log-prob) and / or
+// chi2_out (workspace[C K .. C K + C) when the caller passes that)
+static int32_t chi2_by_chunks(const PairArgs &a, const RowGeom &g, double *workspace, double *out,
+                              double *chi2_out, hipStream_t st)
+{
+    const int K = (int)chi2_chunks(g.D);
+    pairdist_chi2_chunk_kernel<8><<<dim3((unsigned)K, (unsigned)g.C), 256, 0, st>>>(a, g, workspace, K);
+    pairdist_chi2_join_kernel<<<dim3((unsigned)((g.C + 255) / 256)), 256, 0, st>>>(g, workspace, K, out, chi2_out);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "pairdist chi^2 by chunks");
+    return 0;
+}
+
+extern "C" int64_t binf_pairdist_chi2_workspace_bytes(int64_t C, int64_t n_beads, int64_t n_pairs)
+{
+    if (!chunks_pay(C, n_beads, n_pairs)) return 0;
+    return (C * chi2_chunks(n_pairs) + C) * (int64_t)sizeof(double);
+}
 
 extern "C" int32_t binf_pairdist_gauss_logp_f64(const double *x, const int32_t *pair_i,
                                                 const int32_t *pair_j, const double *ys,
                                                 double precision,
                                                 const double *precision_chain, double *out,
                                                 int64_t C, int64_t n_beads,
-                                                int64_t n_pairs, void *stream)
+                                                int64_t n_pairs, void *workspace,
+                                                int64_t workspace_bytes, void *stream)
 {
     return pairdist_logp_run(x, pair_i, pair_j, ys, precision, precision_chain, out, nullptr, nullptr,
-                             C, n_beads, n_pairs, stream);
+                             C, n_beads, n_pairs, workspace, workspace_bytes, stream);
 }
 
 // The same with a per-chain memo of chi^2 (a function of the chain's coordinates alone),
@@ -1671,7 +1779,8 @@ extern "C" int32_t binf_pairdist_gauss_logp_memo_f64(const double *x, const int3
                                                      const double *precision_chain, double *out,
                                                      double *memo_x, double *memo_chi2,
                                                      uint8_t *skip, int64_t C, int64_t n_beads,
-                                                     int64_t n_pairs, void *stream)
+                                                     int64_t n_pairs, void *workspace,
+                                                     int64_t workspace_bytes, void *stream)
 {
     if (C < 0 || n_beads < 0 || n_pairs < 0)
         return fail(BINF_E_ARG, "pairdist_gauss_logp_memo: negative size");
@@ -1684,11 +1793,18 @@ extern "C" int32_t binf_pairdist_gauss_logp_memo_f64(const double *x, const int3
         return fail(BINF_E_ARG, "pairdist_gauss_logp_memo: null buffer");
     int32_t rc = row_reduce_check(C, n_pairs, "pairdist_gauss_logp_memo");
     if (rc) return rc;
+    {
+        const int64_t need = binf_pairdist_chi2_workspace_bytes(C, n_beads, n_pairs);
+        if (need > 0 && workspace && workspace_bytes >= need &&
+            (overlap_f64(workspace, need / 8, x, C * 3 * n_beads) || overlap_f64(workspace, need / 8, out, C) ||
+             overlap_f64(workspace, need / 8, memo_x, 2 * C * 3 * n_beads) || overlap_f64(workspace, need / 8, memo_chi2, 2 * C)))
+            return fail(BINF_E_ALIAS, "pairdist_gauss_logp_memo: the workspace overlaps a buffer");
+    }
     rc = row_memo_check(x, memo_x, skip, C, 3 * n_beads, (hipStream_t)stream,
                         "pairdist_gauss_logp_memo check launch");
     if (rc) return rc;
     return pairdist_logp_run(x, pair_i, pair_j, ys, precision, precision_chain, out, skip, memo_chi2,
-                             C, n_beads, n_pairs, stream);
+                             C, n_beads, n_pairs, workspace, workspace_bytes, stream);
 }
 
 // tree height of an np.sum over D elements as the block reductions walk it (rowsum.hpp:
@@ -1738,7 +1854,8 @@ static int pairdist_logp_rows(int64_t C, int64_t n_beads, int64_t n_pairs)
 static int32_t pairdist_logp_run(const double *x, const int32_t *pair_i, const int32_t *pair_j,
                                  const double *ys, double precision, const double *precision_chain,
                                  double *out, const uint8_t *skip, double *memo_chi2, int64_t C,
-                                 int64_t n_beads, int64_t n_pairs, void *stream)
+                                 int64_t n_beads, int64_t n_pairs, void *workspace,
+                                 int64_t workspace_bytes, void *stream)
 {
     if (C < 0 || n_beads < 0 || n_pairs < 0)
         return fail(BINF_E_ARG, "pairdist_gauss_logp: negative size");
@@ -1751,6 +1868,20 @@ static int32_t pairdist_logp_run(const double *x, const int32_t *pair_i, const i
     int32_t rc;
     GaussFinish fin;                // lp = -0.5 chi2 tau + N/2 log tau, written by the reduction
     fin.on = 1; fin.minus = nullptr; fin.tau = precision; fin.tau_chain = precision_chain; fin.n_data = (double)n_pairs;
+    {
+        // few chains (or more than 2048 beads): every 8192-pair chunk a workgroup of its own
+        const int64_t need = binf_pairdist_chi2_workspace_bytes(C, n_beads, n_pairs);
+        if (need > 0 && workspace && workspace_bytes >= need) {
+            if (overlap_f64(workspace, need / 8, x, C * 3 * n_beads) || overlap_f64(workspace, need / 8, out, C))
+                return fail(BINF_E_ALIAS, "pairdist_gauss_logp: the workspace overlaps x or out");
+            RowGeom g;
+            g.C = C; g.D = (int32_t)n_pairs; g.scale = 1.0; g.fin = fin;
+            g.skip = skip; g.way = skip ? skip + C : nullptr; g.memo_sum = memo_chi2;
+            g.H = npsum_tree_height(n_pairs);
+            if (g.H > 7) return fail(BINF_E_UNSUPPORTED, "pairdist_gauss_logp: pairwise tree height %d", g.H);
+            return chi2_by_chunks(a, g, (double *)workspace, out, nullptr, st);
+        }
+    }
     if (n_beads <= 2048 && !pairdist_logp_lds_tree()) {       // 48 KiB of coordinates fit the LDS budget
         if (C > 0x7fffffffLL || n_pairs > 0x7fffffffLL)
             return fail(BINF_E_UNSUPPORTED, "pairdist_gauss_logp: too large");
@@ -1798,7 +1929,8 @@ extern "C" int32_t binf_pairdist_hmc_energy_f64(const double *x, const double *p
                                                 double extra1_scalar,
                                                 double *energy, double *log_prob, double *memo_x,
                                                 double *memo_chi2, uint8_t *memo_state, int64_t C,
-                                                int64_t n_beads, int64_t n_pairs, void *stream)
+                                                int64_t n_beads, int64_t n_pairs, void *workspace,
+                                                int64_t workspace_bytes, void *stream)
 {
     if (C < 0 || n_beads < 1 || n_pairs < 0)
         return fail(BINF_E_ARG, "pairdist_hmc_energy: bad sizes");
@@ -1837,9 +1969,40 @@ extern "C" int32_t binf_pairdist_hmc_energy_f64(const double *x, const double *p
     for (int k = 0; k < 4; ++k) a.term_kind[k] = k < n_terms ? term_kind[k] : 1;
     a.extra[0] = extra0; a.extra[1] = extra1; a.extra_scalar[0] = extra0_scalar; a.extra_scalar[1] = extra1_scalar;
     a.n_beads = (int32_t)n_beads; a.H_d = npsum_tree_height(3 * n_beads);
+    a.chi2_in = nullptr;
     if (g.H > 7 || a.H_d > 7)
         return fail(BINF_E_UNSUPPORTED, "pairdist_hmc_energy: pairwise tree height %d", g.H > a.H_d ? g.H : a.H_d);
     hipStream_t st = (hipStream_t)stream;
+    {
+        // few chains: chi^2 by chunks first (every 8192-pair chunk a workgroup of its own), the rest
+        // of the energy from it
+        const int64_t need = binf_pairdist_chi2_workspace_bytes(C, n_beads, n_pairs);
+        if (need > 0 && workspace && workspace_bytes >= need) {
+            if (overlap_f64(workspace, need / 8, x, C * 3 * n_beads) || overlap_f64(workspace, need / 8, p, C * 3 * n_beads) ||
+                overlap_f64(workspace, need / 8, energy, C) || (log_prob && overlap_f64(workspace, need / 8, log_prob, C)))
+                return fail(BINF_E_ALIAS, "pairdist_hmc_energy: the workspace overlaps a buffer");
+            PairArgs pa;
+            pa.x = x; pa.I = pair_i; pa.J = pair_j; pa.ys = ys; pa.n_beads = n_beads;
+            RowGeom gc = g;
+            if (memo_x) {
+                // the memo as the log-prob entry point keeps it: checked (and, on a miss, its
+                // coordinates rewritten) by a launch of its own, hits skip their chunks, the join
+                // stores the new sums -- the same entries and flags the one-launch kernel leaves
+                if (overlap_f64(workspace, need / 8, memo_x, 2 * C * 3 * n_beads) || overlap_f64(workspace, need / 8, memo_chi2, 2 * C))
+                    return fail(BINF_E_ALIAS, "pairdist_hmc_energy: the workspace overlaps the memo");
+                const int32_t rm = row_memo_check(x, memo_x, memo_state, C, 3 * n_beads, st,
+                                                  "pairdist_hmc_energy memo check launch");
+                if (rm) return rm;
+                gc.skip = memo_state; gc.way = memo_state + C; gc.memo_sum = memo_chi2;
+            } else {
+                gc.memo_sum = nullptr; gc.skip = nullptr; gc.way = nullptr;
+            }
+            double *chi2 = (double *)workspace + C * chi2_chunks(n_pairs);
+            const int32_t rc = chi2_by_chunks(pa, gc, (double *)workspace, nullptr, chi2, st);
+            if (rc) return rc;
+            a.chi2_in = chi2;
+        }
+    }
     const int rows = pairdist_logp_rows(C, n_beads, n_pairs);
     const size_t lds = (size_t)rows * n_beads * 3 * sizeof(double);
     if (rows == 2)
@@ -1872,6 +2035,12 @@ static bool ring_serves(int64_t n_beads)
     return v != 0 && n_beads > SYM_MAX_BEADS && n_beads <= RING_MAX_BEADS;
 }
 
+// ... and up to TILES_MAX_BEADS the tile kernels alone (no workgroup-per-chain form there)
+static bool tiles_serve(int64_t n_beads)
+{
+    return ring_serves(n_beads) || (ring_serves(RING_MAX_BEADS) && n_beads > RING_MAX_BEADS && n_beads <= TILES_MAX_BEADS);
+}
+
 // workgroups of the ring kernels: as many as the chip holds at a time (NBLK <= 8: two
 // per CU, 16 waves; else one), each walks its share of the chains
 static unsigned ring_grid(int64_t C, int nblk)
@@ -1894,7 +2063,8 @@ static bool tiles_pay(int64_t C, int64_t n_beads)
         v = e ? (e[0] == '0' ? 0 : 1) : -1;
         forced.store(v, std::memory_order_relaxed);
     }
-    if (!ring_serves(n_beads) || C > 65535) return false;
+    if (!tiles_serve(n_beads) || C > 65535) return false;
+    if (n_beads > RING_MAX_BEADS) return true;       // the only symmetric form beyond 1024 beads
     if (v >= 0) return v == 1;
     // measured cross-over (scripts/probe_pairdist_few_chains.py, 256 CUs): a sample() of L = 20
     // costs 0.52 / 0.87 / 2.9 ms with a workgroup per chain at 320 / 512 / 1024 beads whatever
@@ -1952,7 +2122,7 @@ extern "C" int64_t binf_pairdist_tiles_workspace_bytes(int64_t C, int64_t n_bead
 extern "C" int64_t binf_pairdist_packed_targets_bytes(int64_t n_beads)
 {
     const int64_t nblk = (n_beads + 63) / 64;
-    if (ring_serves(n_beads)) return nblk * ring_steps((int)nblk) * 64 * (int64_t)sizeof(double);
+    if (tiles_serve(n_beads)) return nblk * ring_steps((int)nblk) * 64 * (int64_t)sizeof(double);
     if (!sym_serves(n_beads)) return 0;
     return nblk * nblk * SYM_STEPS * 64 * (int64_t)sizeof(double);
 }
@@ -1961,13 +2131,13 @@ extern "C" int32_t binf_pairdist_pack_targets_f64(const double *ymat, double *pa
                                                   int64_t n_beads, void *stream)
 {
     if (n_beads < 1) return fail(BINF_E_ARG, "pairdist_pack_targets: bad size");
-    if (!sym_serves(n_beads) && !ring_serves(n_beads))
+    if (!sym_serves(n_beads) && !tiles_serve(n_beads))
         return fail(BINF_E_UNSUPPORTED, "pairdist_pack_targets: n_beads=%lld has no packed form "
                     "(binf_pairdist_packed_targets_bytes is 0)", (long long)n_beads);
     if (!ymat || !packed) return fail(BINF_E_ARG, "pairdist_pack_targets: null buffer");
     hipStream_t st = (hipStream_t)stream;
     const int nblk = (int)((n_beads + 63) / 64);
-    if (ring_serves(n_beads)) {
+    if (tiles_serve(n_beads)) {
         ring_pack_targets_kernel<<<dim3((unsigned)nblk), 256, 0, st>>>(ymat, packed, (int)n_beads, nblk);
         const hipError_t er = hipGetLastError();
         if (er != hipSuccess) return hip_fail(er, "pairdist_pack_targets launch");
@@ -2014,7 +2184,9 @@ extern "C" int32_t binf_pairdist_gauss_grad_packed_f64(const double *x, const do
         else if (nblk == 3) launch_grad_sym<3>(x, ymat, packed, precision, precision_chain, out, C, n_beads, gst);
         else                launch_grad_sym<4>(x, ymat, packed, precision, precision_chain, out, C, n_beads, gst);
     }
-    else if (packed && ring_serves(n_beads)) {
+    else if (packed && tiles_serve(n_beads) &&
+             (ring_serves(n_beads) || (workspace && workspace_bytes >= binf_pairdist_tiles_workspace_bytes(C, n_beads) &&
+                                       binf_pairdist_tiles_workspace_bytes(C, n_beads) > 0))) {
         const int64_t need = binf_pairdist_tiles_workspace_bytes(C, n_beads);
         if (need > 0 && workspace && workspace_bytes >= need) {
             if (overlap_f64(workspace, need / 8, x, C * 3 * n_beads) || overlap_f64(workspace, need / 8, out, C * 3 * n_beads))
@@ -2069,8 +2241,13 @@ extern "C" int32_t binf_pairdist_leapfrog_packed_f64(double *q, const double *q_
         return fail(BINF_E_ARG, "pairdist_leapfrog: unknown mode %d", mode);
     if (C == 0) return 0;
     if (!q || !p || !ymat) return fail(BINF_E_ARG, "pairdist_leapfrog: null buffer");
-    if (n_beads > 1024)
-        return fail(BINF_E_UNSUPPORTED, "pairdist_leapfrog: n_beads=%lld > 1024 not covered by the fused kernel", (long long)n_beads);
+    const bool beyond = n_beads > 1024;          // only as a wave per tile (packed targets + workspace)
+    if (beyond && !(packed && tiles_serve(n_beads) && workspace &&
+                    binf_pairdist_tiles_workspace_bytes(C, n_beads) > 0 &&
+                    workspace_bytes >= binf_pairdist_tiles_workspace_bytes(C, n_beads)))
+        return fail(BINF_E_UNSUPPORTED, "pairdist_leapfrog: n_beads=%lld > 1024 needs packed targets and the "
+                    "workspace of binf_pairdist_tiles_workspace_bytes (up to %d beads)", (long long)n_beads,
+                    TILES_MAX_BEADS);
     if (C > 0x7fffffffLL) return fail(BINF_E_UNSUPPORTED, "pairdist_leapfrog: too many chains");
     // q_from may be q itself (in place) or a separate buffer; a PARTIAL overlap -- with q, or with
     // the momenta the launch updates -- would have chains read what others already wrote
@@ -2103,7 +2280,7 @@ extern "C" int32_t binf_pairdist_leapfrog_packed_f64(double *q, const double *q_
         if (es != hipSuccess) return hip_fail(es, "pairdist_leapfrog launch");
         return 0;
     }
-    if (packed && ring_serves(n_beads)) {
+    if (packed && tiles_serve(n_beads)) {
         const int64_t need = binf_pairdist_tiles_workspace_bytes(C, n_beads);
         if (need > 0 && workspace && workspace_bytes >= need) {
             const int64_t nq = C * 3 * n_beads;
@@ -2120,8 +2297,10 @@ extern "C" int32_t binf_pairdist_leapfrog_packed_f64(double *q, const double *q_
                 if (fma) pairdist_tiles_update_kernel<true><<<ug, 256, 0, st>>>((const double *)workspace, a, qin, nblk, e);
                 else     pairdist_tiles_update_kernel<false><<<ug, 256, 0, st>>>((const double *)workspace, a, qin, nblk, e);
             }
-        } else {
+        } else if (ring_serves(n_beads)) {
             launch_leapfrog_ring(a, fma, st);
+        } else {
+            return fail(BINF_E_UNSUPPORTED, "pairdist_leapfrog: n_beads=%lld needs the tiles workspace", (long long)n_beads);
         }
         hipError_t es = hipGetLastError();
         if (es != hipSuccess) return hip_fail(es, "pairdist_leapfrog launch");

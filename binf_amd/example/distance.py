@@ -283,10 +283,13 @@ def match_energy(posterior, variable_name):
 
 def leapfrog(sampler, spec, q2, p2, dt, dtc, nsteps, mode, q_from):
     """The whole integration in one launch (bit-identical to the per-step loop)."""
-    if q2.shape[1] % 3 != 0 or q2.shape[1] // 3 > 1024:
-        return False
     _, em, precision, prior, prior_first = spec
     packed = getattr(em, 'ypacked_device', None)
+    n = q2.shape[1] // 3
+    # beyond 1024 beads only as a wave per tile: packed targets + the library's workspace
+    if q2.shape[1] % 3 != 0 or (n > 1024 and (packed is None or packed(q2.device) is None or
+                                              _native.lib().binf_pairdist_tiles_workspace_bytes(q2.shape[0], n) <= 0)):
+        return False
     qf = None
     if q_from is not None:
         qf = q_from

@@ -46,7 +46,8 @@ extern "C" {
  *    tensor never has to be read back to the host); binf_hmc_sample_n_gauss_rng_f64 /
  *    binf_hmc_gauss_rng_draws_f64 take one stream position per TRANSITION (offset + i),
  *    as the long-chain entry points always did.
- * 6: packed targets and the ring kernels for 257..1024 beads (binf_pairdist_packed_targets_bytes
+ * 6: optional workspace for the pair-distance log-prob / energy entry points (chi^2 by chunks with
+ *    few chains: binf_pairdist_chi2_workspace_bytes); packed targets and the ring kernels for 257..1024 beads (binf_pairdist_packed_targets_bytes
  *    is no longer 0 there), the `_packed_` entry points take an optional workspace
  *    (binf_pairdist_tiles_workspace_bytes: a wave per tile when there are few chains); binf_predictive_density_f64 / _workspace_bytes (the consumer side of the sample store: the
  *    posterior-predictive density over a grid of points in one launch). */
@@ -719,11 +720,20 @@ int32_t binf_pairdist_forward_f64(const double *x, const int32_t *pair_i,
  * pair-distance forward model + Gaussian error model, fused: the same bits as
  * binf_pairdist_forward_f64 followed by binf_gauss_err_logp_f64, without the
  * [C x n_pairs] distances going through HBM. */
+/* workspace (ABI 6; the three entry points below): with FEWER chains than CUs -- or more than
+ * 2048 beads -- a workgroup per chain walking the whole pair list leaves the chip idle (0.3 ms
+ * at 1024 beads, 1.2 ms at 2048, 18 ms at 4096, whatever the number of chains).  np.sum adds
+ * the sums of 8192-element chunks one after the other, so given
+ * binf_pairdist_chi2_workspace_bytes(C, n_beads, n_pairs) bytes of device memory (0 when that
+ * does not apply; NULL is always accepted -- only the speed changes) every chunk is a
+ * workgroup of its own and a second launch adds the chunk sums in order: the same bits. */
+int64_t binf_pairdist_chi2_workspace_bytes(int64_t C, int64_t n_beads, int64_t n_pairs);
 int32_t binf_pairdist_gauss_logp_f64(const double *x, const int32_t *pair_i,
                                      const int32_t *pair_j, const double *ys,
                                      double precision, const double *precision_chain,
                                      double *out, int64_t C, int64_t n_beads,
-                                     int64_t n_pairs, void *stream);
+                                     int64_t n_pairs, void *workspace,
+                                     int64_t workspace_bytes, void *stream);
 
 /* The same with a two-entry per-chain memo of chi^2 (it depends on the chain's coordinates
  * alone): memo_x [2 x C x 3 n_beads] / memo_chi2 [2 x C] / memo_state [2 x C] as in
@@ -735,7 +745,8 @@ int32_t binf_pairdist_gauss_logp_memo_f64(const double *x, const int32_t *pair_i
                                           double precision, const double *precision_chain,
                                           double *out, double *memo_x, double *memo_chi2,
                                           uint8_t *memo_state, int64_t C, int64_t n_beads,
-                                          int64_t n_pairs, void *stream);
+                                          int64_t n_pairs, void *workspace,
+                                          int64_t workspace_bytes, void *stream);
 
 /* HMCSampler.sample()'s energy (binf/samplers/hmc.py:143,148,150) for the restraint
  * posterior in ONE launch:
@@ -763,7 +774,8 @@ int32_t binf_pairdist_hmc_energy_f64(const double *x, const double *p, const int
                                      const double *extra1, double extra1_scalar,
                                      double *energy, double *log_prob, double *memo_x,
                                      double *memo_chi2, uint8_t *memo_state, int64_t C,
-                                     int64_t n_beads, int64_t n_pairs, void *stream);
+                                     int64_t n_beads, int64_t n_pairs, void *workspace, int64_t workspace_bytes,
+                                     void *stream);
 
 /* Energy gradient of the Gaussian restraint likelihood,
  *   out[c, 3i+a] = precision_c * sum_{j != i} (d_ij - ymat[j][i]) (x_i - x_j)[a] / d_ij,

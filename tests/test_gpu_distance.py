@@ -396,7 +396,8 @@ def test_few_chains_take_a_wave_per_tile_same_bits_as_the_ring_kernels(device, n
     C = 5
     need = L.binf_pairdist_tiles_workspace_bytes(C, n)
     assert need > 0 and L.binf_pairdist_tiles_workspace_bytes(100000, n) == 0
-    assert L.binf_pairdist_tiles_workspace_bytes(C, 256) == 0 and L.binf_pairdist_tiles_workspace_bytes(C, 1025) == 0
+    assert L.binf_pairdist_tiles_workspace_bytes(C, 256) == 0 and L.binf_pairdist_tiles_workspace_bytes(C, 4097) == 0
+    assert L.binf_pairdist_tiles_workspace_bytes(100000, 1025) == 0 and L.binf_pairdist_tiles_workspace_bytes(5000, 1025) > 0
     rs = np.random.RandomState(n)
     xx, tau = dev_t(x, device), dev_t(rs.uniform(0.5, 3.0, size=C), device)
     pp = lambda t: ctypes.c_void_p(t.data_ptr())
@@ -431,8 +432,124 @@ def test_few_chains_take_a_wave_per_tile_same_bits_as_the_ring_kernels(device, n
                                                  st) == _native.E_ALIAS
 
 
+@pytest.mark.parametrize('n,C', [(1025, 2), (1500, 3), (2048, 2), (3000, 1), (4096, 1)])
+def test_beyond_1024_beads_every_unordered_pair_once_as_a_wave_per_tile(device, n, C):
+    """1025..4096 beads: no workgroup-per-chain form exists, the tile kernels serve alone (packed
+    targets + workspace, both brought by the Python wrappers): force against the one-sided loops
+    to 1e-13 and against numpy (one chain) to 1e-12; the fused leapfrog -- one tile launch and one
+    update launch per force evaluation, inside ONE C-ABI call -- bit for bit the per-step sequence;
+    HMCSampler takes it through the registered kind."""
+    ys, x = synth(n, C, 17 * n)
+    lik = make_distance_likelihood(ys, n)
+    ymat = lik.error_model.ymat_device(device)
+    packed = _native.pairdist_pack_targets(ymat)
+    assert packed is not None and _native.lib().binf_pairdist_tiles_workspace_bytes(C, n) > 0
+    rs = np.random.RandomState(n)
+    xx, tau = dev_t(x, device), dev_t(rs.uniform(0.5, 3.0, size=C), device)
+    g = _native.pairdist_gauss_grad(xx, ymat, tau, packed=packed)
+    one_sided = _native.pairdist_gauss_grad(xx, ymat, tau)
+    assert float((g - one_sided).abs().max()) <= 1e-13 * float(one_sided.abs().max())
+    ym = ymat.cpu().numpy()
+    xc = x[0].reshape(n, 3)
+    dd = xc[:, None, :] - xc[None, :, :]
+    r = np.sqrt((dd ** 2).sum(-1))
+    np.fill_diagonal(r, 1.0)
+    w = 1.0 - ym / r
+    np.fill_diagonal(w, 0.0)
+    want = float(tau[0]) * (w[:, :, None] * dd).sum(1).reshape(-1)
+    assert np.abs(g[0].cpu().numpy() - want).max() <= 1e-12 * np.abs(want).max()
+    p0 = dev_t(rs.standard_normal((C, 3 * n)), device)
+    L, dt = 2, 1e-3
+    qa, pa = xx.clone(), p0.clone()
+    _native.pairdist_leapfrog(qa, pa, ymat, tau, (0.05, 0.1), True, dt, None, L, packed=packed)
+    qb, pb = xx.clone(), p0.clone()
+    force = lambda q: _native.sum_terms([_native.gauss_grad(q, 0.05, 0.1),
+                                         _native.pairdist_gauss_grad(q, ymat, tau, packed=packed)])
+    _native.leapfrog_kick(pb, force(qb), dt, None, half=True)
+    _native.leapfrog_drift(qb, pb, dt, None)
+    for _ in range(L - 1):
+        _native.leapfrog_kick_drift(qb, pb, force(qb), dt, None)
+    _native.leapfrog_kick(pb, force(qb), dt, None, half=True)
+    assert torch.equal(qa, qb) and torch.equal(pa, pb)
+    # without packed targets the fused call has nothing to offer beyond 1024 beads
+    with pytest.raises(NotImplementedError):
+        _native.pairdist_leapfrog(xx.clone(), p0.clone(), ymat, tau, None, False, dt, None, L)
+    # through the class stack: the fused leapfrog of the registered kind
+    prior = IsotropicGaussian(0.05, 0.1, name='coordinates_prior', variable_name='coordinates')
+    cond = Posterior({lik.name: lik}, {prior.name: prior}).conditional_factory(precision=2.0)
+    s = HMCSampler(cond, xx.clone(), 5e-4, 3, variable_name='coordinates', rng=DeviceRNG(1, device))
+    t = HMCSampler(cond, xx.clone(), 5e-4, 3, variable_name='coordinates', rng=DeviceRNG(1, device))
+    t.fused_leapfrog = False
+    assert torch.equal(s.sample(), t.sample()) and bool(s.last_move_accepted.any())
+
+
+@pytest.mark.parametrize('n,C', [(200, 3), (257, 5), (512, 2), (1000, 7), (1024, 1), (2048, 2), (2500, 2), (4096, 1)])
+def test_chi2_by_chunks_with_few_chains_same_bits(device, n, C):
+    """With fewer chains than CUs (or more than 2048 beads) the log-prob / energy entry points, given
+    the workspace the library asks for, make every 8192-pair chunk of np.sum a workgroup of its own
+    and add the chunk sums in order: bit for bit the workgroup-per-chain kernels (forced here through
+    the C ABI by withholding the workspace), the numpy restatement on one chain, the memo variant on
+    hits and misses, and the one-launch energy."""
+    import ctypes
+    ys, x = synth(n, C, 19 * n)
+    lik = make_distance_likelihood(ys, n)
+    I, J = lik.forward_model.pair_index(device)
+    ty = lik.error_model.ys_device(device)
+    P = I.numel()
+    L = _native.lib()
+    need = L.binf_pairdist_chi2_workspace_bytes(C, n, P)
+    assert need > 0 and L.binf_pairdist_chi2_workspace_bytes(C, 100, 4950) == 0       # a short pair list
+    assert L.binf_pairdist_chi2_workspace_bytes(100000, n, P) == 0 or n > 2048
+    rs = np.random.RandomState(n)
+    xx, tau = dev_t(x, device), dev_t(rs.uniform(0.5, 3.0, size=C), device)
+    pp = lambda t: ctypes.c_void_p(t.data_ptr())
+    st = _native.stream_handle(device)
+    ws = torch.empty(need // 8, dtype=torch.float64, device=device)
+
+    def logp(with_ws):
+        out = torch.empty(C, dtype=torch.float64, device=device)
+        rc = L.binf_pairdist_gauss_logp_f64(pp(xx), pp(I), pp(J), pp(ty), 0.0, pp(tau), pp(out), C, n, P,
+                                            pp(ws) if with_ws else None, need if with_ws else 0, st)
+        assert rc == 0
+        return out
+
+    a, b = logp(True), logp(False)
+    assert torch.equal(a, b) and torch.equal(_native.pairdist_gauss_logp(xx, I, J, ty, tau), a)
+    want = RD.DistancePosterior(ys, float(tau[0]), n).log_prob(coordinates=x[0]) if n <= 1024 else None
+    if want is not None:
+        assert float(a[0]) == want
+    # the memo variant: a miss stores the chunk-summed chi^2, a hit returns it, a changed chain misses
+    memo = _native.new_chi2_memo(C, 3 * n, device)
+    m1 = _native.pairdist_gauss_logp_memo(xx, I, J, ty, tau, memo)
+    m2 = _native.pairdist_gauss_logp_memo(xx, I, J, ty, tau * 2.0, memo)
+    assert torch.equal(m1, a) and torch.equal(m2, _native.pairdist_gauss_logp(xx, I, J, ty, tau * 2.0))
+    assert bool((memo[2][0] == 1).all())                                             # every chain a hit
+    moved = xx.clone()
+    moved[0, 0] += 1e-3
+    m3 = _native.pairdist_gauss_logp_memo(moved, I, J, ty, tau, memo)
+    assert torch.equal(m3, _native.pairdist_gauss_logp(moved, I, J, ty, tau)) and int(memo[2][0][0]) == 0
+    # the one-launch energy (up to 2048 beads): chi^2 by chunks inside, same bits as without
+    if n <= 2048:
+        p0 = dev_t(rs.standard_normal((C, 3 * n)), device)
+        kinds = (ctypes.c_int32 * 4)(0, 1, 1, 1)
+
+        def energy(with_ws):
+            e = torch.empty(C, dtype=torch.float64, device=device)
+            lp = torch.empty(C, dtype=torch.float64, device=device)
+            rc = L.binf_pairdist_hmc_energy_f64(pp(xx), pp(p0), pp(I), pp(J), pp(ty), 0.0, pp(tau), 0.05, 0.1, 2, kinds,
+                                                None, 0.0, None, 0.0, pp(e), pp(lp), None, None, None, C, n, P,
+                                                pp(ws) if with_ws else None, need if with_ws else 0, st)
+            assert rc == 0
+            return e, lp
+
+        (e1, l1), (e2, l2) = energy(True), energy(False)
+        assert torch.equal(e1, e2) and torch.equal(l1, l2)
+    assert L.binf_pairdist_gauss_logp_f64(pp(xx), pp(I), pp(J), pp(ty), 1.0, None, pp(ws), C, n, P, pp(ws), need,
+                                          st) == _native.E_ALIAS
+
+
 def test_bead_counts_without_a_packed_form(device):
-    for n in (8, 31, 1025, 1500):
+    for n in (8, 31, 4097, 5000):
         assert _native.lib().binf_pairdist_packed_targets_bytes(n) == 0
         ys, _ = synth(n, 1, n)
         em = make_distance_likelihood(ys, n).error_model

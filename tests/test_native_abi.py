@@ -113,7 +113,7 @@ def test_memo_entry_points_refuse_before_touching_the_memo():
                                          fake[5], fake[6], big, 4, 20, None)
     assert rc == _native.E_UNSUPPORTED and 'too large' in _native.last_error()
     rc = L.binf_pairdist_gauss_logp_memo_f64(fake[0], fake[1], fake[2], fake[3], 1.0, None, fake[4],
-                                             fake[5], fake[6], fake[7], big, 4, 6, None)
+                                             fake[5], fake[6], fake[7], big, 4, 6, None, 0, None)
     assert rc == _native.E_UNSUPPORTED and 'too large' in _native.last_error()
 
 
