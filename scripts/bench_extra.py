@@ -146,6 +146,36 @@ def c5_distance(dev, C=256, n=256, L=20):
             'timing': leg['timing']}
 
 
+def c5_more_beads(dev, L=20):
+    """The same model beyond the configured 256 beads, with the few chains structure inference
+    runs with: the symmetric force as ring kernels / a wave per tile, chi^2 by chunks (round 4);
+    HMCSampler.sample() through the class stack, device draws."""
+    from binf_amd.example.distance import make_distance_likelihood
+    from binf_amd.pdf import IsotropicGaussian
+    from binf_amd.pdf.posteriors import Posterior
+    from binf_amd.samplers.hmc import HMCSampler
+    from binf_amd.samplers.rng import DeviceRNG
+    out = {}
+    for n, C in ((1024, 32), (1024, 1024), (2048, 16), (4096, 8)):
+        rs = np.random.RandomState(0)
+        truth = rs.standard_normal((n, 3)) * 2.0
+        I, J = np.triu_indices(n, 1)
+        ys = np.abs(np.sqrt(np.sum((truth[I] - truth[J]) ** 2, axis=1)) + 0.05 * rs.standard_normal(len(I)))
+        x = torch.from_numpy(truth.reshape(-1)[None, :] + 0.1 * rs.standard_normal((C, 3 * n))).to(dev)
+        lik = make_distance_likelihood(ys, n)
+        prior = IsotropicGaussian(0.05, 0.0, name='coordinates_prior', variable_name='coordinates')
+        cond = Posterior({lik.name: lik}, {prior.name: prior}).conditional_factory(precision=4.0)
+        s = HMCSampler(cond, x, 0.001 if n <= 1024 else 0.0005, L, variable_name='coordinates', rng=DeviceRNG(0, dev))
+        t = _timed(s.sample, 8, warm=3)
+        out['%d beads x %d chains' % (n, C)] = {
+            'hmc_sample_ms': t * 1e3, 'chain_leapfrog_steps_per_s': C * L / t,
+            'unordered_pairs_per_s': C * (n * (n - 1) / 2.0) * (L + 1) / t,
+            'acceptance': float(s.acceptance_rate.mean())}
+    out['workload'] = ('pair-distance posterior beyond C5\'s 256 beads: HMCSampler.sample(), L=%d, device draws; '
+                       'start of round 4: 9.7 / 50 / 100 / 426 ms' % L)
+    return out
+
+
 def c5_gibbs(dev, C=256, n=256, L=20):
     """C5's model inside the reference's Gibbs scheme: HMC on the coordinates + the conjugate
     Gamma draw of one precision per chain (example/distance.py: make_restraint_gibbs_sampler)."""
@@ -330,6 +360,7 @@ def run_all(dev, kstats=None):
     for name, fn in (('C3', c3_polynomial), ('C4', c4_gibbs), ('C5', c5_distance),
                      ('C5_2048_chains', lambda d: c5_distance(d, C=2048)),
                      ('C5_gibbs', c5_gibbs),
+                     ('C5_more_beads', c5_more_beads),
                      ('C1_gibbs', c1_gibbs),
                      ('C2_device_rng', c2_device_rng),
                      ('C2_strong_scaling_shares', c2_strong_scaling_shares)):
