@@ -124,6 +124,13 @@ def test_example_distance_restraints_keeps_the_structure(device):
     kept = _load_example('distance_restraints').main(
         ['--chains', '8', '--beads', '40', '--iterations', '40', '--thin', '10', '--gibbs'])
     assert kept.shape == (4, 8, 120) and torch.isfinite(kept).all()
+    # beyond 256 beads with the few chains structure inference runs with: the symmetric force as a
+    # wave per tile, chi^2 by chunks (700 beads: 11 blocks, ghosts in the last one)
+    kept = _load_example('distance_restraints').main(
+        ['--chains', '6', '--beads', '700', '--iterations', '40', '--thin', '10', '--timestep', '0.001'])
+    assert kept.shape == (4, 6, 2100) and torch.isfinite(kept).all()
+    x = kept[-1].reshape(6, 700, 3)
+    assert float((x[:, 1:] - x[:, :-1]).norm(dim=-1).mean()) > 0.5        # a structure, not a collapsed point
 
 
 def test_example_custom_pdf_samples_both_wells(device):
@@ -135,6 +142,9 @@ def test_example_custom_pdf_samples_both_wells(device):
     assert 0.5 < float(s.acceptance_rate.mean()) <= 1.0
     assert abs(float((x > 0).double().mean()) - 0.5) < 0.02
     assert 0.8 < float(x.abs().mean()) < 1.1
+    # the same run with every transition replayed from one HIP graph: the same chains
+    g = _load_example('custom_pdf').main(['--chains', '512', '--dims', '32', '--draws', '300', '--graph'])
+    assert len(g._graphs) == 1 and torch.equal(g.state, x) and torch.equal(g.n_accepted, s.n_accepted)
 
 
 def test_gibbs_launches_with_two_different_moves_agree_on_the_posterior(device):
