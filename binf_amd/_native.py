@@ -1143,6 +1143,11 @@ def _pairdist_tiles_workspace(C, n, packed, device):
     key = (device, stream_handle(device))
     ws = _tiles_ws.get(key)
     if ws is None or ws.numel() * 8 < need:
+        # scratch, not state: never more than a quarter of what is free (many chains of several
+        # thousand beads would ask for tens of GB) -- without it the library takes its other kernels
+        _tiles_ws.pop(key, None)
+        if need > torch.cuda.mem_get_info(device)[0] // 4:
+            return None, 0
         ws = _tiles_ws[key] = torch.empty(need // 8, dtype=torch.float64, device=device)
     return ws.data_ptr(), ws.numel() * 8
 

@@ -287,9 +287,12 @@ def leapfrog(sampler, spec, q2, p2, dt, dtc, nsteps, mode, q_from):
     packed = getattr(em, 'ypacked_device', None)
     n = q2.shape[1] // 3
     # beyond 1024 beads only as a wave per tile: packed targets + the library's workspace
-    if q2.shape[1] % 3 != 0 or (n > 1024 and (packed is None or packed(q2.device) is None or
-                                              _native.lib().binf_pairdist_tiles_workspace_bytes(q2.shape[0], n) <= 0)):
+    if q2.shape[1] % 3 != 0:
         return False
+    if n > 1024:
+        pk = packed(q2.device) if packed is not None else None
+        if pk is None or _native._pairdist_tiles_workspace(q2.shape[0], n, pk, q2.device)[1] <= 0:
+            return False                   # no packed form / no room for the scratch: the per-step tier
     qf = None
     if q_from is not None:
         qf = q_from
