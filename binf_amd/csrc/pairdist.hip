@@ -1255,7 +1255,7 @@ __global__ void __launch_bounds__(1024) pairdist_leapfrog_sym_kernel(const PairL
 //    512 beads, shared by all chains and resident in L2).
 // ---------------------------------------------------------------------------
 constexpr int RING_MAX_BEADS = 1024;     // a workgroup (<= 16 waves) per chain
-constexpr int TILES_MAX_BEADS = 4096;    // a wave per tile: any number of blocks (packed targets: 64 MiB here)
+constexpr int TILES_MAX_BEADS = 8192;    // a wave per tile: any number of blocks (packed targets: 256 MiB here)
 constexpr int RING_CHUNK = 8;            // steps whose targets are in flight / in use at a time
                                          // (4: -2 %, 16: -8 % at 512 .. 1024 beads, same-box A/B)
 

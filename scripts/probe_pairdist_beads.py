@@ -14,7 +14,7 @@ out = {}
 import os
 SHAPES = ((256, 256), (256, 2048), (384, 256), (512, 256), (512, 1024), (1024, 256), (1024, 1024))
 if os.environ.get('PROBE_BIG'):
-    SHAPES = ((1500, 64), (2048, 16), (2048, 128), (4096, 8), (4096, 64))
+    SHAPES = ((1500, 64), (2048, 16), (2048, 128), (4096, 8), (4096, 64), (8192, 8))
 elif os.environ.get('PROBE_RAGGED'):
     SHAPES = ((500, 256), (500, 1024), (512, 1024), (1000, 256), (1000, 1024), (1024, 1024), (700, 512))
 for n, C in SHAPES:

@@ -396,7 +396,7 @@ def test_few_chains_take_a_wave_per_tile_same_bits_as_the_ring_kernels(device, n
     C = 5
     need = L.binf_pairdist_tiles_workspace_bytes(C, n)
     assert need > 0 and L.binf_pairdist_tiles_workspace_bytes(100000, n) == 0
-    assert L.binf_pairdist_tiles_workspace_bytes(C, 256) == 0 and L.binf_pairdist_tiles_workspace_bytes(C, 4097) == 0
+    assert L.binf_pairdist_tiles_workspace_bytes(C, 256) == 0 and L.binf_pairdist_tiles_workspace_bytes(C, 8193) == 0
     assert L.binf_pairdist_tiles_workspace_bytes(100000, 1025) == 0 and L.binf_pairdist_tiles_workspace_bytes(5000, 1025) > 0
     rs = np.random.RandomState(n)
     xx, tau = dev_t(x, device), dev_t(rs.uniform(0.5, 3.0, size=C), device)
@@ -432,9 +432,9 @@ def test_few_chains_take_a_wave_per_tile_same_bits_as_the_ring_kernels(device, n
                                                  st) == _native.E_ALIAS
 
 
-@pytest.mark.parametrize('n,C', [(1025, 2), (1500, 3), (2048, 2), (3000, 1), (4096, 1)])
+@pytest.mark.parametrize('n,C', [(1025, 2), (1500, 3), (2048, 2), (3000, 1), (4096, 1), (8192, 1)])
 def test_beyond_1024_beads_every_unordered_pair_once_as_a_wave_per_tile(device, n, C):
-    """1025..4096 beads: no workgroup-per-chain form exists, the tile kernels serve alone (packed
+    """1025..8192 beads: no workgroup-per-chain form exists, the tile kernels serve alone (packed
     targets + workspace, both brought by the Python wrappers): force against the one-sided loops
     to 1e-13 and against numpy (one chain) to 1e-12; the fused leapfrog -- one tile launch and one
     update launch per force evaluation, inside ONE C-ABI call -- bit for bit the per-step sequence;
@@ -549,7 +549,7 @@ def test_chi2_by_chunks_with_few_chains_same_bits(device, n, C):
 
 
 def test_bead_counts_without_a_packed_form(device):
-    for n in (8, 31, 4097, 5000):
+    for n in (8, 31, 8193, 9000):
         assert _native.lib().binf_pairdist_packed_targets_bytes(n) == 0
         ys, _ = synth(n, 1, n)
         em = make_distance_likelihood(ys, n).error_model
