@@ -78,12 +78,21 @@ def _dist(device, C=11, n=100):
         cond.log_prob
 
 
-def _dist_onesided(device):
-    return _dist(device, C=3, n=300)          # above 256 beads: the one-sided force loops
+def _dist_tiles(device):
+    return _dist(device, C=3, n=300)          # above 256 beads, few chains: a wave per 64 x 64 tile
+
+
+def _dist_ring(device):
+    return _dist(device, C=200, n=320)        # ... many chains: a workgroup per chain (ring kernels)
+
+
+def _dist_big(device):
+    return _dist(device, C=2, n=1500)         # beyond 1024 beads: tiles only, chi^2 by chunks
 
 
 MODELS = {'gaussian': _gauss, 'polynomial': _poly, 'polynomial_mfma': _poly_big, 'distance': _dist,
-          'distance_300_beads': _dist_onesided}
+          'distance_300_beads': _dist_tiles, 'distance_320_beads_ring': _dist_ring,
+          'distance_1500_beads': _dist_big}
 
 
 # The fifth entry of a model is the log-probability whose derivative the FORCE is.  For the
@@ -184,3 +193,28 @@ def test_accept_rule_and_rejected_chains(device, model):
         if seen == {True, False}:
             break
     assert seen == {True, False}
+
+
+@pytest.mark.parametrize('n,C', [(100, 5), (256, 3), (300, 3), (320, 200), (700, 4), (1024, 150), (1500, 2), (4096, 1)])
+def test_pair_forces_obey_newtons_third_law(device, n, C):
+    """The restraint forces are pair forces along the connecting lines: whatever the kernel (every
+    unordered pair once in registers / ring phases / a wave per tile, or the one-sided loops), the
+    net force and the net torque on a chain vanish, to rounding -- a pair counted twice, dropped,
+    or booked to the wrong bead shows up here at once."""
+    from binf_amd import _native
+    rs = np.random.RandomState(n)
+    truth = rs.standard_normal((n, 3)) * 2.0
+    I, J = np.triu_indices(n, 1)
+    ys = np.abs(np.sqrt(((truth[I] - truth[J]) ** 2).sum(1)) + 0.3 * rs.standard_normal(len(I)))
+    lik = make_distance_likelihood(ys, n)
+    x = _t(truth.reshape(1, -1) + 0.3 * rs.standard_normal((C, 3 * n)), device)
+    f = lik.gradient(coordinates=x, precision=3.0).reshape(C, n, 3)
+    r = x.reshape(C, n, 3)
+    scale = f.abs().sum(dim=(1, 2))
+    assert bool((f.sum(dim=1).abs().max(dim=1).values <= 1e-12 * scale).all())
+    torque = torch.cross(r, f, dim=2).sum(dim=1)
+    assert bool((torque.abs().max(dim=1).values <= 1e-11 * (r.abs().max() * scale)).all())
+    # ... and a rigid translation of a chain changes no force by more than rounding
+    g = lik.gradient(coordinates=(r + _t(np.array([3.0, -2.0, 0.5]), device)).reshape(C, 3 * n).contiguous(),
+                     precision=3.0).reshape(C, n, 3)
+    assert float((g - f).abs().max()) <= 1e-10 * float(f.abs().max())
