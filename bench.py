@@ -627,6 +627,7 @@ def main():
 
     acc_rate = float(sampler.acceptance_rate.mean())
     gather_ms = None
+    gather_error = None
 
     # Outside the metric: the same workload in the other arithmetic mode ('fma'
     # contracts each multiply-add; within 1e-10 of 'exact', not bit-identical).
@@ -654,24 +655,31 @@ def main():
                             device=dev if backend == 'nccl' else 'cpu')
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax[0])
-        # the only collective of the path: gather one recorded draw (RCCL)
-        from binf_amd.dist import gather_chains
-        state = sampler.state if backend == 'nccl' else sampler.state.cpu()
-        gather_chains(state)
-        barrier()
-        t1 = time.perf_counter()
-        for _ in range(5):
+        # the only collective of the path: gather one recorded draw (RCCL); a backend that refuses
+        # it costs the two gather figures, not the line
+        gather_ms = gather_dst0_ms = None
+        try:
+            from binf_amd.dist import gather_chains
+            state = sampler.state if backend == 'nccl' else sampler.state.cpu()
             gather_chains(state)
-        barrier()
-        gather_ms = (time.perf_counter() - t1) / 5 * 1e3
-        # gather to rank 0 only (what writing the samples out needs)
-        gather_chains(state, dst=0)
-        barrier()
-        t1 = time.perf_counter()
-        for _ in range(5):
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(5):
+                gather_chains(state)
+            barrier()
+            gather_ms = (time.perf_counter() - t1) / 5 * 1e3
+            # gather to rank 0 only (what writing the samples out needs)
             gather_chains(state, dst=0)
-        barrier()
-        gather_dst0_ms = (time.perf_counter() - t1) / 5 * 1e3
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(5):
+                gather_chains(state, dst=0)
+            barrier()
+            gather_dst0_ms = (time.perf_counter() - t1) / 5 * 1e3
+        except Exception as e:                      # noqa: BLE001
+            gather_error = '%s: %s' % (type(e).__name__, e)
+        else:
+            gather_error = None
         # what every rank saw: the line is self-checking for the driver's first SCALE run
         mine = {'rank': rank, 'world_size_seen': dist.get_world_size(), 'backend': dist.get_backend(),
                 'device': '%s:%d' % (torch.cuda.get_device_name(dev_index), dev_index),
@@ -691,8 +699,11 @@ def main():
         torch.cuda.empty_cache()
         from scripts import bench_legs
         comm = bench_legs.Comm(dist, backend, dev)
-        legs = bench_legs.run_legs(dev, comm, scaling=args.scaling)
-        if args.scaling == 'weak' and F > 1:
+        try:
+            legs = bench_legs.run_legs(dev, comm, scaling=args.scaling)
+        except Exception as e:                      # noqa: BLE001 -- never breaks the headline
+            legs = {'error': 'run_legs: %s: %s' % (type(e).__name__, e)}
+        if args.scaling == 'weak' and F > 1 and 'error' not in legs:
             try:
                 legs['C2_strong'] = c2_strong_leg(args, comm, dev, F, thin, D, L)
             except Exception as e:                  # noqa: BLE001 -- never breaks the headline
@@ -811,10 +822,12 @@ def main():
             'acceptance_rate': acc_rate,
             'roofline': roof,
         }
-        if gather_ms is not None:
+        if multi:
             res['sample_gather_ms'] = gather_ms
             res['sample_gather_to_rank0_ms'] = gather_dst0_ms
             res['sample_gather_bytes_per_rank'] = C * D * 8
+            if gather_error is not None:
+                res['sample_gather_error'] = gather_error
             res['ranks'] = per_rank
         if sustained is not None:
             res['value_sustained'] = sustained['value_per_gpu'] * world if not multi else \

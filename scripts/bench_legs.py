@@ -364,7 +364,10 @@ def run_legs(dev, comm, scaling='weak', c4_sweeps=20, c5_sweeps=100):
         if errs:
             out[name] = {'error': errs[0], 'ranks_failed': len(errs)}
         else:
-            out[name] = run_leg(leg, comm, sweeps, thin=thin)
+            try:
+                out[name] = run_leg(leg, comm, sweeps, thin=thin)
+            except Exception as e:            # noqa: BLE001 -- e.g. a collective refused by the backend:
+                out[name] = {'error': 'run_leg: %s: %s' % (type(e).__name__, e)}    # the headline still prints
         del leg
         if torch.device(dev).type == 'cuda':
             torch.cuda.empty_cache()
