@@ -16,13 +16,18 @@
 //   5 the same call captured into a hipGraph and replayed (include/binf_hip.h: "safe
 //     inside hipGraph stream capture")
 //   6 argument errors come back as codes with a text, nothing is thrown or printed
-// Build: hipcc -O2 tests/cabi/host_check.cpp -o tests/cabi/host_check -ldl
+//   7 four host threads, each with a stream of its own, call concurrently (the header's
+//     "stateless and re-entrant"): every thread's chain of transitions == the oracle's,
+//     and binf_last_error is per thread
+// Build: hipcc -O2 tests/cabi/host_check.cpp -o tests/cabi/host_check -ldl -lpthread
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <atomic>
+#include <thread>
 #include <vector>
 #include "../../include/binf_hip.h"
 
@@ -282,6 +287,52 @@ int main(int argc, char **argv)
                           1.05, 0.95, 0, st);
         check(rc == 0, "6 zero chains is a no-op");
         HIP(hipStreamSynchronize(st));
+    }
+    // 7: concurrent callers
+    {
+        const int T = 4, ROUNDS = 8;
+        std::atomic<int> bad(0), err_mixed(0);
+        std::vector<std::thread> th;
+        for (int t = 0; t < T; ++t)
+            th.emplace_back([&, t] {
+                const int64_t C = 20 + 17 * t, D = (t & 1) ? 1024 : 520;
+                const int L = 5 + t;
+                uint64_t z = 77 + t;
+                auto unit = [&z] {
+                    z = z * 6364136223846793005ull + 1442695040888963407ull;
+                    return (double)(z >> 11) * (1.0 / 9007199254740992.0);
+                };
+                std::vector<double> q(C * D), p(C * D), u(C);
+                for (auto &x : q) x = 3.0 * unit() - 1.5;
+                for (auto &x : p) x = 3.0 * unit() - 1.5;
+                for (auto &x : u) x = unit();
+                hipStream_t s2;
+                HIP(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+                Dev<double> da(q), db(C * D), dp(p), du(u);
+                Dev<uint8_t> df(C);
+                int rc = 0;
+                for (int i = 0; i < ROUNDS; ++i)
+                    rc |= sample_gauss(i & 1 ? db.p : da.p, dp.p, du.p, i & 1 ? da.p : db.p, df.p, nullptr, nullptr,
+                                       nullptr, 0.13, nullptr, C, D, L, 1.5, 0.25, 0, 1.05, 0.95, t & 1, s2);
+                // an error of THIS thread's own, raised while the others are computing
+                char msg[128] = "";
+                int e = sample_gauss(da.p, dp.p, du.p, db.p, df.p, nullptr, nullptr, nullptr, 0.13, nullptr, C, D, L,
+                                     1.5, 0.25, 0, 1.05, 0.95, 40 + t, s2);
+                last_error(msg, sizeof msg);
+                char want[32];
+                snprintf(want, sizeof want, "mode %d", 40 + t);
+                if (e != BINF_E_ARG || !strstr(msg, want)) ++err_mixed;
+                HIP(hipStreamSynchronize(s2));
+                std::vector<double> qq = q;
+                for (int i = 0; i < ROUNDS; ++i)
+                    qq = oracle_call(oracle[t & 1], qq, p.data(), u.data(), std::vector<double>(C, 0.13), C, D, L, 1.5,
+                                     0.25, 0).q;
+                if (rc || !same(da.get(), qq)) ++bad;
+                HIP(hipStreamDestroy(s2));
+            });
+        for (auto &x : th) x.join();
+        check(bad.load() == 0, "7 concurrent callers == oracle");
+        check(err_mixed.load() == 0, "7 binf_last_error is the calling thread's");
     }
     HIP(hipStreamDestroy(st));
     if (n_failed) { printf("FAILED %d of %d checks\n", n_failed, n_checks); return 1; }
