@@ -77,6 +77,9 @@ def parse(argv=None):
                          'the C4 / C5 legs then shard their BASELINE totals (32768 / 2048 chains)')
     ap.add_argument('--no-legs', action='store_true',
                     help='with --gpus N > 1: skip the sharded C4 / C5 legs')
+    ap.add_argument('--legs-timeout', type=float, default=300.0,
+                    help='with --gpus N > 1: seconds the sharded legs may take before rank 0 prints '
+                         'the headline line without them (LineGuard)')
     ap.add_argument('--dims', type=int, default=1024)
     ap.add_argument('--nsteps', type=int, default=20, help='leapfrog steps')
     ap.add_argument('--timestep', type=float, default=0.05)
@@ -308,6 +311,45 @@ def pmc_traffic_committed(C, D, L, F, thin, mode):
 
 
 # ---------------------------------------------------------------------------
+class LineGuard:
+    """The optional multi-rank sections (the sharded C4 / C5 legs) run under this guard: if
+    they have not finished after ``seconds`` -- one rank failed on its own and the others
+    wait in a collective for it -- rank 0 prints the headline line it already holds, with
+    the reason in place of the legs, and every rank leaves with exit code 0.  A hang there
+    costs the legs, never the N-GPU value."""
+
+    def __init__(self, res, seconds, what='the sharded legs'):
+        import threading
+        self.res, self.seconds, self.what = res, seconds, what
+        self.lock = threading.Lock()
+        self.done = False
+        self.timer = threading.Timer(seconds, self._fire)
+        self.timer.daemon = True
+        self.timer.start()
+
+    def _fire(self):
+        with self.lock:
+            if self.done:
+                return
+            self.done = True
+            if self.res is not None:
+                self.res['extra'] = {'error': '%s did not finish within %g s (a rank failed or a '
+                                              'collective hung); every field of the headline above '
+                                              'was complete before they started'
+                                              % (self.what, self.seconds)}
+                print(json.dumps(self.res), flush=True)
+            else:
+                time.sleep(3.0)                     # rank 0 prints first
+            sys.stdout.flush()
+            os._exit(0)
+
+    def finish(self):
+        with self.lock:                             # blocks for good if the timer is printing
+            self.done = True
+        self.timer.cancel()
+
+
+# ---------------------------------------------------------------------------
 def dry_run(args, rank, world):
     """BINF_BENCH_DRYRUN=1: the multi-rank control flow without a GPU (CPU test
     suite): rendezvous, barrier, MAX over ranks, the sample gather -- no sampling."""
@@ -335,14 +377,22 @@ def dry_run(args, rank, world):
                            torch.device('cpu'))
     start, count = shard_chains(args.chains if args.scaling == 'strong' else args.chains * world,
                                 rank, world)
+    res = None
+    if rank == 0:
+        res = {'dry_run': True, 'n_gpus': world, 'steps': args.steps,
+               'warmup': args.warmup, 'max_elapsed': elapsed,
+               'gathered_rows': None if gathered is None else int(gathered.shape[0]),
+               'scaling': args.scaling, 'shard': [start, count], 'value': None}
+    guard = LineGuard(res, args.legs_timeout) if world > 1 else None
+    if os.environ.get('BINF_BENCH_DRYRUN_HANG_RANK') == str(rank):
+        time.sleep(3600)                            # test hook: this rank never reaches the leg
     leg = bench_legs.StandInLeg(comm, chains_per_gpu=args.chains, scaling=args.scaling)
     legs = {'stand_in': bench_legs.run_leg(leg, comm, sweeps=6, warm=1, thin=2, settle_s=0.0)}
+    if guard is not None:
+        guard.finish()
     if rank == 0:
-        print(json.dumps({'dry_run': True, 'n_gpus': world, 'steps': args.steps,
-                          'warmup': args.warmup, 'max_elapsed': elapsed,
-                          'gathered_rows': None if gathered is None else int(gathered.shape[0]),
-                          'scaling': args.scaling, 'shard': [start, count],
-                          'extra': legs, 'value': None}), flush=True)
+        res['extra'] = legs
+        print(json.dumps(res), flush=True)
     if world > 1:
         dist.destroy_process_group()
 
@@ -690,25 +740,7 @@ def main():
         per_rank = [None] * world
         dist.all_gather_object(per_rank, mine)
 
-    # The sharded C4 / C5 legs (every rank: they hold barriers and the sample gather), and --
-    # in a weak-scaling run -- the C2 job of FIXED size (--chains in all) sharded over the same
-    # ranks: SURVEY 8(e)'s secondary, strong-scaling figure from the same invocation.
-    legs = None
-    if multi and not args.no_legs and not args.no_extra:
-        del p_bufs, u_bufs, rec_bufs
-        torch.cuda.empty_cache()
-        from scripts import bench_legs
-        comm = bench_legs.Comm(dist, backend, dev)
-        try:
-            legs = bench_legs.run_legs(dev, comm, scaling=args.scaling)
-        except Exception as e:                      # noqa: BLE001 -- never breaks the headline
-            legs = {'error': 'run_legs: %s: %s' % (type(e).__name__, e)}
-        if args.scaling == 'weak' and F > 1 and 'error' not in legs:
-            try:
-                legs['C2_strong'] = c2_strong_leg(args, comm, dev, F, thin, D, L)
-            except Exception as e:                  # noqa: BLE001 -- never breaks the headline
-                legs['C2_strong'] = {'error': '%s: %s' % (type(e).__name__, e)}
-
+    res = None
     if rank == 0:
         transitions = K * F
         steps_total = float(C_total) * L * transitions
@@ -838,6 +870,30 @@ def main():
                                         'the ranks)' % args.sustain_ms}
         if other is not None:
             res['other_mode'] = other
+
+    # The sharded C4 / C5 legs (every rank: they hold barriers and the sample gather), and --
+    # in a weak-scaling run -- the C2 job of FIXED size (--chains in all) sharded over the same
+    # ranks: SURVEY 8(e)'s secondary, strong-scaling figure from the same invocation.
+    legs = None
+    if multi and not args.no_legs and not args.no_extra:
+        del p_bufs, u_bufs, rec_bufs
+        torch.cuda.empty_cache()
+        from scripts import bench_legs
+        comm = bench_legs.Comm(dist, backend, dev)
+        guard = LineGuard(res, args.legs_timeout)
+        try:
+            legs = bench_legs.run_legs(dev, comm, scaling=args.scaling)
+        except Exception as e:                      # noqa: BLE001 -- never breaks the headline
+            legs = {'error': 'run_legs: %s: %s' % (type(e).__name__, e)}
+        if args.scaling == 'weak' and F > 1 and 'error' not in legs:
+            try:
+                legs['C2_strong'] = c2_strong_leg(args, comm, dev, F, thin, D, L)
+            except Exception as e:                  # noqa: BLE001 -- never breaks the headline
+                legs['C2_strong'] = {'error': '%s: %s' % (type(e).__name__, e)}
+        guard.finish()
+
+
+    if rank == 0:
         if not multi and not args.no_extra:
             # free the C2 buffers first (the sub-results allocate their own)
             del p_bufs, u_bufs, rec_bufs, sampler

@@ -99,3 +99,20 @@ def test_single_rank_dry_run_needs_no_process_group():
     res = json.loads(r.stdout.decode().strip().splitlines()[-1])
     assert res['n_gpus'] == 1 and res['steps'] == 20 and res['warmup'] == 5
     _check_leg(res['extra']['stand_in'], world=1, total=4096)
+
+
+def test_a_rank_that_never_reaches_the_legs_costs_the_legs_not_the_line():
+    """bench.py's LineGuard: rank 1 hangs before the sharded legs (test hook), rank 0 waits
+    for it in the leg's first collective -- after --legs-timeout rank 0 prints the line it
+    already held, with the reason in place of the legs, and both ranks leave with code 0."""
+    r = subprocess.run([sys.executable, BENCH, '--gpus', '2', '--steps', '3', '--warmup', '1',
+                        '--chains', '6', '--legs-timeout', '4'],
+                       env=_env(BINF_BENCH_DRYRUN='1', BINF_BENCH_BACKEND='gloo',
+                                BINF_BENCH_DRYRUN_HANG_RANK='1'),
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    lines = [l for l in r.stdout.decode().splitlines() if l.startswith('{')]
+    assert len(lines) == 1
+    res = json.loads(lines[0])
+    assert res['n_gpus'] == 2 and res['max_elapsed'] == 2.0 and res['gathered_rows'] == 12
+    assert 'did not finish within 4 s' in res['extra']['error']
