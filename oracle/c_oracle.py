@@ -38,7 +38,37 @@ def lib():
                                          ctypes.c_double, ctypes.c_int32,
                                          ctypes.c_double, ctypes.c_double,
                                          ctypes.c_int32])
+        _lib.oracle_polyval.restype = ctypes.c_int
+        _lib.oracle_polyval.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int64] * 3
+        _lib.oracle_poly_gauss_logp.restype = ctypes.c_int
+        _lib.oracle_poly_gauss_logp.argtypes = [ctypes.c_void_p] * 6 + [ctypes.c_int64] * 3
     return _lib
+
+
+def polyval(xs, coeffs):
+    """``[C, N]``: numpy.polynomial.polynomial.polyval(xs, coeffs[c]) per row (oracle_c.c)."""
+    xs = np.ascontiguousarray(xs, dtype=np.float64)
+    co = np.ascontiguousarray(np.atleast_2d(coeffs), dtype=np.float64)
+    out = np.empty((co.shape[0], xs.size))
+    rc = lib().oracle_polyval(xs.ctypes.data, co.ctypes.data, out.ctypes.data, co.shape[0], co.shape[1], xs.size)
+    if rc != 0:
+        raise ValueError('oracle_polyval rc=%d' % rc)
+    return out
+
+
+def poly_gauss_logp(coeffs, xs, ys, precision):
+    """(log_prob [C], chi2 [C]) of the polynomial + Gaussian likelihood (oracle_c.c)."""
+    xs = np.ascontiguousarray(xs, dtype=np.float64)
+    ys = np.ascontiguousarray(ys, dtype=np.float64)
+    co = np.ascontiguousarray(np.atleast_2d(coeffs), dtype=np.float64)
+    C = co.shape[0]
+    pr = np.ascontiguousarray(np.broadcast_to(np.asarray(precision, dtype=np.float64), (C,))).copy()
+    out, chi2 = np.empty(C), np.empty(C)
+    rc = lib().oracle_poly_gauss_logp(co.ctypes.data, xs.ctypes.data, ys.ctypes.data, pr.ctypes.data,
+                                      out.ctypes.data, chi2.ctypes.data, C, co.shape[1], xs.size)
+    if rc != 0:
+        raise ValueError('oracle_poly_gauss_logp rc=%d' % rc)
+    return out, chi2
 
 
 def np_sum(a):

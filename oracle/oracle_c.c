@@ -184,3 +184,56 @@ int oracle_hmc_sample_gauss_fma(const double *q0, const double *p0, const double
     return hmc_sample_gauss(q0, p0, u, q_out, accepted, e_before, e_after, dt, C, D, nsteps, k, x0,
                             adapt, uprate, downrate, nthreads, 1);
 }
+
+/* ---------------------------------------------------------------------------
+ * The example's polynomial model (BASELINE C1 / C3 / C4), the parts whose bits are numpy's.
+ *
+ * ForwardModel._evaluate (binf/example/likelihood.py:24-26) with
+ * numpy.polynomial.polynomial.polyval as the `polynomial` (example_script.py:21): Horner from the
+ * highest coefficient, c0 = c[-1] + x*0;  c0 = c[-i] + c0*x  (oracle/ref_numpy.py:225-233).
+ * out[c*N + n] = polyval(xs[n], coeffs[c*K ...]).
+ */
+int oracle_polyval(const double *xs, const double *coeffs, double *out, int64_t C, int64_t K, int64_t N)
+{
+    if (C < 0 || K < 1 || N < 0) return -1;
+    for (int64_t c = 0; c < C; c++) {
+        const double *co = coeffs + c * K;
+        for (int64_t n = 0; n < N; n++) {
+            const double x = xs[n];
+            double c0 = co[K - 1] + x * 0;
+            for (int64_t i = 2; i <= K; i++) c0 = co[K - i] + c0 * x;
+            out[c * N + n] = c0;
+        }
+    }
+    return 0;
+}
+
+/*
+ * Likelihood._evaluate_log_prob (binf/pdf/likelihoods.py:141-146) for that forward model and
+ * GaussianErrorModel._evaluate_log_prob (binf/example/likelihood.py:54-57):
+ *   -0.5 * np.sum((mock - ys)**2) * precision + len(ys) * 0.5 * np.log(precision)
+ * np.sum in numpy's order (oracle_np_sum); `log` is this host's libm -- numpy's own log differs
+ * between CPUs, so only precisions whose log is exact (1, 2, 4 ...) make the LAST term a fixed
+ * bit pattern; chi^2 and its scaling always are.  chi2_out (may be NULL) receives np.sum(...).
+ */
+int oracle_poly_gauss_logp(const double *coeffs, const double *xs, const double *ys, const double *precision,
+                           double *out, double *chi2_out, int64_t C, int64_t K, int64_t N)
+{
+    if (C < 0 || K < 1 || N < 1) return -1;
+    double *mock = (double *)malloc(sizeof(double) * (size_t)N);
+    if (!mock) return -2;
+    for (int64_t c = 0; c < C; c++) {
+        oracle_polyval(xs, coeffs + c * K, mock, 1, K, N);
+        for (int64_t n = 0; n < N; n++) {
+            const double d = mock[n] - ys[n];
+            mock[n] = d * d;
+        }
+        const double chi2 = oracle_np_sum(mock, N);
+        const double p = precision[c];
+        const double logZ = (double)N * 0.5 * log(p);
+        out[c] = -0.5 * chi2 * p + logZ;
+        if (chi2_out) chi2_out[c] = chi2;
+    }
+    free(mock);
+    return 0;
+}

@@ -14,6 +14,10 @@ int oracle_hmc_sample_gauss(const double *q0, const double *p0, const double *u,
                             int64_t C, int64_t D, int32_t nsteps, double k, double x0, int32_t adapt,
                             double uprate, double downrate, int32_t nthreads);
 
+int oracle_polyval(const double *xs, const double *coeffs, double *out, int64_t C, int64_t K, int64_t N);
+int oracle_poly_gauss_logp(const double *coeffs, const double *xs, const double *ys, const double *precision,
+                           double *out, double *chi2_out, int64_t C, int64_t K, int64_t N);
+
 static double rnd(uint64_t *s)
 {
     *s ^= *s << 13; *s ^= *s >> 7; *s ^= *s << 17;
@@ -53,6 +57,22 @@ int main(void)
         }
         free(q0); free(p0); free(qo); free(u); free(eb); free(ea); free(dt); free(acc);
     }
+    const int64_t pshapes[][3] = {{1, 1, 1}, {3, 4, 20}, {2, 33, 129}, {2, 9, 8193}, {4, 2, 7}};
+    for (unsigned i = 0; i < sizeof(pshapes) / sizeof(pshapes[0]); ++i) {
+        const int64_t C = pshapes[i][0], K = pshapes[i][1], N = pshapes[i][2];
+        double *co = (double *)malloc(sizeof(double) * C * K), *xs = (double *)malloc(sizeof(double) * N);
+        double *ys = (double *)malloc(sizeof(double) * N), *mock = (double *)malloc(sizeof(double) * C * N);
+        double *pr = (double *)malloc(sizeof(double) * C), *lp = (double *)malloc(sizeof(double) * C);
+        double *chi2 = (double *)malloc(sizeof(double) * C);
+        for (int64_t j = 0; j < C * K; ++j) co[j] = rnd(&s);
+        for (int64_t j = 0; j < N; ++j) { xs[j] = rnd(&s); ys[j] = rnd(&s); }
+        for (int64_t c = 0; c < C; ++c) pr[c] = 1.5 + rnd(&s);
+        if (oracle_polyval(xs, co, mock, C, K, N) != 0) return 4;
+        if (oracle_poly_gauss_logp(co, xs, ys, pr, lp, (i & 1) ? chi2 : NULL, C, K, N) != 0) return 5;
+        for (int64_t c = 0; c < C; ++c) check += mock[c * N + N - 1] + lp[c];
+        free(co); free(xs); free(ys); free(mock); free(pr); free(lp); free(chi2);
+    }
+    if (oracle_polyval(NULL, NULL, NULL, 1, 0, 1) == 0) return 6;       /* K < 1 must be refused */
     if (oracle_hmc_sample_gauss(NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, 1, 0, 1, 1.0, 0.0, 0, 1.05,
                                 0.95, 1) == 0) return 2;               /* D < 1 must be refused */
     printf("sanitized oracle run ok (%.17g)\n", check);

@@ -16,12 +16,16 @@
 //   5 the same call captured into a hipGraph and replayed (include/binf_hip.h: "safe
 //     inside hipGraph stream capture")
 //   6 argument errors come back as codes with a text, nothing is thrown or printed
+//   8 the polynomial model (binf/example/likelihood.py:24-26, 54-57): forward bit for bit,
+//     log-prob bit for bit where log(precision) is exact, to an ulp of N/2 log(precision)
+//     otherwise (the device library's log), rows longer than numpy's 8192-element buffer too
 //   7 four host threads, each with a stream of its own, call concurrently (the header's
 //     "stateless and re-entrant"): every thread's chain of transitions == the oracle's,
 //     and binf_last_error is per thread
 // Build: hipcc -O2 tests/cabi/host_check.cpp -o tests/cabi/host_check -ldl -lpthread
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
+#include <math.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -61,7 +65,12 @@ static decltype(&binf_leapfrog_kick_drift_f64) kick_drift;
 static decltype(&binf_gauss_grad_f64) gauss_grad;
 static decltype(&binf_clipped_exp_f64) clipped_exp;
 static decltype(&binf_accept_select_f64) accept_select;
+static decltype(&binf_poly_forward_f64) poly_forward;
+static decltype(&binf_poly_gauss_logp_f64) poly_logp;
 
+typedef int (*oracle_polyval_fn)(const double *, const double *, double *, int64_t, int64_t, int64_t);
+typedef int (*oracle_poly_logp_fn)(const double *, const double *, const double *, const double *, double *,
+                                   double *, int64_t, int64_t, int64_t);
 typedef int (*oracle_fn)(const double *, const double *, const double *, double *, uint8_t *,
                          double *, double *, double *, int64_t, int64_t, int32_t, double, double,
                          int32_t, double, double, int32_t);
@@ -80,6 +89,8 @@ static void bind(void *h)
     gauss_grad = sym<decltype(gauss_grad)>(h, "binf_gauss_grad_f64");
     clipped_exp = sym<decltype(clipped_exp)>(h, "binf_clipped_exp_f64");
     accept_select = sym<decltype(accept_select)>(h, "binf_accept_select_f64");
+    poly_forward = sym<decltype(poly_forward)>(h, "binf_poly_forward_f64");
+    poly_logp = sym<decltype(poly_logp)>(h, "binf_poly_gauss_logp_f64");
 }
 
 // splitmix64 -> doubles: the inputs only have to be the same on both sides
@@ -287,6 +298,42 @@ int main(int argc, char **argv)
                           1.05, 0.95, 0, st);
         check(rc == 0, "6 zero chains is a no-op");
         HIP(hipStreamSynchronize(st));
+    }
+    // 8: the polynomial model
+    {
+        oracle_polyval_fn o_polyval = sym<oracle_polyval_fn>(ho, "oracle_polyval");
+        oracle_poly_logp_fn o_logp = sym<oracle_poly_logp_fn>(ho, "oracle_poly_gauss_logp");
+        struct PShape { int64_t C, K, N; };
+        const PShape ps[] = {{7, 4, 20}, {3, 33, 700}, {2, 9, 16389}, {5, 1, 64}, {300, 17, 129}};
+        for (const PShape &s : ps) {
+            std::vector<double> co(s.C * s.K), xs(s.N), ys(s.N), tau(s.C);
+            fill(co, -1.5, 1.5); fill(xs, -1.0, 1.0); fill(ys, -2.0, 2.0); fill(tau, 0.3, 6.0);
+            Dev<double> dco(co), dxs(xs), dys(ys), dtau(tau), dmock(s.C * s.N), dlp(s.C);
+            std::vector<double> want(s.C * s.N);
+            o_polyval(xs.data(), co.data(), want.data(), s.C, s.K, s.N);
+            int rc = poly_forward(dco.p, dxs.p, dmock.p, s.C, s.K, s.N, st);
+            HIP(hipStreamSynchronize(st));
+            check(rc == 0 && same(dmock.get(), want), "8 polynomial forward == oracle");
+            for (double p : {1.0, 2.0, 0.25}) {
+                std::vector<double> pr(s.C, p), lp(s.C);
+                o_logp(co.data(), xs.data(), ys.data(), pr.data(), lp.data(), nullptr, s.C, s.K, s.N);
+                rc = poly_logp(dco.p, dxs.p, dys.p, p, nullptr, dlp.p, s.C, s.K, s.N, st);
+                HIP(hipStreamSynchronize(st));
+                check(rc == 0 && same(dlp.get(), lp), "8 log-prob == oracle (log(precision) exact)");
+            }
+            std::vector<double> lp(s.C);
+            o_logp(co.data(), xs.data(), ys.data(), tau.data(), lp.data(), nullptr, s.C, s.K, s.N);
+            rc = poly_logp(dco.p, dxs.p, dys.p, 0.0, dtau.p, dlp.p, s.C, s.K, s.N, st);
+            HIP(hipStreamSynchronize(st));
+            std::vector<double> got = dlp.get();
+            bool ok = rc == 0;
+            for (int64_t c = 0; c < s.C; ++c) {
+                const double logz = fabs((double)s.N * 0.5 * log(tau[c]));
+                const double tol = 4e-16 * (logz > fabs(lp[c]) ? logz : fabs(lp[c]));
+                ok &= fabs(got[c] - lp[c]) <= tol;
+            }
+            check(ok, "8 log-prob, one precision per chain: within an ulp of N/2 log(precision)");
+        }
     }
     // 7: concurrent callers
     {

@@ -72,3 +72,23 @@ def test_restated_example_loop_reproduces_the_reference_subsamplers_bitwise(path
     assert out['acceptance_rate'] == g['acceptance_rate'][-1]
     assert R.gamma_shape(len(g['xs']), RE.PRIOR_SHAPE) == float(g['gamma_shape'])   # the "- 1" of samplers.py:32
     assert 0.05 < g['accepted'].mean() < 0.95
+
+
+@pytest.mark.parametrize('path', MODELS, ids=ident)
+def test_c_restatement_of_the_polynomial_model_reproduces_the_reference_bitwise(path):
+    """oracle/oracle_c.c: oracle_polyval / oracle_poly_gauss_logp -- the checker of the Python-free
+    host program (tests/cabi/host_check.cpp) -- against what the reference's own ForwardModel /
+    GaussianErrorModel code produced (likelihood.py:24-26, 54-57): mock data bit for bit, the
+    log-prob at unit precision bit for bit (log(1) = 0), at the fixture's precisions to an ulp of
+    the N/2 log(precision) term (C's log and numpy's are different functions)."""
+    from oracle import c_oracle
+    g = load_golden(path)
+    xs, ys, theta, taus = g['xs'], g['ys'], g['theta'], g['precision']
+    st = int(g['mock_stride'])
+    assert np.array_equal(c_oracle.polyval(xs, theta)[:, ::st], g['mock'])
+    lp1, chi2 = c_oracle.poly_gauss_logp(theta, xs, ys, 1.0)
+    assert np.array_equal(lp1, g['error_logp_unit_precision'])
+    assert np.array_equal(-0.5 * chi2 * 1.0 + 0.0, lp1)
+    lp, _ = c_oracle.poly_gauss_logp(theta, xs, ys, taus)
+    logz = np.abs(len(xs) * 0.5 * np.log(taus))
+    assert np.all(np.abs(lp - g['error_logp']) <= 4e-16 * np.maximum(logz, np.abs(lp)))
