@@ -27,7 +27,8 @@ constexpr int JT_LD = JT_N + 1;   // padded LDS row (doubles)
 
 // ---- shared Jacobian: out[c][k] = sum_n r[c][n] J[k][n] ------------------------
 // A workgroup owns 16 chains x 16 RT rows of J.  Per tile of 64 data points the
-// rows of J and of r are staged in LDS with coalesced 512-byte row segments; wave
+// rows of J and of r are staged in LDS with coalesced 512-byte row segments (the next
+// tile prefetched into registers, two LDS images, one barrier per tile); wave
 // w multiplies the tile's data points 16 w .. 16 w + 15 (four k-steps of the
 // 16x16x4 f64 MFMA: A[m = row of J][k = n], B[k = n][col = chain]).  The four
 // waves' accumulators are joined at the end in the order (w0 + w1) + (w2 + w3).
@@ -36,12 +37,12 @@ __global__ void __launch_bounds__(256)
 jac_shared_mfma_kernel(const double *__restrict__ r, const double *__restrict__ J,
                        double *__restrict__ out, int64_t C, int32_t K, int32_t N)
 {
-    // the accumulator exchange at the end reuses the tile of J
+    // two LDS images of a tile (rows of J, rows of r): tile t + 1 is written while tile t is
+    // multiplied, ONE barrier per tile; the accumulator exchange at the end reuses image 0
     constexpr int SJ_N = 16 * RT * JT_LD, SACC_N = 4 * 16 * RT * 17;
-    __shared__ double sbuf[SJ_N > SACC_N ? SJ_N : SACC_N];
-    __shared__ double sR[16][JT_LD];
-    double (*sJ)[JT_LD] = reinterpret_cast<double (*)[JT_LD]>(sbuf);
-    double (*sAcc)[16 * RT][17] = reinterpret_cast<double (*)[16 * RT][17]>(sbuf);
+    __shared__ double sbuf[2][SJ_N > SACC_N ? SJ_N : SACC_N];
+    __shared__ double sRb[2][16][JT_LD];
+    double (*sAcc)[16 * RT][17] = reinterpret_cast<double (*)[16 * RT][17]>(sbuf[0]);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lc = lane & 15, lk = lane >> 4;
     const int64_t c0 = (int64_t)blockIdx.x * 16;
@@ -50,30 +51,46 @@ jac_shared_mfma_kernel(const double *__restrict__ r, const double *__restrict__ 
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) acc[rt] = (v4d){0.0, 0.0, 0.0, 0.0};
     const int col = tid & 63, row0 = tid >> 6;              // staging: 4 rows per pass
-    for (int n0 = 0; n0 < N; n0 += JT_N) {
+    // the NEXT tile's rows travel in registers while this tile's products run (a workgroup walks
+    // its N / 64 tiles in sequence: without the prefetch every tile paid a full HBM latency)
+    double pj[4 * RT], pr[4];
+    auto fetch = [&](int n0) {
         const int n = n0 + col;
         const bool nv = n < N;
 #pragma unroll
         for (int p = 0; p < 4 * RT; ++p) {
-            const int kr = 4 * p + row0;
-            const int k = k0 + kr;
-            sJ[kr][col] = (nv && k < K) ? J[(int64_t)k * N + n] : 0.0;
+            const int k = k0 + 4 * p + row0;
+            pj[p] = (nv && k < K) ? J[(int64_t)k * N + n] : 0.0;
         }
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
-            const int cr = 4 * p + row0;
-            const int64_t c = c0 + cr;
-            sR[cr][col] = (nv && c < C) ? r[c * N + n] : 0.0;
+            const int64_t c = c0 + 4 * p + row0;
+            pr[p] = (nv && c < C) ? r[c * N + n] : 0.0;
         }
-        __syncthreads();
+    };
+    auto stage = [&](int b) {
+        double (*sJ)[JT_LD] = reinterpret_cast<double (*)[JT_LD]>(sbuf[b]);
+#pragma unroll
+        for (int p = 0; p < 4 * RT; ++p) sJ[4 * p + row0][col] = pj[p];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) sRb[b][4 * p + row0][col] = pr[p];
+    };
+    fetch(0);
+    stage(0);
+    __syncthreads();
+    int b = 0;
+    for (int n0 = 0; n0 < N; n0 += JT_N, b ^= 1) {
+        fetch(n0 + JT_N);                                   // beyond N: nothing is loaded
+        double (*sJ)[JT_LD] = reinterpret_cast<double (*)[JT_LD]>(sbuf[b]);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const int nn = 16 * wave + 4 * s + lk;
-            const double bv = sR[lc][nn];
+            const double bv = sRb[b][lc][nn];
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt)
                 acc[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(sJ[16 * rt + lc][nn], bv, acc[rt], 0, 0, 0);
         }
+        stage(b ^ 1);                                       // every wave left that image a barrier ago
         __syncthreads();
     }
     // D layout: row (of J) = lk + 4 i, column (chain) = lc
@@ -168,6 +185,8 @@ extern "C" int32_t binf_jacobian_contract_f64(const double *jacobian, const doub
             jac_shared_mfma_kernel<1><<<dim3((unsigned)ctiles, 1), 256, 0, st>>>(emgrad, jacobian, out, C, (int32_t)K, (int32_t)N);
         else if (K <= 32)
             jac_shared_mfma_kernel<2><<<dim3((unsigned)ctiles, 1), 256, 0, st>>>(emgrad, jacobian, out, C, (int32_t)K, (int32_t)N);
+        else if (K <= 48)
+            jac_shared_mfma_kernel<3><<<dim3((unsigned)ctiles, 1), 256, 0, st>>>(emgrad, jacobian, out, C, (int32_t)K, (int32_t)N);
         else {
             const int64_t kblocks = (K + 63) / 64;
             if (kblocks > 65535) return fail(BINF_E_UNSUPPORTED, "jacobian_contract: too many parameters");
