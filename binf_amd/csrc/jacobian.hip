@@ -108,6 +108,83 @@ jac_shared_mfma_kernel(const double *__restrict__ r, const double *__restrict__ 
     }
 }
 
+// The same with 32 chains per workgroup of 8 waves: waves 0-3 multiply the tile of J with
+// chains 0-15, waves 4-7 with chains 16-31 -- every workgroup streams all of J through L2, so
+// twice the chains per workgroup is half of that traffic (at C3's size it is twice the bytes
+// of the residuals themselves).  Same order of a chain's sums, same bits.
+template <int RT>
+__global__ void __launch_bounds__(512)
+jac_shared_mfma32_kernel(const double *__restrict__ r, const double *__restrict__ J,
+                         double *__restrict__ out, int64_t C, int32_t K, int32_t N)
+{
+    constexpr int SJ_N = 16 * RT * JT_LD, SACC_N = 8 * 16 * RT * 17;
+    __shared__ double sbuf[2 * SJ_N > SACC_N ? 2 * SJ_N : SACC_N];
+    __shared__ double sRb[2][32][JT_LD];
+    double (*sAcc)[16 * RT][17] = reinterpret_cast<double (*)[16 * RT][17]>(sbuf);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = wave >> 2, w4 = wave & 3;
+    const int lc = lane & 15, lk = lane >> 4;
+    const int64_t c0 = (int64_t)blockIdx.x * 32;
+    const int k0 = blockIdx.y * 16 * RT;
+    v4d acc[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) acc[rt] = (v4d){0.0, 0.0, 0.0, 0.0};
+    const int col = tid & 63, row0 = tid >> 6;              // staging: 8 rows per pass
+    double pj[2 * RT], pr[4];
+    auto fetch = [&](int n0) {
+        const int n = n0 + col;
+        const bool nv = n < N;                              // beyond N: nothing is loaded
+#pragma unroll
+        for (int p = 0; p < 2 * RT; ++p) {
+            const int k = k0 + 8 * p + row0;
+            pj[p] = (nv && k < K) ? J[(int64_t)k * N + n] : 0.0;
+        }
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int64_t c = c0 + 8 * p + row0;
+            pr[p] = (nv && c < C) ? r[c * N + n] : 0.0;
+        }
+    };
+    auto stage = [&](int b) {
+        double (*sJ)[JT_LD] = reinterpret_cast<double (*)[JT_LD]>(sbuf + b * SJ_N);
+#pragma unroll
+        for (int p = 0; p < 2 * RT; ++p) sJ[8 * p + row0][col] = pj[p];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) sRb[b][8 * p + row0][col] = pr[p];
+    };
+    fetch(0);
+    stage(0);
+    __syncthreads();
+    int b = 0;
+    for (int n0 = 0; n0 < N; n0 += JT_N, b ^= 1) {
+        fetch(n0 + JT_N);
+        double (*sJ)[JT_LD] = reinterpret_cast<double (*)[JT_LD]>(sbuf + b * SJ_N);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int nn = 16 * w4 + 4 * s + lk;
+            const double bv = sRb[b][16 * half + lc][nn];
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+                acc[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(sJ[16 * rt + lc][nn], bv, acc[rt], 0, 0, 0);
+        }
+        stage(b ^ 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) sAcc[wave][16 * rt + lk + 4 * i][lc] = acc[rt][i];
+    __syncthreads();
+    for (int e = tid; e < 2 * 16 * RT * 16; e += 512) {
+        const int h = e / (16 * RT * 16), kr = (e >> 4) % (16 * RT), cc = e & 15;
+        const int k = k0 + kr;
+        const int64_t c = c0 + 16 * h + cc;
+        if (k < K && c < C)
+            out[c * K + k] = (sAcc[4 * h][kr][cc] + sAcc[4 * h + 1][kr][cc]) +
+                             (sAcc[4 * h + 2][kr][cc] + sAcc[4 * h + 3][kr][cc]);
+    }
+}
+
 // ---- per-chain Jacobian: out[c][k] = sum_n J[c][k][n] r[c][n] -------------------
 // One workgroup per chain; wave w owns rows k = w, w + 4, ...; lane l adds the
 // products of n = l, l + 64, ... in order (coalesced 512-byte row segments), the
@@ -158,6 +235,17 @@ __global__ void __launch_bounds__(256) sum_terms_kernel(const SumTermsArgs a, do
     }
 }
 
+// development aid: BINF_JAC_CHAINS=16 keeps the 16-chain workgroups (A/B, bit-equality tests)
+static bool jac_force16()
+{
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("BINF_JAC_CHAINS");
+        v = (e && atoi(e) == 16) ? 1 : 0;
+    }
+    return v == 1;
+}
+
 }  // namespace binf
 
 using namespace binf;
@@ -180,6 +268,16 @@ extern "C" int32_t binf_jacobian_contract_f64(const double *jacobian, const doub
     } else {
         const int64_t ctiles = (C + 15) / 16;
         if (ctiles > 0x7fffffffLL) return fail(BINF_E_UNSUPPORTED, "jacobian_contract: too many chains");
+        // enough chains for a 32-chain workgroup on every CU, and enough data points for J's
+        // traffic to matter: the 8-wave kernel (half the reads of J)
+        const int64_t ctiles32 = (C + 31) / 32;
+        if (ctiles32 >= 256 && N >= 1024 && K <= 64 && !jac_force16()) {
+            const dim3 g32((unsigned)ctiles32, 1);
+            if (K <= 16) jac_shared_mfma32_kernel<1><<<g32, 512, 0, st>>>(emgrad, jacobian, out, C, (int32_t)K, (int32_t)N);
+            else if (K <= 32) jac_shared_mfma32_kernel<2><<<g32, 512, 0, st>>>(emgrad, jacobian, out, C, (int32_t)K, (int32_t)N);
+            else if (K <= 48) jac_shared_mfma32_kernel<3><<<g32, 512, 0, st>>>(emgrad, jacobian, out, C, (int32_t)K, (int32_t)N);
+            else jac_shared_mfma32_kernel<4><<<g32, 512, 0, st>>>(emgrad, jacobian, out, C, (int32_t)K, (int32_t)N);
+        } else
         // up to 64 rows of J per workgroup (the residual tile is read once for them)
         if (K <= 16)
             jac_shared_mfma_kernel<1><<<dim3((unsigned)ctiles, 1), 256, 0, st>>>(emgrad, jacobian, out, C, (int32_t)K, (int32_t)N);

@@ -81,6 +81,26 @@ def test_contraction_order_does_not_depend_on_the_batch(device):
     assert one.shape == (K,) and torch.equal(one, full[7])
 
 
+@pytest.mark.parametrize('K,N', [(5, 1024), (20, 1100), (33, 2049), (50, 1024), (64, 1500)])
+def test_big_batches_take_32_chain_workgroups_with_the_same_bits(device, K, N):
+    """From 8192 chains and 1024 data points up a shared Jacobian is contracted by workgroups of
+    32 chains / 8 waves (csrc/jacobian.hip: half the reads of J through L2): a chain's sums are
+    formed in the same order as in the 16-chain workgroups a small batch takes -- the first, a
+    middle and the last (ragged) chains recomputed as small batches equal the big run's rows bit
+    for bit -- and match numpy within the bar."""
+    C = 8192 + 17
+    rs = np.random.RandomState(K * 1000 + N)
+    J, r = rs.standard_normal((K, N)), rs.standard_normal((C, N))
+    tJ, tr = dev_t(J, device), dev_t(r, device)
+    full = _native.jacobian_contract(tJ, tr)
+    for lo, hi in ((0, 40), (4090, 4130), (C - 49, C), (C - 1, C)):
+        part = _native.jacobian_contract(tJ, tr[lo:hi].contiguous())
+        assert torch.equal(part, full[lo:hi])
+    want = r[:64].dot(J.T)
+    bound = 1e-10 * np.abs(r[:64]).dot(np.abs(J).T)
+    assert np.all(np.abs(full[:64].cpu().numpy() - want) <= bound)
+
+
 def test_contraction_argument_checks(device):
     J = torch.zeros((3, 5), dtype=torch.float64, device=device)
     with pytest.raises(ValueError):
