@@ -297,7 +297,10 @@ def test_multi_sweep_gibbs_launch_stays_inside_its_buffers(device, K, N, C, n, t
 
 
 @pytest.mark.parametrize('K,N,C,batched', [(1, 1, 1, False), (17, 65, 17, False), (33, 1000, 20, True),
-                                           (65, 129, 3, False), (5, 63, 9, True), (64, 64, 16, False)])
+                                           (65, 129, 3, False), (5, 63, 9, True), (64, 64, 16, False),
+                                           # from 8192 chains x 1024 points up: 32 chains per workgroup
+                                           (33, 1025, 8197, False), (16, 1024, 8193, False),
+                                           (49, 1100, 8200, False), (64, 1030, 8223, False)])
 def test_contraction_and_term_sum_stay_inside_their_buffers(device, K, N, C, batched):
     rs = np.random.RandomState(K + N + C)
     J = rs.standard_normal((C, K, N) if batched else (K, N))
