@@ -11,7 +11,7 @@ step() {                                  # step <seconds> <name> <args...>
     tail -1 $O/$name.log
     return $rc
 }
-step 400 fuzz_models 1500 ${2:-91} && step 400 fuzz_gauss 20000 $((${2:-91}+1)) && step 200 fuzz_reductions 12000 $((${2:-91}+2)) && step 300 fuzz_gibbs_n 25000 $((${2:-91}+3)) && step 300 fuzz_graph 20000 $((${2:-91}+4)) && step 400 fuzz_pairdist_big 600 $((${2:-91}+5))
+step 400 fuzz_models 1500 ${2:-91} && step 400 fuzz_gauss 20000 $((${2:-91}+1)) && step 200 fuzz_reductions 12000 $((${2:-91}+2)) && step 300 fuzz_gibbs_n 25000 $((${2:-91}+3)) && step 300 fuzz_graph 20000 $((${2:-91}+4)) && step 400 fuzz_pairdist_big 600 $((${2:-91}+5)) && step 300 fuzz_contract 200 $((${2:-91}+6))
 rc=$?
 grep -c MISMATCH $O/*.log || true
 exit $rc
