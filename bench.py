@@ -311,6 +311,30 @@ def pmc_traffic_committed(C, D, L, F, thin, mode):
 
 
 # ---------------------------------------------------------------------------
+# stdout carries ONE line.  Libraries write there too -- RCCL a version banner when its first
+# communicator is made, gloo its connection messages -- so a rank hands its C-level stdout over to
+# stderr as it starts and writes the JSON line to the descriptor it kept.
+_LINE_FD = None
+
+
+def claim_stdout():
+    global _LINE_FD
+    if _LINE_FD is None:
+        sys.stdout.flush()
+        _LINE_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(res):
+    line = (json.dumps(res) + '\n').encode()
+    if _LINE_FD is None:
+        sys.stdout.write(line.decode())
+        sys.stdout.flush()
+    else:
+        os.write(_LINE_FD, line)
+
+
+# ---------------------------------------------------------------------------
 class LineGuard:
     """The optional multi-rank sections (the sharded C4 / C5 legs) run under this guard: if
     they have not finished after ``seconds`` -- one rank failed on its own and the others
@@ -337,7 +361,7 @@ class LineGuard:
                                               'collective hung); every field of the headline above '
                                               'was complete before they started'
                                               % (self.what, self.seconds)}
-                print(json.dumps(self.res), flush=True)
+                emit(self.res)
             else:
                 time.sleep(3.0)                     # rank 0 prints first
             sys.stdout.flush()
@@ -392,7 +416,7 @@ def dry_run(args, rank, world):
         guard.finish()
     if rank == 0:
         res['extra'] = legs
-        print(json.dumps(res), flush=True)
+        emit(res)
     if world > 1:
         dist.destroy_process_group()
 
@@ -450,6 +474,7 @@ def main():
     in_dist = 'WORLD_SIZE' in os.environ and 'RANK' in os.environ
     if args.gpus > 1 and not in_dist:
         self_launch(args, argv)
+    claim_stdout()
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -911,7 +936,7 @@ def main():
         if not multi and not args.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline(D, L, dt, args.cpu_chains,
                                                args.cpu_calls)
-        print(json.dumps(res), flush=True)
+        emit(res)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -26,6 +26,9 @@ def test_self_launch_two_ranks_gloo_dry_run():
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     lines = [l for l in r.stdout.decode().splitlines() if l.startswith('{')]
     assert len(lines) == 1                       # rank 0 only
+    # ... and nothing else on stdout: what libraries print there (gloo's connection lines, RCCL's
+    # version banner on the GPU) is sent to stderr (bench.py: claim_stdout)
+    assert r.stdout.decode().strip().splitlines() == lines
     res = json.loads(lines[0])
     assert res['dry_run'] is True and res['n_gpus'] == 2
     assert res['steps'] == 3 and res['warmup'] == 1
